@@ -1,0 +1,102 @@
+"""ctypes binding of include/icpgpu.h (libicpgpu.so).  Fails loudly when the HIP library is missing:
+there is no CPU or PyTorch fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicpgpu.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_NO_INPUT, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+P2P_SVD, GICP = 0, 1
+NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+STATE_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
+               5: "NO_CORRESPONDENCES"}
+
+
+class Params(C.Structure):
+    _fields_ = [("method", C.c_int32), ("max_iterations", C.c_int32), ("transformation_epsilon", C.c_double),
+                ("max_correspondence_distance", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
+                ("min_correspondences", C.c_int32), ("force_iterations", C.c_int32), ("nn_mode", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32),
+                ("convergence_state", C.c_int32), ("n_correspondences", C.c_uint32), ("mse_last", C.c_double),
+                ("fitness", C.c_double), ("t_total_ms", C.c_double), ("t_device_ms", C.c_double)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("nn_launches", C.c_uint64), ("nn_ms", C.c_double), ("nn_pairs", C.c_uint64),
+                ("nn_bytes", C.c_uint64), ("reduce_launches", C.c_uint64), ("reduce_ms", C.c_double),
+                ("reduce_bytes", C.c_uint64), ("transform_launches", C.c_uint64), ("transform_ms", C.c_double),
+                ("transform_bytes", C.c_uint64), ("iterations", C.c_uint64), ("aligns", C.c_uint64)]
+
+
+# every symbol include/icpgpu.h declares (tests/test_abi.py checks the header against this list)
+EXPORTS = [
+    "icpgpu_create", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params",
+    "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
+    "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
+    "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
+    "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_get_stream", "icpgpu_synchronize",
+]
+
+_lib = None
+
+
+class IcpGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"icpgpu error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """dlopen libicpgpu.so and declare the prototypes. Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C icpslam_amd/csrc`). icpslam_amd has no fallback path.")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing only
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.icpgpu_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.icpgpu_destroy.argtypes = [vp]
+    L.icpgpu_last_error.argtypes = [vp]
+    L.icpgpu_last_error.restype = C.c_char_p
+    L.icpgpu_version.argtypes = []
+    L.icpgpu_default_params.argtypes = [C.POINTER(Params)]
+    L.icpgpu_default_params.restype = None
+    L.icpgpu_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.icpgpu_get_params.argtypes = [vp, C.POINTER(Params)]
+    L.icpgpu_set_source.argtypes = [vp, fp, C.c_size_t]
+    L.icpgpu_set_target.argtypes = [vp, fp, C.c_size_t]
+    L.icpgpu_set_source_device.argtypes = [vp, vp, C.c_size_t]
+    L.icpgpu_set_target_device.argtypes = [vp, vp, C.c_size_t]
+    L.icpgpu_promote_source_to_target.argtypes = [vp]
+    L.icpgpu_align.argtypes = [vp, fp, fp, C.c_int, C.POINTER(Result)]
+    L.icpgpu_fitness.argtypes = [vp, C.c_double, dp]
+    L.icpgpu_align_batch.argtypes = [vp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp),
+                                     C.POINTER(C.c_size_t), C.c_int, C.POINTER(Result)]
+    L.icpgpu_nn.argtypes = [vp, fp, ip, fp]
+    L.icpgpu_reduce.argtypes = [vp, fp, C.c_double, dp]
+    L.icpgpu_solve.argtypes = [dp, dp]
+    L.icpgpu_transform.argtypes = [vp, fp, fp]
+    L.icpgpu_profile_reset.argtypes = [vp]
+    L.icpgpu_profile_get.argtypes = [vp, C.POINTER(Profile)]
+    L.icpgpu_get_stream.argtypes = [vp, C.POINTER(vp)]
+    L.icpgpu_synchronize.argtypes = [vp]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("icpgpu_last_error", "icpgpu_default_params"):
+            fn.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,550 @@
+// icpgpu_api.cpp -- the C-ABI of libicpgpu.so (include/icpgpu.h): context, buffers, the ICP iteration loop.
+//
+// Host side of the hot path behind the PCL Registration protocol used at
+//   /root/reference/src/icpslam/icp_odometer.cpp:188-201 and src/icpslam/octree_mapper.cpp:104-117.
+// Per iteration: [fill keys] -> NN kernel (a2) -> reduce kernels (a3+a4) -> 136-byte D2H -> host SVD (a5) + convergence
+// test (a7).  The source cloud is never rewritten: every kernel applies the accumulated transform on load (a6 fused).
+// There is deliberately no CPU fallback: if HIP or the device is unusable every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/icpgpu.h"
+#include "icp_kernels.h"
+#include "icp_solver.h"
+
+using namespace icpgpu;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;      // bytes owned (0 when external)
+  bool external = false;
+};
+
+struct Cloud {
+  DeviceBuf buf;
+  size_t n = 0;
+  bool set = false;
+  const float4* data() const { return static_cast<const float4*>(buf.ptr); }
+};
+
+}  // namespace
+
+struct icpgpu_ctx {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  icpgpu_params params{};
+  Cloud src, tgt;
+  DeviceBuf keys, partials, sums, out, idx, d2;
+  double* h_sums = nullptr;  // pinned
+  bool have_final = false;
+  Mat4d final_T = mat4_identity();
+  icpgpu_profile prof{};
+  int nn_variant = 0;
+  std::string err;
+};
+
+namespace {
+
+int fail(icpgpu_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(c, expr)                                                                              \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail((c), e_ == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "%s failed: %s", #expr, \
+                  hipGetErrorString(e_));                                                             \
+  } while (0)
+
+int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes) {
+  if (b.external) {
+    b.ptr = nullptr;
+    b.cap = 0;
+    b.external = false;
+  }
+  if (bytes <= b.cap) return ICPGPU_OK;
+  if (b.ptr) HIP_TRY(c, hipFree(b.ptr));
+  b.ptr = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4;  // amortise growth across scans of slightly different size
+  if (want < 256) want = 256;
+  HIP_TRY(c, hipMalloc(&b.ptr, want));
+  b.cap = want;
+  return ICPGPU_OK;
+}
+
+void release(DeviceBuf& b) {
+  if (b.ptr && !b.external) (void)hipFree(b.ptr);
+  b = DeviceBuf{};
+}
+
+Xform to_xform(const Mat4d& T) {
+  float f[16];
+  mat4_to_float(T, f);
+  Xform x;
+  for (int r = 0; r < 3; ++r) {
+    x.m[4 * r + 0] = f[0 * 4 + r];
+    x.m[4 * r + 1] = f[1 * 4 + r];
+    x.m[4 * r + 2] = f[2 * 4 + r];
+    x.m[4 * r + 3] = f[3 * 4 + r];
+  }
+  return x;
+}
+
+Xform to_xform(const float* T) {
+  Mat4d m;
+  for (int i = 0; i < 16; ++i) m[i] = T ? (double)T[i] : (i % 5 == 0 ? 1.0 : 0.0);
+  return to_xform(m);
+}
+
+// largest float f with (double)f <= r2, so that the device's float compare equals PCL's double compare
+float threshold_from(double r2) {
+  if (std::isnan(r2)) return NAN;
+  if (r2 >= (double)FLT_MAX) return FLT_MAX;
+  if (r2 < 0.0) return -1.0f;
+  float f = (float)r2;
+  if ((double)f > r2) f = std::nextafterf(f, -INFINITY);
+  return f;
+}
+
+int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n) {
+  if (n > 0 && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  int rc = ensure(c, cl.buf, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) {
+    HIP_TRY(c, hipMemcpyAsync(cl.buf.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free xyzw as soon as we return
+  }
+  cl.n = n;
+  cl.set = true;
+  return ICPGPU_OK;
+}
+
+int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
+  if (n > 0 && !d_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null device pointer with n = %zu", n);
+  if (((uintptr_t)d_xyzw & 15u) != 0) return fail(c, ICPGPU_ERR_INVALID_ARG, "device cloud must be 16-byte aligned");
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  release(cl.buf);
+  cl.buf.ptr = const_cast<void*>(d_xyzw);
+  cl.buf.external = true;
+  cl.n = n;
+  cl.set = true;
+  return ICPGPU_OK;
+}
+
+struct SweepTimes {
+  float nn_ms = 0.f, reduce_ms = 0.f;
+};
+
+// One NN sweep + reduction with transform T; leaves the 17 sums in c->h_sums. Synchronises the stream.
+int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, SweepTimes* times) {
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  int rc = ensure(c, c->keys, (size_t)(n_s ? n_s : 1) * sizeof(unsigned long long));
+  if (rc) return rc;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
+  if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, T, plan, keys, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, static_cast<double*>(c->partials.ptr),
+                           static_cast<double*>(c->sums.ptr), c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.ptr, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  SweepTimes t;
+  HIP_TRY(c, hipEventElapsedTime(&t.nn_ms, c->ev[0], c->ev[1]));
+  HIP_TRY(c, hipEventElapsedTime(&t.reduce_ms, c->ev[1], c->ev[2]));
+  c->prof.nn_launches += (n_s > 0);
+  c->prof.nn_ms += t.nn_ms;
+  c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
+  c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  c->prof.reduce_launches += 1;
+  c->prof.reduce_ms += t.reduce_ms;
+  c->prof.reduce_bytes += 40ull * (uint64_t)n_s + 136;
+  if (times) *times = t;
+  return ICPGPU_OK;
+}
+
+int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {
+  const int n_s = (int)c->src.n;
+  if (!out_xyzw || n_s == 0) return ICPGPU_OK;
+  int rc = ensure(c, c->out, (size_t)n_s * sizeof(float4));
+  if (rc) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_transform(c->src.data(), n_s, T, static_cast<float4*>(c->out.ptr), c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->out.ptr, (size_t)n_s * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.transform_launches += 1;
+  c->prof.transform_ms += ms;
+  c->prof.transform_bytes += 32ull * (uint64_t)n_s;
+  return ICPGPU_OK;
+}
+
+void init_result(icpgpu_result* r) {
+  std::memset(r, 0, sizeof(*r));
+  for (int i = 0; i < 16; ++i) r->T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  r->fitness = NAN;
+}
+
+int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  const auto t_start = std::chrono::steady_clock::now();
+  init_result(res);
+  c->prof.aligns += 1;
+  double dev_ms = 0.0;
+
+  Mat4d final_T = mat4_identity();
+  if (guess)
+    for (int i = 0; i < 16; ++i) final_T[i] = (double)guess[i];
+
+  // pcl::Registration::setInputTarget refuses an empty target, initCompute() then fails and align() returns
+  // with converged_ = false and final_transformation_ = identity.
+  if (c->tgt.n == 0) {
+    c->final_T = mat4_identity();
+    c->have_final = true;
+    int rc = write_output_cloud(c, to_xform(c->final_T), out_xyzw);
+    if (rc) return rc;
+    res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    return ICPGPU_OK;
+  }
+
+  const icpgpu_params& P = c->params;
+  ConvergenceCriteria crit(P.max_iterations, P.transformation_epsilon, P.euclidean_fitness_epsilon,
+                           P.force_iterations != 0);
+  const float thr = threshold_from(P.max_correspondence_distance * P.max_correspondence_distance);
+
+  int nr_iter = 0, state = ICPGPU_NOT_CONVERGED;
+  bool converged = false;
+  unsigned n_corr = 0;
+  double mse = 0.0;
+  for (;;) {
+    SweepTimes st;
+    int rc = nn_and_reduce(c, to_xform(final_T), thr, &st);
+    if (rc) return rc;
+    dev_ms += st.nn_ms + st.reduce_ms;
+    const double* sums = c->h_sums;
+    n_corr = (unsigned)sums[0];
+    Mat4d Tk;
+    if ((int)n_corr < P.min_correspondences || !solve_umeyama(sums, Tk)) {
+      state = ICPGPU_CONV_NO_CORRESPONDENCES;
+      converged = false;
+      break;
+    }
+    final_T = mat4_mul(Tk, final_T);
+    mse = sums[16] / sums[0];
+    ++nr_iter;
+    c->prof.iterations += 1;
+    if (crit.has_converged(nr_iter, Tk, mse)) {
+      converged = true;
+      state = crit.state();
+      break;
+    }
+  }
+
+  c->final_T = final_T;
+  c->have_final = true;
+  mat4_to_float(final_T, res->T);
+  res->converged = converged ? 1 : 0;
+  res->iterations = nr_iter;
+  res->convergence_state = state;
+  res->n_correspondences = n_corr;
+  res->mse_last = mse;
+
+  const Xform Tf = to_xform(final_T);
+  if (want_fitness) {
+    SweepTimes st;
+    int rc = nn_and_reduce(c, Tf, FLT_MAX, &st);
+    if (rc) return rc;
+    dev_ms += st.nn_ms + st.reduce_ms;
+    res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
+  }
+  int rc = write_output_cloud(c, Tf, out_xyzw);
+  if (rc) return rc;
+  res->t_device_ms = dev_ms;
+  res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  return ICPGPU_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int icpgpu_version(void) { return ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR; }
+
+void icpgpu_default_params(icpgpu_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->method = ICPGPU_P2P_SVD;
+  p->max_iterations = 10;                    // icp_odometer.h:65
+  p->transformation_epsilon = 1e-6;          // icp_odometer.h:64
+  p->max_correspondence_distance = 1.0;      // icp_odometer.h:63
+  p->euclidean_fitness_epsilon = -DBL_MAX;   // PCL default
+  p->min_correspondences = 3;                // PCL default
+  p->force_iterations = 0;
+  p->nn_mode = ICPGPU_NN_AUTO;
+}
+
+int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
+  if (!out_ctx) return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "out_ctx is null");
+  *out_ctx = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "no HIP device available (%s); libicpgpu has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device_id < 0 || device_id >= count)
+    return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "device_id %d out of range [0, %d)", device_id, count);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return fail(nullptr, ICPGPU_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "device %d is %s; libicpgpu is built for gfx950 (MI355X) only", device_id,
+                prop.gcnArchName);
+
+  icpgpu_ctx* c = new (std::nothrow) icpgpu_ctx();
+  if (!c) return fail(nullptr, ICPGPU_ERR_OOM, "out of host memory");
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  icpgpu_default_params(&c->params);
+  if (const char* v = std::getenv("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v) == 1 ? 1 : 0;
+
+  auto bail = [&](const char* what, hipError_t err) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+    icpgpu_destroy(c);
+    return fail(nullptr, err == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "%s", msg.c_str());
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  for (auto& ev : c->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), kReduceTerms * sizeof(double), hipHostMallocDefault)) !=
+      hipSuccess)
+    return bail("hipHostMalloc", e);
+  if ((e = hipMalloc(&c->partials.ptr, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double))) != hipSuccess)
+    return bail("hipMalloc(partials)", e);
+  c->partials.cap = (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double);
+  if ((e = hipMalloc(&c->sums.ptr, kReduceTerms * sizeof(double))) != hipSuccess) return bail("hipMalloc(sums)", e);
+  c->sums.cap = kReduceTerms * sizeof(double);
+  *out_ctx = c;
+  return ICPGPU_OK;
+}
+
+int icpgpu_destroy(icpgpu_ctx* c) {
+  if (!c) return ICPGPU_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  release(c->src.buf);
+  release(c->tgt.buf);
+  release(c->keys);
+  release(c->partials);
+  release(c->sums);
+  release(c->out);
+  release(c->idx);
+  release(c->d2);
+  if (c->h_sums) (void)hipHostFree(c->h_sums);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ICPGPU_OK;
+}
+
+const char* icpgpu_last_error(const icpgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* p) {
+  if (!c || !p) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (p->method != ICPGPU_P2P_SVD && p->method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad method");
+  if (p->nn_mode < ICPGPU_NN_AUTO || p->nn_mode > ICPGPU_NN_GRID) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad nn_mode");
+  c->params = *p;
+  return ICPGPU_OK;
+}
+
+int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
+  if (!c || !p) return ICPGPU_ERR_INVALID_ARG;
+  *p = c->params;
+  return ICPGPU_OK;
+}
+
+#define ENTER(c)                                                   \
+  if (!(c)) return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "null context"); \
+  HIP_TRY((c), hipSetDevice((c)->device))
+
+int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
+  ENTER(c);
+  return set_cloud_host(c, c->src, xyzw, n);
+}
+int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
+  ENTER(c);
+  return set_cloud_host(c, c->tgt, xyzw, n);
+}
+int icpgpu_set_source_device(icpgpu_ctx* c, const void* d, size_t n) {
+  ENTER(c);
+  return set_cloud_device(c, c->src, d, n);
+}
+int icpgpu_set_target_device(icpgpu_ctx* c, const void* d, size_t n) {
+  ENTER(c);
+  return set_cloud_device(c, c->tgt, d, n);
+}
+
+int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
+  ENTER(c);
+  if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "promote_source_to_target: no source set");
+  std::swap(c->src, c->tgt);
+  c->src.n = 0;
+  c->src.set = false;
+  if (c->src.buf.external) c->src.buf = DeviceBuf{};
+  c->have_final = false;
+  return ICPGPU_OK;
+}
+
+int icpgpu_align(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  ENTER(c);
+  if (!res) return fail(c, ICPGPU_ERR_INVALID_ARG, "result is null");
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "align: source and target must be set first");
+  if (c->params.method == ICPGPU_GICP) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP mode is not built yet");
+  return align_p2p(c, guess, out_xyzw, want_fitness, res);
+}
+
+int icpgpu_fitness(icpgpu_ctx* c, double max_range, double* out) {
+  ENTER(c);
+  if (!out) return fail(c, ICPGPU_ERR_INVALID_ARG, "out is null");
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "fitness: source and target must be set first");
+  const Mat4d T = c->have_final ? c->final_T : mat4_identity();
+  int rc = nn_and_reduce(c, to_xform(T), threshold_from(max_range), nullptr);
+  if (rc) return rc;
+  *out = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
+  return ICPGPU_OK;
+}
+
+int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src,
+                       const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
+  ENTER(c);
+  if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  for (size_t k = 0; k < n_pairs; ++k) {
+    int rc = set_cloud_host(c, c->src, src[k], n_src[k]);
+    if (rc) return rc;
+    rc = set_cloud_host(c, c->tgt, tgt[k], n_tgt[k]);
+    if (rc) return rc;
+    rc = align_p2p(c, nullptr, nullptr, want_fitness, &results[k]);
+    if (rc) return rc;
+  }
+  return ICPGPU_OK;
+}
+
+int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {
+  ENTER(c);
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "nn: source and target must be set first");
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  if (n_s == 0) return ICPGPU_OK;
+  if (!idx || !d2) return fail(c, ICPGPU_ERR_INVALID_ARG, "null output");
+  int rc = ensure(c, c->keys, (size_t)n_s * sizeof(unsigned long long));
+  if (rc) return rc;
+  if ((rc = ensure(c, c->idx, (size_t)n_s * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c, c->d2, (size_t)n_s * sizeof(float)))) return rc;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
+  if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, to_xform(T), plan, keys, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, launch_unpack_keys(keys, n_s, static_cast<int32_t*>(c->idx.ptr), static_cast<float*>(c->d2.ptr), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(idx, c->idx.ptr, (size_t)n_s * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d2, c->d2.ptr, (size_t)n_s * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.nn_launches += 1;
+  c->prof.nn_ms += ms;
+  c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
+  c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  return ICPGPU_OK;
+}
+
+int icpgpu_reduce(icpgpu_ctx* c, const float* T, double max_dist, double sums[17]) {
+  ENTER(c);
+  if (!sums) return fail(c, ICPGPU_ERR_INVALID_ARG, "sums is null");
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "reduce: source and target must be set first");
+  if (!c->keys.ptr || c->keys.cap < c->src.n * sizeof(unsigned long long))
+    return fail(c, ICPGPU_ERR_NO_INPUT, "reduce: no nearest-neighbour sweep to reduce (call icpgpu_nn first)");
+  HIP_TRY(c, launch_reduce(c->src.data(), (int)c->src.n, c->tgt.data(), static_cast<unsigned long long*>(c->keys.ptr),
+                           to_xform(T), threshold_from(max_dist * max_dist), static_cast<double*>(c->partials.ptr),
+                           static_cast<double*>(c->sums.ptr), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.ptr, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::memcpy(sums, c->h_sums, kReduceTerms * sizeof(double));
+  return ICPGPU_OK;
+}
+
+int icpgpu_solve(const double sums[17], double Tk[16]) {
+  if (!sums || !Tk) return ICPGPU_ERR_INVALID_ARG;
+  Mat4d M;
+  const bool ok = solve_umeyama(sums, M);
+  for (int i = 0; i < 16; ++i) Tk[i] = M[i];
+  return ok ? ICPGPU_OK : ICPGPU_ERR_INVALID_ARG;
+}
+
+int icpgpu_transform(icpgpu_ctx* c, const float* T, float* out_xyzw) {
+  ENTER(c);
+  if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "transform: no source set");
+  if (c->src.n && !out_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "out is null");
+  return write_output_cloud(c, to_xform(T), out_xyzw);
+}
+
+int icpgpu_profile_reset(icpgpu_ctx* c) {
+  if (!c) return ICPGPU_ERR_INVALID_ARG;
+  std::memset(&c->prof, 0, sizeof(c->prof));
+  return ICPGPU_OK;
+}
+
+int icpgpu_profile_get(icpgpu_ctx* c, icpgpu_profile* out) {
+  if (!c || !out) return ICPGPU_ERR_INVALID_ARG;
+  *out = c->prof;
+  return ICPGPU_OK;
+}
+
+int icpgpu_get_stream(icpgpu_ctx* c, void** out_stream) {
+  if (!c || !out_stream) return ICPGPU_ERR_INVALID_ARG;
+  *out_stream = static_cast<void*>(c->stream);
+  return ICPGPU_OK;
+}
+
+int icpgpu_synchronize(icpgpu_ctx* c) {
+  ENTER(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ICPGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+"""Host-side mirror of the PCL `Registration` protocol the reference drives, on top of the C-ABI.
+
+The reference calls (identically at /root/reference/src/icpslam/icp_odometer.cpp:188-201 and
+src/icpslam/octree_mapper.cpp:104-117):
+
+    icp.setMaximumIterations(ICP_MAX_ITERS); icp.setTransformationEpsilon(ICP_EPSILON);
+    icp.setMaxCorrespondenceDistance(ICP_MAX_CORR_DIST); icp.setRANSACIterations(0);
+    icp.setInputSource(curr); icp.setInputTarget(prev); icp.align(out);
+    T = icp.getFinalTransformation(); icp.hasConverged(); icp.getFitnessScore()
+
+`IterativeClosestPoint` below keeps those method names, argument meaning and error behaviour
+(failure = hasConverged() False, never an exception on the data path) so the parity tests read like
+a PCL caller.  `Context` is the thin 1:1 wrapper over include/icpgpu.h used by bench.py.
+The C++ twin of this class is include/icpgpu_registration.hpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import IcpGpuError, Params, Profile, Result
+
+
+def _as_cloud(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 4:
+        raise ValueError("cloud must be (N, 4) float32: the pcl::PointXYZ layout x, y, z, pad")
+    return a
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _colmajor16(T) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T).reshape(16)
+
+
+class Context:
+    """One icpgpu_ctx: one device, one HIP stream, reusable scratch."""
+
+    def __init__(self, device_id: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.icpgpu_create(C.byref(h), int(device_id))
+        if rc != 0:
+            raise IcpGpuError(rc, self._L.icpgpu_last_error(None).decode())
+        self._h = h
+        self.n_source = 0
+        self.n_target = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.icpgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise IcpGpuError(rc, self._L.icpgpu_last_error(self._h).decode())
+
+    # parameters -----------------------------------------------------------------------------------------
+    def default_params(self) -> Params:
+        p = Params()
+        self._L.icpgpu_default_params(C.byref(p))
+        return p
+
+    def get_params(self) -> Params:
+        p = Params()
+        self._check(self._L.icpgpu_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_params(self, p: Params | None = None, **kw):
+        p = p or self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self._check(self._L.icpgpu_set_params(self._h, C.byref(p)))
+
+    # inputs ----------------------------------------------------------------------------------------------
+    def set_source(self, cloud):
+        cloud = _as_cloud(cloud)
+        self._check(self._L.icpgpu_set_source(self._h, _fp(cloud), cloud.shape[0]))
+        self.n_source = cloud.shape[0]
+
+    def set_target(self, cloud):
+        cloud = _as_cloud(cloud)
+        self._check(self._L.icpgpu_set_target(self._h, _fp(cloud), cloud.shape[0]))
+        self.n_target = cloud.shape[0]
+
+    def set_source_device(self, ptr: int, n: int):
+        self._check(self._L.icpgpu_set_source_device(self._h, C.c_void_p(ptr), n))
+        self.n_source = n
+
+    def set_target_device(self, ptr: int, n: int):
+        self._check(self._L.icpgpu_set_target_device(self._h, C.c_void_p(ptr), n))
+        self.n_target = n
+
+    def promote_source_to_target(self):
+        self._check(self._L.icpgpu_promote_source_to_target(self._h))
+        self.n_target, self.n_source = self.n_source, 0
+
+    # hot path ---------------------------------------------------------------------------------------------
+    def align(self, guess=None, want_cloud: bool = False, want_fitness: bool = False):
+        res = Result()
+        g = None
+        if guess is not None:
+            gbuf = _colmajor16(guess)
+            g = _fp(gbuf)
+        out = np.empty((self.n_source, 4), np.float32) if want_cloud else None
+        self._check(self._L.icpgpu_align(self._h, g, _fp(out) if out is not None else None, int(want_fitness),
+                                         C.byref(res)))
+        return result_dict(res, out)
+
+    def fitness(self, max_range: float = float(np.finfo(np.float64).max)) -> float:
+        v = C.c_double()
+        self._check(self._L.icpgpu_fitness(self._h, float(max_range), C.byref(v)))
+        return v.value
+
+    def align_batch(self, sources, targets, want_fitness: bool = False):
+        n = len(sources)
+        srcs = [_as_cloud(s) for s in sources]
+        tgts = [_as_cloud(t) for t in targets]
+        FP = C.POINTER(C.c_float)
+        sp = (FP * n)(*[_fp(s) for s in srcs])
+        tp = (FP * n)(*[_fp(t) for t in tgts])
+        ns = (C.c_size_t * n)(*[s.shape[0] for s in srcs])
+        nt = (C.c_size_t * n)(*[t.shape[0] for t in tgts])
+        res = (Result * n)()
+        self._check(self._L.icpgpu_align_batch(self._h, n, sp, ns, tp, nt, int(want_fitness), res))
+        return [result_dict(r, None) for r in res]
+
+    # kernel-level entry points ------------------------------------------------------------------------------
+    def nn(self, T=np.eye(4)):
+        idx = np.empty(self.n_source, np.int32)
+        d2 = np.empty(self.n_source, np.float32)
+        Tb = _colmajor16(T)
+        self._check(self._L.icpgpu_nn(self._h, _fp(Tb), idx.ctypes.data_as(C.POINTER(C.c_int32)), _fp(d2)))
+        return idx, d2
+
+    def reduce(self, T, max_dist: float) -> np.ndarray:
+        sums = np.zeros(17, np.float64)
+        Tb = _colmajor16(T)
+        self._check(self._L.icpgpu_reduce(self._h, _fp(Tb), float(max_dist), sums.ctypes.data_as(C.POINTER(C.c_double))))
+        return sums
+
+    def solve(self, sums) -> np.ndarray:
+        sums = np.ascontiguousarray(sums, np.float64)
+        Tk = np.zeros(16, np.float64)
+        dp = C.POINTER(C.c_double)
+        rc = self._L.icpgpu_solve(sums.ctypes.data_as(dp), Tk.ctypes.data_as(dp))
+        if rc != 0:
+            raise IcpGpuError(rc, "solve failed (n < 1 or non-finite sums)")
+        return Tk.reshape(4, 4).T.copy()
+
+    def transform(self, T) -> np.ndarray:
+        out = np.empty((self.n_source, 4), np.float32)
+        Tb = _colmajor16(T)
+        self._check(self._L.icpgpu_transform(self._h, _fp(Tb), _fp(out)))
+        return out
+
+    # measurement -----------------------------------------------------------------------------------------------
+    def profile_reset(self):
+        self._check(self._L.icpgpu_profile_reset(self._h))
+
+    def profile(self) -> Profile:
+        p = Profile()
+        self._check(self._L.icpgpu_profile_get(self._h, C.byref(p)))
+        return p
+
+    def synchronize(self):
+        self._check(self._L.icpgpu_synchronize(self._h))
+
+
+def result_dict(res: Result, cloud):
+    return dict(T=np.array(res.T, dtype=np.float32).reshape(4, 4).T.copy(), converged=bool(res.converged),
+                iterations=int(res.iterations), state=int(res.convergence_state), n_corr=int(res.n_correspondences),
+                mse=float(res.mse_last), fitness=float(res.fitness), cloud=cloud, t_total_ms=float(res.t_total_ms),
+                t_device_ms=float(res.t_device_ms))
+
+
+class IterativeClosestPoint:
+    """pcl::IterativeClosestPoint<PointXYZ, PointXYZ>-shaped front end (same method names as the reference uses)."""
+
+    _shared_ctx: dict = {}
+
+    def __init__(self, device_id: int = 0, method: int = _lib.P2P_SVD):
+        # the reference builds a fresh registration object per scan (icp_odometer.cpp:188); the GPU context is
+        # cached per device so that doing the same here costs nothing
+        ctx = IterativeClosestPoint._shared_ctx.get(device_id)
+        if ctx is None or ctx._h is None:
+            ctx = Context(device_id)
+            IterativeClosestPoint._shared_ctx[device_id] = ctx
+        self._ctx = ctx
+        self._params = ctx.default_params()
+        self._params.method = method
+        self._source = None
+        self._target = None
+        self._result = None
+        self._fitness = None
+
+    # setters used by the reference -----------------------------------------------------------------------------
+    def setMaximumIterations(self, n):           # icp_odometer.cpp:189 (passes a double constant)
+        self._params.max_iterations = int(n)
+
+    def setTransformationEpsilon(self, eps):     # icp_odometer.cpp:190
+        self._params.transformation_epsilon = float(eps)
+
+    def setMaxCorrespondenceDistance(self, d):   # icp_odometer.cpp:191
+        self._params.max_correspondence_distance = float(d)
+
+    def setRANSACIterations(self, n):            # icp_odometer.cpp:192 -- always 0 in the reference
+        if int(n) != 0:
+            raise NotImplementedError("RANSAC outlier rejection is not on the reference's path (always 0)")
+
+    def setEuclideanFitnessEpsilon(self, eps):
+        self._params.euclidean_fitness_epsilon = float(eps)
+
+    def setInputSource(self, cloud):             # icp_odometer.cpp:193
+        self._source = _as_cloud(cloud)
+
+    def setInputTarget(self, cloud):             # icp_odometer.cpp:194
+        self._target = _as_cloud(cloud)
+
+    # the call ------------------------------------------------------------------------------------------------------
+    def align(self, guess=None) -> np.ndarray:   # icp_odometer.cpp:198; returns the aligned source cloud
+        if self._source is None or self._target is None:
+            raise IcpGpuError(_lib.ERR_NO_INPUT, "align: setInputSource/setInputTarget first")
+        self._ctx.set_params(self._params)
+        self._ctx.set_source(self._source)
+        self._ctx.set_target(self._target)
+        self._result = self._ctx.align(guess=guess, want_cloud=True)
+        self._fitness = None
+        return self._result["cloud"]
+
+    def getFinalTransformation(self) -> np.ndarray:   # icp_odometer.cpp:199
+        return np.eye(4, dtype=np.float32) if self._result is None else self._result["T"]
+
+    def hasConverged(self) -> bool:                   # icp_odometer.cpp:201
+        return bool(self._result and self._result["converged"])
+
+    def getFitnessScore(self, max_range: float = float(np.finfo(np.float64).max)) -> float:   # icp_odometer.cpp:201
+        if self._result is None:
+            raise IcpGpuError(_lib.ERR_NO_INPUT, "getFitnessScore before align")
+        return self._ctx.fitness(max_range)
+
+    @property
+    def result(self):
+        return self._result

@@ -1,0 +1,186 @@
+/*
+ * icpgpu.h -- C-ABI of libicpgpu.so: MI355X (gfx950) ICP scan-matching core.
+ *
+ * Drop-in boundary for the one data-parallel hot path of YoshuaNava/icpslam: the per-scan
+ * registration the reference delegates to a PCL `Registration` object at
+ *   /root/reference/src/icpslam/icp_odometer.cpp:188-201   (IcpOdometer::laserCloudCallback)
+ *   /root/reference/src/icpslam/octree_mapper.cpp:104-117  (OctreeMapper::estimateTransformICP)
+ * The reference has no FFI/plugin registry; the interface it binds is the 10-call PCL protocol
+ *   ctor -> setMaximumIterations -> setTransformationEpsilon -> setMaxCorrespondenceDistance ->
+ *   setRANSACIterations(0) -> setInputSource -> setInputTarget -> align(out) ->
+ *   getFinalTransformation -> hasConverged -> getFitnessScore.
+ * Each entry point below names the protocol call (reference file:line) it replaces.  A header-only
+ * C++ shim with exactly those method names lives in include/icpgpu_registration.hpp; the
+ * reference-side edit is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; every function returns an int status
+ *     (0 = ICPGPU_OK, < 0 = error) and never throws or aborts.  Non-convergence is NOT an error:
+ *     it is reported as result.converged == 0, like PCL's hasConverged().
+ *   - clouds are `pcl::PointXYZ` arrays: 16-byte stride float {x, y, z, pad}; pad is ignored on
+ *     input and written as 1.0f on output.
+ *   - transforms are float[16] column-major 4x4 (memory layout of Eigen::Matrix4f), mapping
+ *     source -> target, i.e. the T the reference chains at icp_odometer.cpp:112-113.
+ *   - one context = one device + one HIP stream + scratch; distinct contexts may be used from
+ *     different threads concurrently (the odometer callback thread and the mapper main-loop
+ *     thread, /root/reference/src/icpslam_node.cpp:9); a single context is not re-entrant.
+ *   - there is no CPU fallback: without a usable gfx950 device icpgpu_create() fails.
+ */
+#ifndef ICPGPU_H
+#define ICPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPGPU_VERSION_MAJOR 0
+#define ICPGPU_VERSION_MINOR 1
+
+typedef struct icpgpu_ctx icpgpu_ctx; /* opaque */
+
+typedef enum {
+  ICPGPU_OK = 0,
+  ICPGPU_ERR_INVALID_ARG = -1,
+  ICPGPU_ERR_NO_DEVICE = -2,   /* no HIP device / not gfx950 / runtime missing */
+  ICPGPU_ERR_HIP = -3,         /* a HIP call failed; see icpgpu_last_error() */
+  ICPGPU_ERR_OOM = -4,
+  ICPGPU_ERR_NO_INPUT = -5,    /* align/fitness before set_source/set_target */
+  ICPGPU_ERR_UNSUPPORTED = -6
+} icpgpu_status;
+
+/* Solver. The reference instantiates pcl::GeneralizedIterativeClosestPoint (icp_odometer.cpp:188,
+ * octree_mapper.cpp:104); BASELINE.json's north_star specifies point-to-point ICP
+ * (pcl::IterativeClosestPoint semantics), which is the primary mode. */
+typedef enum { ICPGPU_P2P_SVD = 0, ICPGPU_GICP = 1 } icpgpu_method;
+
+/* Correspondence search strategy; every mode returns the exact nearest neighbour. */
+typedef enum {
+  ICPGPU_NN_AUTO = 0,
+  ICPGPU_NN_BRUTE = 1, /* LDS-tiled brute force (north_star) */
+  ICPGPU_NN_GRID = 2   /* uniform-grid accelerated exact search */
+} icpgpu_nn_mode;
+
+/* pcl::registration::DefaultConvergenceCriteria::ConvergenceState */
+typedef enum {
+  ICPGPU_NOT_CONVERGED = 0,
+  ICPGPU_CONV_ITERATIONS = 1,
+  ICPGPU_CONV_TRANSFORM = 2,
+  ICPGPU_CONV_ABS_MSE = 3,
+  ICPGPU_CONV_REL_MSE = 4,
+  ICPGPU_CONV_NO_CORRESPONDENCES = 5
+} icpgpu_convergence_state;
+
+typedef struct {
+  int32_t method;                     /* icpgpu_method */
+  int32_t max_iterations;             /* setMaximumIterations: icp_odometer.cpp:189 (10), octree_mapper.cpp:105 (30) */
+  double transformation_epsilon;      /* setTransformationEpsilon: icp_odometer.cpp:190 (1e-6) */
+  double max_correspondence_distance; /* setMaxCorrespondenceDistance: icp_odometer.cpp:191 (1.0 m) */
+  double euclidean_fitness_epsilon;   /* PCL default -DBL_MAX: relative-MSE test off (never set by the reference) */
+  int32_t min_correspondences;        /* PCL default 3 (P2P) / 4 (GICP) */
+  int32_t force_iterations;           /* != 0: run exactly max_iterations (benchmarking; no PCL equivalent) */
+  int32_t nn_mode;                    /* icpgpu_nn_mode */
+  int32_t reserved;
+} icpgpu_params;
+
+typedef struct {
+  float T[16];                /* getFinalTransformation(): icp_odometer.cpp:199, octree_mapper.cpp:115 */
+  int32_t converged;          /* hasConverged(): icp_odometer.cpp:201, octree_mapper.cpp:117 */
+  int32_t iterations;
+  int32_t convergence_state;  /* icpgpu_convergence_state */
+  uint32_t n_correspondences; /* accepted pairs in the last iteration */
+  double mse_last;            /* mean squared correspondence distance of the last iteration (m^2) */
+  double fitness;             /* getFitnessScore(): icp_odometer.cpp:201; NaN unless requested */
+  double t_total_ms;          /* host wall time of the align call */
+  double t_device_ms;         /* HIP-event time of all kernels of the call on the context's stream */
+} icpgpu_result;
+
+/* Kernel-level accounting since the last icpgpu_profile_reset(); times are HIP-event times on the
+ * context's own stream (this is what bench.py's roofline object is computed from). */
+typedef struct {
+  uint64_t nn_launches;       /* correspondence-search launches (a2) */
+  double nn_ms;               /* their summed duration */
+  uint64_t nn_pairs;          /* point pairs evaluated by those launches */
+  uint64_t nn_bytes;          /* algorithmic bytes: 16*(N_s+N_t) + 8*N_s per launch */
+  uint64_t reduce_launches;   /* rejection + covariance reduction launches (a3+a4) */
+  double reduce_ms;
+  uint64_t reduce_bytes;
+  uint64_t transform_launches; /* a6 */
+  double transform_ms;
+  uint64_t transform_bytes;
+  uint64_t iterations;        /* ICP iterations executed */
+  uint64_t aligns;            /* align calls */
+} icpgpu_profile;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* replaces: construction of the stack `icp` object, icp_odometer.cpp:188 / octree_mapper.cpp:104.
+ * Unlike the reference (fresh object per scan) a context is meant to be created once and reused. */
+int icpgpu_create(icpgpu_ctx** out_ctx, int device_id);
+int icpgpu_destroy(icpgpu_ctx* ctx);
+const char* icpgpu_last_error(const icpgpu_ctx* ctx); /* ctx may be NULL: last create() error */
+int icpgpu_version(void);                             /* major*1000 + minor */
+
+/* ---- parameters (icp_odometer.cpp:189-192, octree_mapper.cpp:105-108) ----------------------- */
+void icpgpu_default_params(icpgpu_params* p); /* PCL defaults + the reference's odometer constants */
+int icpgpu_set_params(icpgpu_ctx* ctx, const icpgpu_params* p);
+int icpgpu_get_params(const icpgpu_ctx* ctx, icpgpu_params* p);
+
+/* ---- inputs --------------------------------------------------------------------------------- */
+/* replaces setInputSource (icp_odometer.cpp:193, octree_mapper.cpp:109): copies n points H2D;
+ * the caller keeps ownership. n may be 0. */
+int icpgpu_set_source(icpgpu_ctx* ctx, const float* xyzw, size_t n);
+/* replaces setInputTarget (icp_odometer.cpp:194, octree_mapper.cpp:110). PCL rejects an empty
+ * target; here n == 0 is accepted and align() then reports converged = 0 with T = identity. */
+int icpgpu_set_target(icpgpu_ctx* ctx, const float* xyzw, size_t n);
+/* same, for clouds already resident in this device's HBM (zero copy; must stay valid and
+ * unmodified until replaced; 16-byte aligned). */
+int icpgpu_set_source_device(icpgpu_ctx* ctx, const void* d_xyzw, size_t n);
+int icpgpu_set_target_device(icpgpu_ctx* ctx, const void* d_xyzw, size_t n);
+/* make the current source the next target without a copy (the reference's
+ * `*prev_cloud_ = *curr_cloud_`, icp_odometer.cpp:209). */
+int icpgpu_promote_source_to_target(icpgpu_ctx* ctx);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* replaces align(out) + getFinalTransformation + hasConverged [+ getFitnessScore]
+ * (icp_odometer.cpp:198-201, octree_mapper.cpp:114-117).
+ *   guess     : float[16] initial transform or NULL (= identity; the reference never passes one)
+ *   out_xyzw  : host buffer for the aligned source cloud (n_source * 16 bytes) or NULL to skip the
+ *               D2H copy (the reference only publishes it for debugging, icp_odometer.cpp:216-218)
+ *   want_fitness : != 0 also evaluates getFitnessScore() (one more NN sweep)                     */
+int icpgpu_align(icpgpu_ctx* ctx, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* result);
+
+/* replaces getFitnessScore(max_range) (icp_odometer.cpp:201) using the last align's transform. */
+int icpgpu_fitness(icpgpu_ctx* ctx, double max_range, double* out_fitness);
+
+/* Many independent scan pairs through one context (BASELINE config 4/5).  Pair k registers
+ * src[k] (n_src[k] points) onto tgt[k]; all pointers are host pointers.  Iterations of different
+ * pairs are interleaved on the device so the per-iteration host solve of one pair overlaps the
+ * kernels of others.  results[k] is filled for every k. */
+int icpgpu_align_batch(icpgpu_ctx* ctx, size_t n_pairs, const float* const* src, const size_t* n_src,
+                       const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results);
+
+/* ---- kernel-level entry points (used by the parity tests; same kernels as align) ------------- */
+/* a2: idx[i], d2[i] = exact nearest neighbour of T*source[i] in target (lowest index on ties);
+ * idx = -1, d2 = +inf when the target is empty or the point is non-finite. */
+int icpgpu_nn(icpgpu_ctx* ctx, const float* T, int32_t* idx, float* d2);
+/* a3+a4: over pairs of the last icpgpu_nn/align NN sweep with (double)d2 <= max_dist^2:
+ * sums = {n, sum p(3), sum q(3), sum q p^T (9, row = q), sum d2}, p = T*source[i], q = target[idx[i]]. */
+int icpgpu_reduce(icpgpu_ctx* ctx, const float* T, double max_dist, double sums[17]);
+/* a5 (host): Umeyama without scaling from the 17 sums -> double[16] column-major. */
+int icpgpu_solve(const double sums[17], double Tk[16]);
+/* a6: out = T * source (w = 1), pcl::transformPointCloud (icp_odometer.cpp:205). */
+int icpgpu_transform(icpgpu_ctx* ctx, const float* T, float* out_xyzw);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+int icpgpu_profile_reset(icpgpu_ctx* ctx);
+int icpgpu_profile_get(icpgpu_ctx* ctx, icpgpu_profile* out);
+/* stream handle (hipStream_t as void*) so a host can order its own work against the context. */
+int icpgpu_get_stream(icpgpu_ctx* ctx, void** out_stream);
+int icpgpu_synchronize(icpgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPGPU_H */
