@@ -160,7 +160,7 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 // a3 + a4: rejection predicate + 17-term reduction in double, deterministic order.
 //   stage 1: grid-stride over source points, per-lane double accumulators, wave shuffle tree, LDS across the
 //            4 waves, one 17-double partial per block
-//   stage 2: one wave sums the partials in block order
+//   stage 2: one workgroup of 17 waves (one per term) sums the partials in a fixed order
 // HBM traffic: 8 B key + 16 B source + 16 B gathered target per accepted point.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RED_BLOCK = 256;
@@ -218,13 +218,17 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
   }
 }
 
-__global__ __launch_bounds__(64) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks,
-                                                          double* __restrict__ sums) {
-  const int k = threadIdx.x;
-  if (k >= kReduceTerms) return;
-  double v = 0.0;
-  for (int b = 0; b < n_blocks; ++b) v += partials[(size_t)b * kReduceTerms + k];
-  sums[k] = v;
+// stage 2: 16 waves; wave w owns terms w, w+16; lane l adds partials l, l+64, ... in that order, then a fixed
+// shuffle tree -> bitwise reproducible run to run.
+__global__ __launch_bounds__(1024) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks,
+                                                            double* __restrict__ sums) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < kReduceTerms; k += 16) {
+    double v = 0.0;
+    for (int b = lane; b < n_blocks; b += 64) v += partials[(size_t)b * kReduceTerms + k];
+    v = wave_sum(v);
+    if (lane == 0) sums[k] = v;
+  }
 }
 
 // a6: output cloud. 32 B/point of HBM traffic, float4 in / float4 out.
@@ -281,7 +285,7 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, stream, partials, blocks, sums_out);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1024), 0, stream, partials, blocks, sums_out);
   return hipGetLastError();
 }
 

@@ -1,0 +1,111 @@
+"""CPU tests of the drop-in boundary: libicpgpu.so builds for gfx950, loads, and exports exactly what
+include/icpgpu.h declares; the host-only entry points work; the device entry points fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from icpslam_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "icpgpu.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(icpgpu_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(built):
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/icpgpu.h but not exported by libicpgpu.so"
+    assert sorted(_lib.EXPORTS) == names
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = sorted(set(re.findall(r"\bT (icpgpu_[a-z_0-9]+)", out)))
+    assert exported == names, "library exports symbols the header does not declare (or vice versa)"
+
+
+def test_library_contains_gfx950_code_object(built):
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"nn_brute_kernel" in blob
+
+
+def test_header_compiles_as_c_and_struct_sizes_match(built, tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "icpgpu.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu\\n", sizeof(icpgpu_params), '
+                   'sizeof(icpgpu_result), sizeof(icpgpu_profile)); return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert sizes == [C.sizeof(_lib.Params), C.sizeof(_lib.Result), C.sizeof(_lib.Profile)]
+
+
+def test_version_and_default_params(built):
+    lib = _lib.load()
+    assert lib.icpgpu_version() >= 1
+    p = _lib.Params()
+    lib.icpgpu_default_params(C.byref(p))
+    # the reference's odometer constants: /root/reference/include/icpslam/icp_odometer.h:63-65
+    assert (p.max_iterations, p.transformation_epsilon, p.max_correspondence_distance) == (10, 1e-6, 1.0)
+    assert p.min_correspondences == 3 and p.method == _lib.P2P_SVD and p.euclidean_fitness_epsilon < -1e300
+
+
+def test_host_solve_matches_oracle(built):
+    """a5 is host code (north_star keeps the 3x3 SVD on the host), so it is testable without a GPU."""
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    dp = C.POINTER(C.c_double)
+    for trial in range(40):
+        n = 500
+        p = rng.normal(size=(n, 3)) * (30, 20, 1.5) + (5, -3, 0.2)
+        T = synth.pose_matrix(*rng.uniform(-0.5, 0.5, 3), *rng.uniform(-0.1, 0.1, 3))
+        q = p @ T[:3, :3].T + T[:3, 3] + rng.normal(size=(n, 3)) * 0.02
+        if trial % 5 == 0:
+            p[:, 2] = q[:, 2] = 0.0                       # rank-deficient covariance
+        sums = np.zeros(17)
+        sums[0], sums[1:4], sums[4:7], sums[7:16] = n, p.sum(0), q.sum(0), (q.T @ p).reshape(-1)
+        Tk = np.zeros(16)
+        assert lib.icpgpu_solve(sums.ctypes.data_as(dp), Tk.ctypes.data_as(dp)) == 0
+        got = Tk.reshape(4, 4).T
+        np.testing.assert_allclose(got, oracle.umeyama(sums), atol=1e-10)
+        assert abs(np.linalg.det(got[:3, :3]) - 1) < 1e-10
+    bad = np.zeros(17)
+    Tk = np.zeros(16)
+    assert lib.icpgpu_solve(bad.ctypes.data_as(dp), Tk.ctypes.data_as(dp)) != 0
+    np.testing.assert_array_equal(Tk.reshape(4, 4), np.eye(4))
+
+
+def test_no_gpu_fails_loudly(built):
+    """No silent CPU fallback: without a device the context cannot be created and says why."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.icpgpu_create(C.byref(h), 0)
+    assert rc == _lib.ERR_NO_DEVICE and not h.value
+    assert b"no CPU fallback" in lib.icpgpu_last_error(None)
+    from icpslam_amd import Context, IcpGpuError
+    with pytest.raises(IcpGpuError):
+        Context(0)
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "icpslam_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text and "icp_oracle" not in text.replace(
+                    "oracle/icp_oracle.c", ""), f
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read()

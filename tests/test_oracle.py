@@ -1,0 +1,204 @@
+"""CPU tests: pin the C oracle (oracle/icp_oracle.c).
+
+The reference has no tests for this path (parity unpinned), so the oracle is pinned by
+  (i) construction-known ground truth, (ii) the independent NumPy/SciPy restatement, (iii) the committed golden
+  fixtures, (iv) properties (permutation invariance, rigid equivariance, identity, kd-tree == brute force).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from icpslam_amd import synth
+from oracle import icp_oracle_np as onp
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def dR(a, b):
+    return float(np.abs(np.asarray(a, np.float64)[:3, :3] - np.asarray(b, np.float64)[:3, :3]).max())
+
+
+def dt(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64)[:3, 3] - np.asarray(b, np.float64)[:3, 3]))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    oracle.build()
+
+
+def test_golden_files_present():
+    assert len(GOLDEN) >= 5
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_oracle_matches_golden(path):
+    g = np.load(path)
+    p = oracle.default_params(max_iterations=int(g["max_iterations"]), max_correspondence_distance=float(g["max_corr"]))
+    guess = g["guess"] if bool(g["has_guess"]) else None
+    r = oracle.icp_align(g["src"], g["tgt"], p, guess=guess, want_fitness=True, want_trace=True)
+    assert r["converged"] == bool(g["converged"])
+    assert r["iterations"] == int(g["iterations"])
+    assert r["state"] == int(g["state"])
+    assert r["n_corr"] == int(g["n_corr"])
+    assert dR(r["T"], g["T"]) <= 1e-6 and dt(r["T"], g["T"]) <= 1e-6
+    assert abs(r["fitness"] - float(g["fitness"])) <= 1e-6 * max(1.0, float(g["fitness"]))
+    assert [t["n_corr"] for t in r["trace"]] == list(g["trace_n_corr"])
+    for k, t in enumerate(r["trace"]):
+        np.testing.assert_allclose(t["Tk"], g["trace_Tk"][k], atol=1e-6)
+        np.testing.assert_allclose(t["final"], g["trace_final"][k], atol=1e-6)
+        assert abs(t["mse"] - g["trace_mse"][k]) <= 1e-7 * max(1.0, g["trace_mse"][k])
+    # bit-level pin of the NN arithmetic contract
+    idx, d2 = oracle.nn(g["src"], g["tgt"], np.eye(4), nn_mode=oracle.NN_KDTREE)
+    assert np.array_equal(idx, g["nn_idx"]) and np.array_equal(d2.view(np.uint32), g["nn_d2"].view(np.uint32))
+
+
+@pytest.mark.parametrize("n_s,n_t,seed", [(1, 1, 0), (50, 3, 1), (2000, 2000, 2), (3000, 777, 3), (100, 20000, 4)])
+def test_kdtree_equals_bruteforce(n_s, n_t, seed):
+    rng = np.random.default_rng(seed)
+    src = np.ones((n_s, 4), np.float32)
+    tgt = np.ones((n_t, 4), np.float32)
+    src[:, :3] = rng.uniform(-30, 30, (n_s, 3))
+    tgt[:, :3] = np.round(rng.uniform(-30, 30, (n_t, 3)), 1)     # rounding creates duplicate coordinates / ties
+    T = synth.pose_matrix(0.3, -0.2, 0.1, 0.01, -0.02, 0.05)
+    for arith in (oracle.ARITH_FMA, oracle.ARITH_FLANN):
+        ik, dk = oracle.nn(src, tgt, T, oracle.NN_KDTREE, arith)
+        ib, db = oracle.nn(src, tgt, T, oracle.NN_BRUTE, arith)
+        assert np.array_equal(ik, ib) and np.array_equal(dk.view(np.uint32), db.view(np.uint32))
+
+
+def test_nn_against_float64_reference():
+    src, tgt, _ = synth.make_pair(3000, 3000, seed=5)
+    idx, d2 = oracle.nn(src, tgt)
+    d = np.linalg.norm(src[:, None, :3].astype(np.float64) - tgt[None, :, :3].astype(np.float64), axis=2) ** 2
+    best = d.min(axis=1)
+    np.testing.assert_allclose(d2, best, rtol=1e-5, atol=1e-9)
+    chosen = d[np.arange(3000), idx]
+    np.testing.assert_allclose(chosen, best, rtol=1e-5, atol=1e-9)
+
+
+def test_svd3_reconstructs_and_is_orthonormal():
+    rng = np.random.default_rng(0)
+    mats = [rng.normal(size=(3, 3)) for _ in range(50)]
+    mats += [np.outer(rng.normal(size=3), rng.normal(size=3)), np.zeros((3, 3)), np.diag([3.0, 1e-9, 0.0]),
+             np.eye(3), -np.eye(3)]
+    for A in mats:
+        U, s, V = oracle.svd3(A)
+        np.testing.assert_allclose(U @ np.diag(s) @ V.T, A, atol=1e-12)
+        np.testing.assert_allclose(U.T @ U, np.eye(3), atol=1e-12)
+        np.testing.assert_allclose(V.T @ V, np.eye(3), atol=1e-12)
+        assert s[0] >= s[1] >= s[2] >= 0
+        np.testing.assert_allclose(s, np.linalg.svd(A, compute_uv=False), atol=1e-12)
+
+
+def test_umeyama_matches_numpy_and_handles_reflection():
+    rng = np.random.default_rng(1)
+    for trial in range(20):
+        p = rng.normal(size=(200, 3)) * (5, 3, 0.5)
+        T = synth.pose_matrix(*rng.uniform(-1, 1, 3), *rng.uniform(-0.3, 0.3, 3))
+        q = p @ T[:3, :3].T + T[:3, 3] + rng.normal(size=(200, 3)) * 0.01
+        if trial % 4 == 0:
+            q[:, 2] = 0.0    # planar target: the reflection branch of umeyama may trigger
+            p[:, 2] = 0.0
+        sums = np.zeros(17)
+        sums[0] = 200
+        sums[1:4] = p.sum(0)
+        sums[4:7] = q.sum(0)
+        sums[7:16] = (q.T @ p).reshape(-1)
+        Tk = oracle.umeyama(sums)
+        ref = onp.umeyama(p, q)
+        np.testing.assert_allclose(Tk, ref, atol=1e-9)
+        assert abs(np.linalg.det(Tk[:3, :3]) - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("seed,n", [(11, 3000), (12, 5000)])
+def test_c_oracle_matches_numpy_restatement(seed, n):
+    src, tgt, _ = synth.make_pair(n, n, seed=seed)
+    for iters in (10, 30):
+        a = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=iters), want_fitness=True, want_trace=True)
+        b = onp.icp_align(src, tgt, max_iterations=iters, want_fitness=True)
+        assert a["iterations"] == b["iterations"] and a["state"] == b["state"] and a["n_corr"] == b["n_corr"]
+        assert dR(a["T"], b["T"]) <= 1e-6 and dt(a["T"], b["T"]) <= 1e-6
+        assert [t["n_corr"] for t in a["trace"]] == [t["n_corr"] for t in b["trace"]]
+        assert abs(a["fitness"] - b["fitness"]) <= 1e-6 * max(1.0, b["fitness"])
+
+
+def test_known_answer_recovers_ground_truth():
+    src, tgt, T_gt = synth.make_known_answer_pair(5000, seed=21)
+    r = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=50))
+    assert r["converged"] and r["state"] == 2
+    assert dR(r["T"], T_gt) <= 1e-5 and dt(r["T"], T_gt) <= 1e-4
+    assert r["n_corr"] == 5000
+
+
+def test_identity_on_identical_clouds():
+    src, _, _ = synth.make_pair(2000, 10, seed=22)
+    r = oracle.icp_align(src, src.copy(), want_fitness=True)
+    assert r["converged"] and r["iterations"] == 1 and r["state"] == 2
+    np.testing.assert_allclose(r["T"], np.eye(4), atol=1e-6)
+    assert r["fitness"] == 0.0
+
+
+def test_permutation_invariance_and_rigid_equivariance():
+    src, tgt, _ = synth.make_pair(3000, 3000, seed=23)
+    base = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=30))
+    rng = np.random.default_rng(0)
+    perm = oracle.icp_align(src[rng.permutation(3000)], tgt[rng.permutation(3000)], oracle.default_params(max_iterations=30))
+    assert perm["iterations"] == base["iterations"] and perm["n_corr"] == base["n_corr"]
+    assert dR(perm["T"], base["T"]) <= 1e-6 and dt(perm["T"], base["T"]) <= 1e-6
+    # move both clouds by the same rigid motion G: T' = G T G^-1
+    G = synth.pose_matrix(3.0, -2.0, 0.5, 0.02, -0.01, 0.7)
+    s2, t2 = oracle.transform_cloud(src, G), oracle.transform_cloud(tgt, G)
+    moved = oracle.icp_align(s2, t2, oracle.default_params(max_iterations=30))
+    expect = G @ base["T"].astype(np.float64) @ np.linalg.inv(G)
+    assert moved["iterations"] == base["iterations"]
+    assert dR(moved["T"], expect) <= 2e-4 and dt(moved["T"], expect) <= 2e-3   # float32 re-quantisation of the inputs
+
+
+def test_mse_non_increasing_and_modes_agree():
+    src, tgt, _ = synth.make_pair(4000, 4000, seed=24)
+    a = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=30), want_trace=True)
+    mses = [t["mse"] for t in a["trace"]]
+    assert all(m2 <= m1 * (1 + 1e-3) + 1e-9 for m1, m2 in zip(mses, mses[1:]))
+    # PCL-float flavour and FLANN (no-FMA) distance order stay within the parity tolerance of the f64/FMA contract
+    b = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=30, precision=oracle.PREC_PCL_F32))
+    c = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=30, arith=oracle.ARITH_FLANN))
+    d = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=30, nn_mode=oracle.NN_BRUTE))
+    assert dR(a["T"], b["T"]) <= 1e-4 and dt(a["T"], b["T"]) <= 1e-3
+    assert dR(a["T"], c["T"]) <= 1e-4 and dt(a["T"], c["T"]) <= 1e-3
+    assert np.array_equal(a["T"], d["T"]) and a["n_corr"] == d["n_corr"]
+
+
+def test_degenerate_inputs():
+    src, tgt, _ = synth.make_pair(500, 500, seed=25)
+    e = np.zeros((0, 4), np.float32)
+    r = oracle.icp_align(src, e)
+    assert not r["converged"] and r["iterations"] == 0 and np.array_equal(r["T"], np.eye(4, dtype=np.float32))
+    r = oracle.icp_align(e, tgt)
+    assert not r["converged"] and r["state"] == 5
+    far = src.copy()
+    far[:, 0] += 1000
+    r = oracle.icp_align(far, tgt, want_fitness=True)
+    assert not r["converged"] and r["state"] == 5 and r["n_corr"] == 0 and r["fitness"] > 20   # the reference's gate
+
+
+def test_voxel_grid_properties():
+    src, _, _ = synth.make_pair(20000, 10, seed=26)
+    out = oracle.voxel_grid(src, 0.2)
+    assert 0 < out.shape[0] < src.shape[0]
+    # every output is the mean of the inputs of one cell; cells are distinct and ordered
+    inv = np.float32(1.0) / np.float32(0.2)
+    ci = np.floor(src[:, :3] * inv).astype(np.int64)
+    mn = ci.min(0)
+    div = ci.max(0) - mn + 1
+    lin = (ci[:, 0] - mn[0]) + (ci[:, 1] - mn[1]) * div[0] + (ci[:, 2] - mn[2]) * div[0] * div[1]
+    cells, inverse, counts = np.unique(lin, return_inverse=True, return_counts=True)
+    assert out.shape[0] == cells.shape[0]
+    means = np.zeros((cells.shape[0], 3))
+    np.add.at(means, inverse, src[:, :3].astype(np.float64))
+    means /= counts[:, None]
+    np.testing.assert_allclose(out[:, :3], means, atol=1e-4)
+    assert (out[:, 3] == 1.0).all()
