@@ -32,7 +32,9 @@ class Profile(C.Structure):
     _fields_ = [("nn_launches", C.c_uint64), ("nn_ms", C.c_double), ("nn_pairs", C.c_uint64),
                 ("nn_bytes", C.c_uint64), ("reduce_launches", C.c_uint64), ("reduce_ms", C.c_double),
                 ("reduce_bytes", C.c_uint64), ("transform_launches", C.c_uint64), ("transform_ms", C.c_double),
-                ("transform_bytes", C.c_uint64), ("iterations", C.c_uint64), ("aligns", C.c_uint64)]
+                ("transform_bytes", C.c_uint64), ("iterations", C.c_uint64), ("aligns", C.c_uint64),
+                ("grid_launches", C.c_uint64), ("grid_ms", C.c_double), ("grid_bytes", C.c_uint64),
+                ("grid_builds", C.c_uint64), ("grid_build_ms", C.c_double), ("grid_fallback_points", C.c_uint64)]
 
 
 # every symbol include/icpgpu.h declares (tests/test_abi.py checks the header against this list)

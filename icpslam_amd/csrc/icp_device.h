@@ -1,0 +1,64 @@
+// icp_device.h -- device-side helpers shared by the kernel translation units (internal).
+// The arithmetic contract of DESIGN.md section 3 lives here: every kernel transforms and measures through these.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "icp_kernels.h"
+
+namespace icpgpu {
+
+__device__ __forceinline__ void xform_point(const Xform& T, float x, float y, float z, float& px, float& py, float& pz) {
+  px = __builtin_fmaf(T.m[2], z, __builtin_fmaf(T.m[1], y, __builtin_fmaf(T.m[0], x, T.m[3])));
+  py = __builtin_fmaf(T.m[6], z, __builtin_fmaf(T.m[5], y, __builtin_fmaf(T.m[4], x, T.m[7])));
+  pz = __builtin_fmaf(T.m[10], z, __builtin_fmaf(T.m[9], y, __builtin_fmaf(T.m[8], x, T.m[11])));
+}
+
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, float py, float pz) {
+  const float dx = qx - px, dy = qy - py, dz = qz - pz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+
+// 17-term accumulation of one accepted pair (p = transformed source, q = target), double precision.
+__device__ __forceinline__ void accumulate_pair(double (&acc)[kReduceTerms], float px, float py, float pz, float qx,
+                                                float qy, float qz, float d2) {
+  const double p[3] = {(double)px, (double)py, (double)pz};
+  const double q[3] = {(double)qx, (double)qy, (double)qz};
+  acc[0] += 1.0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    acc[1 + a] += p[a];
+    acc[4 + a] += q[a];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[7 + 3 * a + b] += q[a] * p[b];
+  }
+  acc[16] += (double)d2;
+}
+
+// Block-level fixed-order reduction of the per-lane accumulators into partials[block][17]. WAVES = blockDim.x / 64.
+template <int WAVES>
+__device__ __forceinline__ void block_reduce_store(const double (&acc)[kReduceTerms], double* __restrict__ partials) {
+  __shared__ double wsum[WAVES][kReduceTerms];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kReduceTerms; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) wsum[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kReduceTerms) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += wsum[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * kReduceTerms + threadIdx.x] = v;
+  }
+}
+
+}  // namespace icpgpu

@@ -1,0 +1,474 @@
+// icp_grid.hip -- uniform-grid accelerated EXACT nearest neighbour for the ICP correspondence step (row a2 of
+// SURVEY.md section 8(a)), plus the fused rejection + covariance reduction (a3 + a4).
+//
+// Replaces the FLANN kd-tree search PCL performs inside `icp.align()` (reached from
+// /root/reference/src/icpslam/icp_odometer.cpp:198 and src/icpslam/octree_mapper.cpp:114).  ICP only keeps
+// correspondences closer than setMaxCorrespondenceDistance (icp_odometer.cpp:191, 1.0 m), so the search may stop at
+// that radius: target points are counting-sorted into a dense uniform grid once per target cloud, and each source
+// point scans the 3x3x3 cells around it, then shells of growing radius, until its best distance is provably smaller
+// than anything outside the scanned cube.  Same arithmetic contract as the brute-force kernel (icp_device.h), same
+// (d2, lowest original index) tie-break, so the keys are bit-identical to brute force for every matched point.
+//
+// HBM-side layout: `sorted` = float4 {x, y, z, original-index bits}, cells x-fastest so a run of cells along x is ONE
+// contiguous range (9 range lookups for a 3x3x3 block); `cell_start` = int32 per cell (+1).
+#include <math.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "icp_device.h"
+#include "icp_kernels.h"
+
+namespace icpgpu {
+namespace {
+
+// ---- order-preserving float <-> int encoding for atomic min/max ------------------------------------------------
+__device__ __forceinline__ int enc_float(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+inline float dec_float(int e) {
+  const int i = e >= 0 ? e : e ^ 0x7FFFFFFF;
+  float f;
+  std::memcpy(&f, &i, 4);
+  return f;
+}
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+  return isfinite(x) && isfinite(y) && isfinite(z);
+}
+
+__global__ void bbox_init_kernel(int* mm) {
+  if (threadIdx.x < 3) mm[threadIdx.x] = 0x7FFFFFFF;
+  else if (threadIdx.x < 6) mm[threadIdx.x] = (int)0x80000000;
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pts, int n, int* __restrict__ mm) {
+  int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    if (finite3(p.x, p.y, p.z)) {
+      const int e[3] = {enc_float(p.x), enc_float(p.y), enc_float(p.z)};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = min(lo[a], e[a]);
+        hi[a] = max(hi[a], e[a]);
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = min(lo[a], __shfl_down(lo[a], off, 64));
+      hi[a] = max(hi[a], __shfl_down(hi[a], off, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&mm[a], lo[a]);
+      atomicMax(&mm[3 + a], hi[a]);
+    }
+  }
+}
+
+// Cell coordinates: the SAME float expression bins targets and queries, and floor((x - o) * inv_h) is monotone in x,
+// which is what the early-exit proof needs.
+__device__ __forceinline__ void cell_of(const GridDesc& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+  const float fx = floorf((x - g.ox) * g.inv_h), fy = floorf((y - g.oy) * g.inv_h), fz = floorf((z - g.oz) * g.inv_h);
+  const float lim = 1048576.0f;
+  cx = (int)fminf(fmaxf(fx, -lim), lim);
+  cy = (int)fminf(fmaxf(fy, -lim), lim);
+  cz = (int)fminf(fmaxf(fz, -lim), lim);
+}
+
+// CLAMP = false: bin the target cloud (points outside the grid / non-finite are dropped: c = -1)
+// CLAMP = true : order the SOURCE cloud by the target cell of T*s, every point keeps a slot (outside -> border cell,
+//                non-finite -> cell 0), so that a wave's 64 consecutive queries share their candidate rows
+template <bool CLAMP>
+__global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restrict__ pts, int n, GridDesc g, Xform T,
+                                                         int* __restrict__ cell_of_point, int* __restrict__ rank,
+                                                         int* __restrict__ counts) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 s = pts[i];
+  float x = s.x, y = s.y, z = s.z;
+  if (CLAMP) xform_point(T, s.x, s.y, s.z, x, y, z);
+  int c = -1;
+  if (finite3(x, y, z)) {
+    int cx, cy, cz;
+    cell_of(g, x, y, z, cx, cy, cz);
+    if (CLAMP) {
+      cx = min(max(cx, 0), g.nx - 1);
+      cy = min(max(cy, 0), g.ny - 1);
+      cz = min(max(cz, 0), g.nz - 1);
+    }
+    if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) c = (cz * g.ny + cy) * g.nx + cx;
+  } else if (CLAMP) {
+    c = 0;
+  }
+  cell_of_point[i] = c;
+  rank[i] = c >= 0 ? atomicAdd(&counts[c], 1) : 0;
+}
+
+// ---- exclusive scan of the per-cell counts (three small kernels) ---------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* total) {
+  // 256 threads; returns the exclusive prefix of v, *total = block sum (valid in all threads)
+  __shared__ int wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+constexpr int SCAN_PER_THREAD = kScanItems / 256;  // 16
+
+__global__ __launch_bounds__(256) void scan_sums_kernel(const int* __restrict__ counts, int n, int* __restrict__ block_sums,
+                                                        int* __restrict__ stats) {
+  const int base = blockIdx.x * kScanItems + threadIdx.x * SCAN_PER_THREAD;
+  int s = 0, m = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+    const int v = (base + k < n) ? counts[base + k] : 0;
+    s += v;
+    m = max(m, v);
+  }
+  int tot;
+  (void)block_exclusive_scan_256(s, &tot);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+  if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], m);
+}
+
+__global__ __launch_bounds__(1024) void scan_top_kernel(int* __restrict__ block_sums, int nb, int* __restrict__ stats) {
+  // one workgroup: each thread owns a contiguous slice of the block sums
+  __shared__ int part[1024];
+  const int per = (nb + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = min(nb, lo + per);
+  int s = 0;
+  for (int k = lo; k < hi; ++k) s += block_sums[k];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 1024; ++t) {
+      const int v = part[t];
+      part[t] = run;
+      run += v;
+    }
+    stats[0] = run;  // number of binned points
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int k = lo; k < hi; ++k) {
+    const int v = block_sums[k];
+    block_sums[k] = run;
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(int* __restrict__ counts, int n, const int* __restrict__ block_sums,
+                                                         const int* __restrict__ stats) {
+  const int base = blockIdx.x * kScanItems + threadIdx.x * SCAN_PER_THREAD;
+  int v[SCAN_PER_THREAD], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+    v[k] = (base + k < n) ? counts[base + k] : 0;
+    s += v[k];
+  }
+  int tot;
+  int run = block_exclusive_scan_256(s, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+    if (base + k < n) counts[base + k] = run;
+    run += v[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) counts[n] = stats[0];  // cell_start[ncells] = total
+}
+
+__global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restrict__ pts, int n,
+                                                           const int* __restrict__ cell_of_point,
+                                                           const int* __restrict__ rank,
+                                                           const int* __restrict__ cell_start,
+                                                           float4* __restrict__ sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_of_point[i];
+  if (c < 0) return;
+  const float4 p = pts[i];
+  sorted[cell_start[c] + rank[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+// ---- correspondence search over the grid: one wave per query ------------------------------------------------------
+// A 64-lane wave owns one source point at a time (WQ_PER_WAVE consecutive points of the cell-ordered source, so
+// successive queries hit the same cache lines).  For the cube of Chebyshev radius rho around the query's cell the lanes
+// fetch the (2*rho+1)^2 cell-row ranges in parallel (a row = fixed y,z and a contiguous x run = ONE range of `sorted`),
+// then the wave walks the non-empty rows two at a time (two independent coalesced 1 KiB reads in flight), 64
+// candidates per row step, 6 flops + one 64-bit compare per candidate.  Each lane keeps a (d2, original index)
+// minimum, merged by a 6-step shuffle tree; the cube radius doubles (1, 2, 4, ... r_max) until the best distance is
+// provably inside the cube.  The fused 17-term accumulation keeps one term per lane.
+constexpr int WQ_BLOCK = 256;  // 4 waves
+constexpr int WQ_WAVES = WQ_BLOCK / 64;
+constexpr int WQ_MAX_QPW = 16;  // queries per wave (fewer for small clouds so that the chip still fills)
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+struct LaneBest {
+  unsigned long long key;  // (d2 bits << 32) | original target index
+  float qx, qy, qz;        // the candidate itself (for the fused reduction)
+};
+
+__device__ __forceinline__ void consider(const float4& q, float px, float py, float pz, LaneBest& b) {
+  const float d = dist2(q.x, q.y, q.z, px, py, pz);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
+  if (d == d && key < b.key) {  // NaN never wins
+    b.key = key;
+    b.qx = q.x;
+    b.qy = q.y;
+    b.qz = q.z;
+  }
+}
+
+// wave-wide winner: key and candidate broadcast to every lane; returns false when no lane holds a candidate
+__device__ __forceinline__ bool merge_lanes(LaneBest& b) {
+  const unsigned long long wbest = wave_min_u64(b.key);
+  const unsigned long long owner = __ballot(b.key == wbest && wbest != kEmptyKey);
+  if (!owner) return false;
+  const int ol = __ffsll((long long)owner) - 1;
+  b.key = wbest;
+  b.qx = __shfl(b.qx, ol, 64);
+  b.qy = __shfl(b.qy, ol, 64);
+  b.qz = __shfl(b.qz, ol, 64);
+  return true;
+}
+
+// walk the non-empty rows among the 64 (lo, len) pairs held by the lanes, two rows per step
+__device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, int lo, int len, int lane, float px, float py,
+                                           float pz, LaneBest& b) {
+  unsigned long long mask = __ballot(len > 0);
+  while (mask) {  // wave-uniform
+    const int ra = __ffsll((long long)mask) - 1;
+    mask &= mask - 1;
+    const int alo = __shfl(lo, ra, 64), alen = __shfl(len, ra, 64);
+    int blo = 0, blen = 0;
+    if (mask) {
+      const int rb = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      blo = __shfl(lo, rb, 64);
+      blen = __shfl(len, rb, 64);
+    }
+    float4 qa, qb;
+    const bool va = lane < alen, vb = lane < blen;
+    if (va) qa = sorted[alo + lane];
+    if (vb) qb = sorted[blo + lane];
+    if (va) consider(qa, px, py, pz, b);
+    if (vb) consider(qb, px, py, pz, b);
+    for (int k = 64 + lane; k < alen; k += 64) consider(sorted[alo + k], px, py, pz, b);  // long rows
+    for (int k = 64 + lane; k < blen; k += 64) consider(sorted[blo + k], px, py, pz, b);
+  }
+}
+
+template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool ORDERED>
+__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src_ordered, int n_s, int qpw, Xform T,
+                                                           const float4* __restrict__ sorted,
+                                                           const int* __restrict__ cell_start, GridDesc g, float accept_thr,
+                                                           unsigned long long* __restrict__ keys,
+                                                           double* __restrict__ partials, int* __restrict__ unmatched,
+                                                           int* __restrict__ unmatched_count) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // fused reduction: lane t < 17 owns term t = qsel * psel (term order of accumulate_pair)
+  double acc = 0.0;
+  int qi = -1, pi = -1;  // which component of q / p this lane multiplies (-1 -> 1.0, qi 3 -> d2)
+  if (lane >= 1 && lane <= 3) pi = lane - 1;
+  else if (lane >= 4 && lane <= 6) qi = lane - 4;
+  else if (lane >= 7 && lane <= 15) { qi = (lane - 7) / 3; pi = (lane - 7) % 3; }
+  else if (lane == 16) qi = 3;
+
+  const int k0 = (blockIdx.x * WQ_WAVES + wave) * qpw;
+  for (int qq = 0; qq < qpw; ++qq) {
+    const int k = k0 + qq;
+    if (k >= n_s) break;  // wave-uniform
+    const float4 s = src_ordered[k];  // ORDERED: w = original index of the source point
+    const int i = ORDERED ? __float_as_int(s.w) : k;
+    float px, py, pz;
+    xform_point(T, s.x, s.y, s.z, px, py, pz);
+    LaneBest b{kEmptyKey, 0.f, 0.f, 0.f};
+    bool found = false;
+    if (finite3(px, py, pz)) {
+      int cx, cy, cz;
+      cell_of(g, px, py, pz, cx, cy, cz);
+      for (int rho = 1;; rho = min(2 * rho, g.r_max)) {  // cube radii 1, 2, 4, ... capped at r_max
+        const int side = 2 * rho + 1, nrows = side * side;
+        const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
+        const float inv_side = 1.0f / (float)side;
+        for (int rb = 0; rb < nrows; rb += 64) {
+          const int r = rb + lane;  // lane -> one cell row of the cube; (y, z) by an exact float reciprocal
+          const int zr = (int)(((float)r + 0.5f) * inv_side), yr = r - zr * side;
+          const int yy = cy + yr - rho, zz = cz + zr - rho;
+          int lo = 0, len = 0;
+          if (r < nrows && x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+            const int row = (zz * g.ny + yy) * g.nx;
+            lo = cell_start[row + x0];
+            len = cell_start[row + x1 + 1] - lo;
+          }
+          sweep_rows(sorted, lo, len, lane, px, py, pz, b);
+        }
+        const bool any = merge_lanes(b);
+        const float safe = (float)rho * g.h * kGridSafety;
+        if (any && __uint_as_float((unsigned int)(b.key >> 32)) <= safe * safe) {
+          found = true;
+          break;
+        }
+        if (rho >= g.r_max) break;
+      }
+    }
+    if constexpr (WRITE_KEYS) {
+      if (lane == 0) keys[i] = found ? b.key : kEmptyKey;
+    }
+    if constexpr (LIST_UNMATCHED) {
+      if (!found && lane == 0) unmatched[atomicAdd(unmatched_count, 1)] = i;
+    }
+    if constexpr (FUSE_REDUCE) {
+      const float d2 = __uint_as_float((unsigned int)(b.key >> 32));
+      if (found && d2 <= accept_thr) {  // wave-uniform
+        const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)b.qx : qi == 1 ? (double)b.qy : qi == 2 ? (double)b.qz : (double)d2);
+        const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
+        acc += a * c;
+      }
+    }
+  }
+  if constexpr (FUSE_REDUCE) {
+    __shared__ double wterm[WQ_WAVES][kReduceTerms];
+    if (lane < kReduceTerms) wterm[wave][lane] = acc;
+    __syncthreads();
+    if (threadIdx.x < kReduceTerms) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < WQ_WAVES; ++w) v += wterm[w][threadIdx.x];
+      partials[(size_t)blockIdx.x * kReduceTerms + threadIdx.x] = v;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t stream) {
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, stream, d_minmax6);
+  if (n > 0) {
+    int blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, stream, pts, n, d_minmax6);
+  }
+  return hipGetLastError();
+}
+
+void decode_bbox(const int enc[6], float lo[3], float hi[3]) {
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = dec_float(enc[a]);
+    hi[a] = dec_float(enc[3 + a]);
+  }
+}
+
+static hipError_t grid_sort(const float4* pts, int n, const GridDesc& g, const Xform* T, int* cell_of_point,
+                            int* rank_in_cell, int* counts, int* block_sums, int* d_stats2, float4* sorted,
+                            hipStream_t stream) {
+  const int ncells = g.nx * g.ny * g.nz;
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d_stats2, 0, 2 * sizeof(int), stream);
+  if (e != hipSuccess) return e;
+  if (n > 0) {
+    if (T)
+      hipLaunchKernelGGL(grid_count_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, *T, cell_of_point,
+                         rank_in_cell, counts);
+    else
+      hipLaunchKernelGGL(grid_count_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, Xform{},
+                         cell_of_point, rank_in_cell, counts);
+  }
+  const int nb = (ncells + kScanItems - 1) / kScanItems;
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats2);
+  hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nb, d_stats2);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats2);
+  if (n > 0)
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, cell_of_point,
+                       rank_in_cell, counts, sorted);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
+                             int* counts, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream) {
+  return grid_sort(pts, n, g, nullptr, cell_of_point, rank_in_cell, counts, block_sums, d_stats2, sorted, stream);
+}
+
+hipError_t launch_order_source(const float4* src, int n, const GridDesc& g_coarse, const Xform& T0, int* cell_of_point,
+                               int* rank_in_cell, int* counts, int* block_sums, int* d_stats2, float4* ordered,
+                               hipStream_t stream) {
+  return grid_sort(src, n, g_coarse, &T0, cell_of_point, rank_in_cell, counts, block_sums, d_stats2, ordered, stream);
+}
+
+// queries per wave: 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
+static int queries_per_wave(int n_s) {
+  static const int forced = [] { const char* v = std::getenv("ICPGPU_QPW"); return v ? std::atoi(v) : 0; }();
+  if (forced > 0) return forced;
+  int qpw = n_s / 8192;
+  if (qpw < 1) qpw = 1;
+  if (qpw > WQ_MAX_QPW) qpw = WQ_MAX_QPW;
+  return qpw;
+}
+
+int grid_search_blocks(int n_s) {
+  const int per_block = WQ_WAVES * queries_per_wave(n_s);
+  return (n_s + per_block - 1) / per_block;
+}
+
+hipError_t launch_nn_grid_search(const float4* src_ordered, bool ordered, int n_s, const Xform& T, const float4* sorted,
+                                 const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
+                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream) {
+  const int blocks = grid_search_blocks(n_s);
+  if (blocks == 0) return hipSuccess;
+  const int qpw = queries_per_wave(n_s);
+  dim3 grid(blocks), block(WQ_BLOCK);
+#define ICP_LAUNCH_WQ(K, F, U)                                                                                          \
+  do {                                                                                                                  \
+    if (ordered)                                                                                                        \
+      hipLaunchKernelGGL((nn_wave_kernel<K, F, U, true>), grid, block, 0, stream, src_ordered, n_s, qpw, T, sorted,     \
+                         cell_start, g, accept_thr, keys, partials, unmatched, unmatched_count);                        \
+    else                                                                                                                \
+      hipLaunchKernelGGL((nn_wave_kernel<K, F, U, false>), grid, block, 0, stream, src_ordered, n_s, qpw, T, sorted,    \
+                         cell_start, g, accept_thr, keys, partials, unmatched, unmatched_count);                        \
+  } while (0)
+  const bool k = keys != nullptr, f = partials != nullptr, u = unmatched != nullptr;
+  if (k && !f && u) ICP_LAUNCH_WQ(true, false, true);
+  else if (k && !f) ICP_LAUNCH_WQ(true, false, false);
+  else if (!k && f && !u) ICP_LAUNCH_WQ(false, true, false);
+  else if (k && f && !u) ICP_LAUNCH_WQ(true, true, false);
+  else return hipErrorInvalidValue;
+#undef ICP_LAUNCH_WQ
+  return hipGetLastError();
+}
+
+}  // namespace icpgpu

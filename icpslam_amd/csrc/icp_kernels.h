@@ -28,7 +28,7 @@ static constexpr int kReduceTerms = 17;   // n, Sp(3), Sq(3), Sqp(9), Sd2
 static constexpr int kMaxReduceBlocks = 1024;
 
 struct NnPlan {
-  int variant;        // 0 = LDS-tiled, 1 = scalar-load (SGPR broadcast)
+  int variant;        // 0 LDS-tiled, 1 scalar-load, 2 LDS + packed f32; +10 = 8 points per lane (tuning knob)
   int splits;         // target splits (grid.y)
   int tgt_per_split;  // multiple of the LDS tile
   int grid_x;
@@ -44,11 +44,55 @@ hipError_t launch_nn_brute(const float4* src, int n_s, const float4* tgt, int n_
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
                          float d2_threshold, double* partials, double* sums_out, hipStream_t stream);
 
+hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, hipStream_t stream);
+
 hipError_t launch_transform(const float4* src, int n_s, const Xform& T, float4* out, hipStream_t stream);
 
 hipError_t launch_fill_keys(unsigned long long* keys, int n, hipStream_t stream);
 
 // keys -> (idx, d2) arrays for the kernel-level C-ABI entry point.
 hipError_t launch_unpack_keys(const unsigned long long* keys, int n, int32_t* idx, float* d2, hipStream_t stream);
+
+// ---- uniform-grid accelerated exact NN (icp_grid.hip) -------------------------------------------------------
+// Target points are counting-sorted by cell (x fastest) into `sorted` (xyz + original index bits in w); a query
+// searches the 3x3x3 block of cells around it, then cubes of growing Chebyshev radius, and stops as soon as the
+// best squared distance is provably smaller than anything outside the searched cube.
+struct GridDesc {
+  float ox, oy, oz;  // origin (min corner)
+  float h, inv_h;    // cell size
+  int nx, ny, nz;
+  int r_max;         // last cube radius searched: r_max * h * kGridSafety >= cutoff distance
+};
+static constexpr float kGridSafety = 0.984375f;  // 63/64: covers the rounding of the float binning
+static constexpr int kScanItems = 4096;           // elements per block of the cell-count scan
+
+// encoded min/max (6 ints, see decode_bbox) of the finite points of a cloud
+hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t stream);
+void decode_bbox(const int enc[6], float lo[3], float hi[3]);  // host
+
+// Produces cell_start (exclusive scan of the per-cell counts, ncells+1 entries, in place in counts_then_start),
+// sorted[n_valid], d_stats2 = {n_valid, max cell population}.
+hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
+                             int* counts_then_start, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream);
+
+// Order the SOURCE cloud by the (coarse) target cell of T0*s so that consecutive queries share candidate rows.
+// `ordered` = float4 {x, y, z (untransformed), original-index bits}; every point keeps a slot.
+hipError_t launch_order_source(const float4* src, int n, const GridDesc& g_coarse, const Xform& T0, int* cell_of_point,
+                               int* rank_in_cell, int* counts, int* block_sums, int* d_stats2, float4* ordered,
+                               hipStream_t stream);
+
+// Exact NN of T*s among the grid's points for every point of `src_ordered` (ordered = false: the plain source cloud), guaranteed whenever the NN lies within the
+// cutoff the grid was built for; otherwise the point is reported unmatched (empty key).  One wave per query.
+//   keys      : optional (nullptr to skip) 8-byte keys, written at the ORIGINAL source index, ORIGINAL target indices
+//   partials  : optional fused a3+a4 reduction: grid_search_blocks(n_s) partials of 17 doubles
+//   unmatched : optional compaction of unmatched original source indices (count at unmatched_count[0], pre-zeroed)
+hipError_t launch_nn_grid_search(const float4* src_ordered, bool ordered, int n_s, const Xform& T, const float4* sorted,
+                                 const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
+                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream);
+int grid_search_blocks(int n_s);
+
+// brute force for a list of source indices (fallback for points the grid could not match); keys pre-filled empty.
+hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,
+                                const Xform& T, int num_cus, unsigned long long* keys, hipStream_t stream);
 
 }  // namespace icpgpu

@@ -17,48 +17,88 @@
 
 #include <math.h>
 
+#include "icp_device.h"
+
 namespace icpgpu {
 namespace {
 
 constexpr int NN_BLOCK = 256;  // 4 waves
-constexpr int NN_R = 4;        // source points held in registers per lane
 constexpr int NN_TILE = 1024;  // target points per LDS tile (16 KiB)
 constexpr int NN_CHUNK = 8;    // targets folded with v_min3 before one index-tracking compare
 
-__device__ __forceinline__ void xform_point(const Xform& T, float x, float y, float z, float& px, float& py, float& pz) {
-  px = __builtin_fmaf(T.m[2], z, __builtin_fmaf(T.m[1], y, __builtin_fmaf(T.m[0], x, T.m[3])));
-  py = __builtin_fmaf(T.m[6], z, __builtin_fmaf(T.m[5], y, __builtin_fmaf(T.m[4], x, T.m[7])));
-  pz = __builtin_fmaf(T.m[10], z, __builtin_fmaf(T.m[9], y, __builtin_fmaf(T.m[8], x, T.m[11])));
-}
-
-__device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, float py, float pz) {
-  const float dx = qx - px, dy = qy - py, dz = qz - pz;
-  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // a2: brute-force nearest neighbour.
-//   grid.x : blocks of NN_BLOCK*NN_R source points (each lane keeps NN_R transformed points in VGPRs)
+//   grid.x : blocks of NN_BLOCK*R source points (each lane keeps R transformed points in VGPRs)
 //   grid.y : target splits; partial results are merged with one 64-bit atomic min per (source point, split)
-//   VARIANT 0: target tiles staged in LDS, read back as wave-uniform ds_read_b128 broadcasts
-//   VARIANT 1: target streamed through the scalar cache (s_load), operands arrive as SGPRs
+//   VARIANT 0: target tiles staged in LDS, read back as wave-uniform ds_read broadcasts, scalar f32 VALU
+//   VARIANT 1: target streamed through the scalar cache (s_load), operands arrive as SGPRs, scalar f32 VALU
+//   VARIANT 2: as 0, but two source points per lane share each v_pk_add/v_pk_mul/v_pk_fma_f32 (same IEEE results)
 // Index tracking is done per chunk of NN_CHUNK targets: min3-fold the chunk's distances, one compare + two selects
 // per chunk, then re-scan the winning chunk once at the end for the exact (lowest) index.
 // ------------------------------------------------------------------------------------------------------------
-template <int VARIANT>
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2v dist2_pk(float qx, float qy, float qz, float2v px, float2v py, float2v pz) {
+  const float2v dx = qx - px, dy = qy - py, dz = qz - pz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+}
+
+// fold one chunk of NN_CHUNK targets (q) into the running (best, bchunk) of R source points
+template <int R, bool PACKED>
+__device__ __forceinline__ void fold_chunk(const float4 (&q)[NN_CHUNK], const float (&px)[R], const float (&py)[R],
+                                           const float (&pz)[R], float (&best)[R], int (&bchunk)[R], int chunk_start) {
+  if constexpr (PACKED) {
+    static_assert(R % 2 == 0, "packed variant needs an even number of points per lane");
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      const float2v x2 = {px[r], px[r + 1]}, y2 = {py[r], py[r + 1]}, z2 = {pz[r], pz[r + 1]};
+      float2v m = dist2_pk(q[0].x, q[0].y, q[0].z, x2, y2, z2);
+#pragma unroll
+      for (int u = 1; u < NN_CHUNK; ++u) {
+        const float2v d = dist2_pk(q[u].x, q[u].y, q[u].z, x2, y2, z2);
+        m.x = fminf(m.x, d.x);
+        m.y = fminf(m.y, d.y);
+      }
+      if (m.x < best[r]) {
+        best[r] = m.x;
+        bchunk[r] = chunk_start;
+      }
+      if (m.y < best[r + 1]) {
+        best[r + 1] = m.y;
+        bchunk[r + 1] = chunk_start;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float m = dist2(q[0].x, q[0].y, q[0].z, px[r], py[r], pz[r]);
+#pragma unroll
+      for (int u = 1; u < NN_CHUNK; ++u) m = fminf(m, dist2(q[u].x, q[u].y, q[u].z, px[r], py[r], pz[r]));
+      if (m < best[r]) {
+        best[r] = m;
+        bchunk[r] = chunk_start;
+      }
+    }
+  }
+}
+
+template <int VARIANT, int R>
 __global__ __launch_bounds__(NN_BLOCK) void nn_brute_kernel(const float4* __restrict__ src, int n_s,
                                                             const float4* __restrict__ tgt, int n_t, Xform T,
                                                             int tgt_per_split, int splits,
-                                                            unsigned long long* __restrict__ keys) {
+                                                            unsigned long long* __restrict__ keys,
+                                                            const int* __restrict__ list) {
+  // `list` (optional): the n_s logical source points are src[list[k]] and results go to keys[list[k]]
   const int tid = threadIdx.x;
-  const int base = blockIdx.x * (NN_BLOCK * NN_R);
+  const int base = blockIdx.x * (NN_BLOCK * R);
 
-  float px[NN_R], py[NN_R], pz[NN_R], best[NN_R];
-  int bchunk[NN_R];
+  float px[R], py[R], pz[R], best[R];
+  int bchunk[R], srci[R];
 #pragma unroll
-  for (int r = 0; r < NN_R; ++r) {
-    const int i = base + r * NN_BLOCK + tid;
-    const float4 s = src[i < n_s ? i : n_s - 1];
+  for (int r = 0; r < R; ++r) {
+    const int k = min(base + r * NN_BLOCK + tid, n_s - 1);
+    srci[r] = list ? list[k] : k;
+    const float4 s = src[srci[r]];
     xform_point(T, s.x, s.y, s.z, px[r], py[r], pz[r]);
     best[r] = INFINITY;
     bchunk[r] = -1;
@@ -67,7 +107,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn_brute_kernel(const float4* __rest
   const int j0 = blockIdx.y * tgt_per_split;
   const int j1 = min(n_t, j0 + tgt_per_split);
 
-  if constexpr (VARIANT == 0) {
+  if constexpr (VARIANT != 1) {
     __shared__ float4 tile[NN_TILE];
     for (int jt = j0; jt < j1; jt += NN_TILE) {
       __syncthreads();
@@ -83,16 +123,7 @@ __global__ __launch_bounds__(NN_BLOCK) void nn_brute_kernel(const float4* __rest
         float4 q[NN_CHUNK];
 #pragma unroll
         for (int u = 0; u < NN_CHUNK; ++u) q[u] = tile[c + u];
-#pragma unroll
-        for (int r = 0; r < NN_R; ++r) {
-          float m = dist2(q[0].x, q[0].y, q[0].z, px[r], py[r], pz[r]);
-#pragma unroll
-          for (int u = 1; u < NN_CHUNK; ++u) m = fminf(m, dist2(q[u].x, q[u].y, q[u].z, px[r], py[r], pz[r]));
-          if (m < best[r]) {
-            best[r] = m;
-            bchunk[r] = jt + c;
-          }
-        }
+        fold_chunk<R, VARIANT == 2>(q, px, py, pz, best, bchunk, jt + c);
       }
     }
   } else {
@@ -104,23 +135,14 @@ __global__ __launch_bounds__(NN_BLOCK) void nn_brute_kernel(const float4* __rest
         q[u] = tgt[j < n_t ? j : n_t - 1];
         if (j >= j1) q[u].x = INFINITY;
       }
-#pragma unroll
-      for (int r = 0; r < NN_R; ++r) {
-        float m = dist2(q[0].x, q[0].y, q[0].z, px[r], py[r], pz[r]);
-#pragma unroll
-        for (int u = 1; u < NN_CHUNK; ++u) m = fminf(m, dist2(q[u].x, q[u].y, q[u].z, px[r], py[r], pz[r]));
-        if (m < best[r]) {
-          best[r] = m;
-          bchunk[r] = jc;
-        }
-      }
+      fold_chunk<R, false>(q, px, py, pz, best, bchunk, jc);
     }
   }
 
 #pragma unroll
-  for (int r = 0; r < NN_R; ++r) {
-    const int i = base + r * NN_BLOCK + tid;
-    if (i >= n_s) continue;
+  for (int r = 0; r < R; ++r) {
+    if (base + r * NN_BLOCK + tid >= n_s) continue;
+    const int i = srci[r];
     unsigned long long key = kEmptyKey;
     if (bchunk[r] >= 0) {
       int idx = -1;
@@ -160,16 +182,10 @@ __global__ void unpack_keys_kernel(const unsigned long long* __restrict__ keys, 
 // a3 + a4: rejection predicate + 17-term reduction in double, deterministic order.
 //   stage 1: grid-stride over source points, per-lane double accumulators, wave shuffle tree, LDS across the
 //            4 waves, one 17-double partial per block
-//   stage 2: one workgroup of 17 waves (one per term) sums the partials in a fixed order
+//   stage 2: 17 workgroups (one per term) sum the partials in a fixed order
 // HBM traffic: 8 B key + 16 B source + 16 B gathered target per accepted point.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RED_BLOCK = 256;
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
 
 __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restrict__ src, int n_s,
                                                            const float4* __restrict__ tgt,
@@ -188,47 +204,24 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
       float px, py, pz;
       xform_point(T, s.x, s.y, s.z, px, py, pz);
       const float4 q = tgt[j];
-      const double p[3] = {(double)px, (double)py, (double)pz};
-      const double qq[3] = {(double)q.x, (double)q.y, (double)q.z};
-      acc[0] += 1.0;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        acc[1 + a] += p[a];
-        acc[4 + a] += qq[a];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) acc[7 + 3 * a + b] += qq[a] * p[b];
-      }
-      acc[16] += (double)d2;
+      accumulate_pair(acc, px, py, pz, q.x, q.y, q.z, d2);
     }
   }
-
-  __shared__ double wsum[RED_BLOCK / 64][kReduceTerms];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kReduceTerms; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) wsum[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kReduceTerms) {
-    double v = 0.0;
-#pragma unroll
-    for (int w = 0; w < RED_BLOCK / 64; ++w) v += wsum[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * kReduceTerms + threadIdx.x] = v;
-  }
+  block_reduce_store<RED_BLOCK / 64>(acc, partials);
 }
 
-// stage 2: 16 waves; wave w owns terms w, w+16; lane l adds partials l, l+64, ... in that order, then a fixed
-// shuffle tree -> bitwise reproducible run to run.
-__global__ __launch_bounds__(1024) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks,
-                                                            double* __restrict__ sums) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = wave; k < kReduceTerms; k += 16) {
-    double v = 0.0;
-    for (int b = lane; b < n_blocks; b += 64) v += partials[(size_t)b * kReduceTerms + k];
-    v = wave_sum(v);
-    if (lane == 0) sums[k] = v;
-  }
+// stage 2: one 256-thread workgroup per term; thread t adds partials t, t+256, ... in that order (independent loads),
+// then a fixed shuffle + LDS tree -> bitwise reproducible run to run.
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks,
+                                                           double* __restrict__ sums) {
+  const int k = blockIdx.x;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[(size_t)b * kReduceTerms + k];
+  v = wave_sum(v);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[k] = (w[0] + w[1]) + (w[2] + w[3]);
 }
 
 // a6: output cloud. 32 B/point of HBM traffic, float4 in / float4 out.
@@ -245,10 +238,13 @@ __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict
 
 }  // namespace
 
+static int points_per_lane(int variant) { return variant >= 10 ? 8 : 4; }
+
 NnPlan plan_nn_brute(int n_s, int n_t, int variant, int num_cus) {
   NnPlan p;
   p.variant = variant;
-  p.grid_x = (n_s + NN_BLOCK * NN_R - 1) / (NN_BLOCK * NN_R);
+  const int per_block = NN_BLOCK * points_per_lane(variant);
+  p.grid_x = (n_s + per_block - 1) / per_block;
   if (p.grid_x < 1) p.grid_x = 1;
   // aim for ~8 resident 256-thread workgroups per CU so the tail imbalance stays small; never split below one tile
   const int want_wgs = num_cus * 8;
@@ -270,12 +266,28 @@ hipError_t launch_nn_brute(const float4* src, int n_s, const float4* tgt, int n_
   if (n_s <= 0) return hipSuccess;
   if (n_t <= 0) return launch_fill_keys(keys, n_s, stream);
   dim3 grid(plan.grid_x, plan.splits), block(NN_BLOCK);
-  if (plan.variant == 1)
-    hipLaunchKernelGGL(nn_brute_kernel<1>, grid, block, 0, stream, src, n_s, tgt, n_t, T, plan.tgt_per_split,
-                       plan.splits, keys);
-  else
-    hipLaunchKernelGGL(nn_brute_kernel<0>, grid, block, 0, stream, src, n_s, tgt, n_t, T, plan.tgt_per_split,
-                       plan.splits, keys);
+#define ICP_LAUNCH_NN(V, R)                                                                                      \
+  hipLaunchKernelGGL((nn_brute_kernel<V, R>), grid, block, 0, stream, src, n_s, tgt, n_t, T, plan.tgt_per_split, \
+                     plan.splits, keys, (const int*)nullptr)
+  switch (plan.variant) {
+    case 1: ICP_LAUNCH_NN(1, 4); break;
+    case 2: ICP_LAUNCH_NN(2, 4); break;
+    case 10: ICP_LAUNCH_NN(0, 8); break;
+    case 12: ICP_LAUNCH_NN(2, 8); break;
+    default: ICP_LAUNCH_NN(0, 4); break;
+  }
+#undef ICP_LAUNCH_NN
+  return hipGetLastError();
+}
+
+hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,
+                                const Xform& T, int num_cus, unsigned long long* keys, hipStream_t stream) {
+  if (n_list <= 0 || n_t <= 0) return hipSuccess;
+  const NnPlan plan = plan_nn_brute(n_list, n_t, 0, num_cus);
+  dim3 grid(plan.grid_x, plan.splits), block(NN_BLOCK);
+  // keys of listed points are empty on entry, so the atomic-min merge is always valid (splits is forced > 1)
+  hipLaunchKernelGGL((nn_brute_kernel<0, 4>), grid, block, 0, stream, src, n_list, tgt, n_t, T, plan.tgt_per_split, 2,
+                     keys, list);
   return hipGetLastError();
 }
 
@@ -285,7 +297,11 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(1024), 0, stream, partials, blocks, sums_out);
+  return launch_reduce_final(partials, blocks, sums_out, stream);
+}
+
+hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(256), 0, stream, partials, n_blocks, sums_out);
   return hipGetLastError();
 }
 

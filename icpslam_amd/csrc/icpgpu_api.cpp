@@ -7,6 +7,7 @@
 // There is deliberately no CPU fallback: if HIP or the device is unusable every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cfloat>
 #include <cmath>
@@ -41,6 +42,28 @@ struct Cloud {
   const float4* data() const { return static_cast<const float4*>(buf.ptr); }
 };
 
+// Uniform grid over the target (icp_grid.hip), built lazily for the cutoff of the current parameters.
+struct GridIndex {
+  bool built = false, usable = false;
+  uint64_t version = 0;      // target version it was built for
+  float cutoff = 0.f;        // correspondence distance it was built for
+  GridDesc g{};
+  int n_binned = 0, max_pop = 0;
+  DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
+};
+
+// Source cloud re-ordered by (coarse) target cell so that the 64 queries of a wave share candidate rows.
+struct SourceOrder {
+  bool usable = false;
+  uint64_t src_version = 0, grid_version = 0;
+  float cutoff = 0.f;
+  DeviceBuf ordered, table, cell_of_point, rank, block_sums, ints;
+};
+
+constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
+constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
+constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-force kernel is launch-latency bound anyway
+
 }  // namespace
 
 struct icpgpu_ctx {
@@ -51,7 +74,12 @@ struct icpgpu_ctx {
   icpgpu_params params{};
   Cloud src, tgt;
   DeviceBuf keys, partials, sums, out, idx, d2;
-  double* h_sums = nullptr;  // pinned
+  GridIndex grid;            // acceleration structure over the current target
+  SourceOrder order;         // source cloud in target-cell order
+  uint64_t src_version = 1;  // bumped whenever the source cloud changes
+  uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
+  double* h_sums = nullptr;  // pinned (17 doubles)
+  int* h_ints = nullptr;     // pinned (8 ints: bbox / stats / counters)
   bool have_final = false;
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
@@ -163,32 +191,223 @@ struct SweepTimes {
   float nn_ms = 0.f, reduce_ms = 0.f;
 };
 
+// (Re)build the grid over the target if the parameters ask for it. Leaves c->grid.usable = false when the grid
+// cannot help (tiny / degenerate / too dense a target): the caller then uses the brute-force kernel.
+int ensure_grid(icpgpu_ctx* c, float accept_thr) {
+  GridIndex& G = c->grid;
+  const int n_t = (int)c->tgt.n;
+  const int mode = c->params.nn_mode;
+  const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && c->tgt.n >= kGridMinTarget);
+  double cut = std::sqrt((double)accept_thr) * (1.0 + 1e-6);
+  if (!want || n_t <= 0 || !(accept_thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
+    G.usable = false;
+    G.built = false;
+    return ICPGPU_OK;
+  }
+  const float cutoff = (float)cut;
+  if (G.built && G.version == c->tgt_version && G.cutoff == cutoff) return ICPGPU_OK;
+  G.built = true;
+  G.usable = false;
+  G.version = c->tgt_version;
+  G.cutoff = cutoff;
+
+  int rc = ensure(c, G.ints, 8 * sizeof(int));
+  if (rc) return rc;
+  int* d_ints = static_cast<int*>(G.ints.ptr);
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_bbox(c->tgt.data(), n_t, d_ints, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float lo[3], hi[3];
+  decode_bbox(c->h_ints, lo, hi);
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite target point
+
+  // cell size: cutoff / ICPGPU_GRID_DIV (default 4; cube radii double, so an unmatched point costs 4 cubes), grown
+  // until the dense table fits
+  double div = 4.0;
+  if (const char* v = std::getenv("ICPGPU_GRID_DIV")) div = std::max(1.0, std::atof(v));
+  double h = cut / div;
+  long long nx, ny, nz;
+  for (;;) {
+    nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
+    ny = (long long)std::floor((hi[1] - lo[1]) / h) + 3;
+    nz = (long long)std::floor((hi[2] - lo[2]) / h) + 3;
+    if (nx * ny * nz <= kMaxGridCells && nx < (1 << 20) && ny < (1 << 20) && nz < (1 << 20)) break;
+    h *= 1.15;
+    if (!std::isfinite(h)) return ICPGPU_OK;
+  }
+  GridDesc g;
+  g.h = (float)h;
+  g.inv_h = 1.0f / g.h;
+  g.ox = lo[0] - g.h;
+  g.oy = lo[1] - g.h;
+  g.oz = lo[2] - g.h;
+  g.nx = (int)nx;
+  g.ny = (int)ny;
+  g.nz = (int)nz;
+  g.r_max = (int)std::ceil(cut / ((double)g.h * (double)kGridSafety));
+  if (g.r_max < 1) g.r_max = 1;
+  if (!std::isfinite(g.ox) || !std::isfinite(g.oy) || !std::isfinite(g.oz) || !(g.inv_h > 0.f) || !std::isfinite(g.inv_h))
+    return ICPGPU_OK;
+  const long long ncells = nx * ny * nz;
+  const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
+  if ((rc = ensure(c, G.sorted, (size_t)n_t * sizeof(float4)))) return rc;
+  if ((rc = ensure(c, G.cell_start, (size_t)(ncells + 1) * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
+  HIP_TRY(c, launch_grid_build(c->tgt.data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
+                               static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6,
+                               static_cast<float4*>(G.sorted.ptr), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.grid_builds += 1;
+  c->prof.grid_build_ms += ms;
+  G.g = g;
+  G.n_binned = c->h_ints[6];
+  G.max_pop = c->h_ints[7];
+  G.usable = G.n_binned > 0 && G.max_pop <= kMaxCellPopulation;
+  return ICPGPU_OK;
+}
+
+// Order the source by target cell under T0 (once per source/grid pair: later transforms of an ICP run stay close to
+// T0, and the ordering only affects speed, never results).
+int ensure_source_order(icpgpu_ctx* c, const Xform& T0) {
+  SourceOrder& S = c->order;
+  const GridIndex& G = c->grid;
+  const int n_s = (int)c->src.n;
+  // Off by default: with one wave per query the caller's order measures no slower than cell order, and skipping the
+  // re-ordering keeps the fused reduction's summation order (hence the result bits) independent of atomic ranks.
+  static const bool enabled = std::getenv("ICPGPU_ORDER_SOURCE") != nullptr;
+  if (!enabled || !G.usable || n_s <= 0) {
+    S.usable = false;
+    return ICPGPU_OK;
+  }
+  if (S.usable && S.src_version == c->src_version && S.grid_version == G.version && S.cutoff == G.cutoff) return ICPGPU_OK;
+  S.usable = false;
+  // coarsen the target grid until the count table is small (ordering needs locality, not exact cells)
+  GridDesc g = G.g;
+
+  while ((long long)g.nx * g.ny * g.nz > (2ll << 20)) {
+    g.h *= 2.0f;
+    g.inv_h = 1.0f / g.h;
+    g.nx = (g.nx + 1) / 2;
+    g.ny = (g.ny + 1) / 2;
+    g.nz = (g.nz + 1) / 2;
+  }
+  const long long ncells = (long long)g.nx * g.ny * g.nz;
+  const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
+  int rc;
+  if ((rc = ensure(c, S.ordered, (size_t)n_s * sizeof(float4)))) return rc;
+  if ((rc = ensure(c, S.table, (size_t)(ncells + 1) * sizeof(int)))) return rc;
+  if ((rc = ensure(c, S.cell_of_point, (size_t)n_s * sizeof(int)))) return rc;
+  if ((rc = ensure(c, S.rank, (size_t)n_s * sizeof(int)))) return rc;
+  if ((rc = ensure(c, S.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
+  if ((rc = ensure(c, S.ints, 2 * sizeof(int)))) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_order_source(c->src.data(), n_s, g, T0, static_cast<int*>(S.cell_of_point.ptr), static_cast<int*>(S.rank.ptr),
+                                 static_cast<int*>(S.table.ptr), static_cast<int*>(S.block_sums.ptr), static_cast<int*>(S.ints.ptr),
+                                 static_cast<float4*>(S.ordered.ptr), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, S.ints.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.grid_build_ms += ms;
+  if (c->h_ints[0] != n_s) return fail(c, ICPGPU_ERR_HIP, "source ordering lost points (%d of %d)", c->h_ints[0], n_s);
+  S.usable = true;
+  S.src_version = c->src_version;
+  S.grid_version = G.version;
+  S.cutoff = G.cutoff;
+  return ICPGPU_OK;
+}
+
+// Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
+// the brute-force kernel. Does not synchronise except for the 4-byte unmatched count.
+int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys) {
+  GridIndex& G = c->grid;
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  int rc = ensure(c, G.unmatched, (size_t)(n_s + 1) * sizeof(int));
+  if (rc) return rc;
+  int* d_list = static_cast<int*>(G.unmatched.ptr);
+  int* d_count = d_list + n_s;
+  HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
+  if ((rc = ensure_source_order(c, T))) return rc;
+  HIP_TRY(c, launch_nn_grid_search(c->order.usable ? static_cast<const float4*>(c->order.ordered.ptr) : c->src.data(),
+                                   c->order.usable, n_s, T, static_cast<const float4*>(G.sorted.ptr),
+                                   static_cast<const int*>(G.cell_start.ptr), G.g, 0.f, keys, nullptr, d_list, d_count,
+                                   c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int n_un = c->h_ints[0];
+  c->prof.grid_fallback_points += (uint64_t)n_un;
+  if (n_un > 0)
+    HIP_TRY(c, launch_nn_brute_list(c->src.data(), d_list, n_un, c->tgt.data(), n_t, T, c->num_cus, keys, c->stream));
+  return ICPGPU_OK;
+}
+
+bool grid_ready(const icpgpu_ctx* c) { return c->grid.usable && c->grid.version == c->tgt_version; }
+
 // One NN sweep + reduction with transform T; leaves the 17 sums in c->h_sums. Synchronises the stream.
-int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, SweepTimes* times) {
+//   open_range = false : ICP iteration; correspondences beyond thr are rejected, so the grid search (cut at the
+//                        correspondence distance) is complete by itself and the reduction is fused into it
+//   open_range = true  : fitness; every point needs its true NN -> grid + brute-force completion + reduce kernel
+int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, SweepTimes* times) {
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   int rc = ensure(c, c->keys, (size_t)(n_s ? n_s : 1) * sizeof(unsigned long long));
   if (rc) return rc;
   auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
-  const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
-  if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+  auto* partials = static_cast<double*>(c->partials.ptr);
+  auto* d_sums = static_cast<double*>(c->sums.ptr);
+  const bool use_grid = grid_ready(c) && n_s > 0 && (open_range || thr <= c->grid.cutoff * c->grid.cutoff);
+  if (use_grid && (rc = ensure_source_order(c, T))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, T, plan, keys, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, static_cast<double*>(c->partials.ptr),
-                           static_cast<double*>(c->sums.ptr), c->stream));
+  if (use_grid && !open_range) {
+    const int blocks = grid_search_blocks(n_s);
+    if ((rc = ensure(c, c->partials, (size_t)blocks * kReduceTerms * sizeof(double)))) return rc;
+    partials = static_cast<double*>(c->partials.ptr);
+    HIP_TRY(c, launch_nn_grid_search(c->order.usable ? static_cast<const float4*>(c->order.ordered.ptr) : c->src.data(),
+                                     c->order.usable, n_s, T, static_cast<const float4*>(c->grid.sorted.ptr),
+                                     static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
+                                     nullptr, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, launch_reduce_final(partials, blocks, d_sums, c->stream));
+  } else {
+    if (use_grid) {
+      if ((rc = nn_keys_grid(c, T, keys))) return rc;
+    } else {
+      const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
+      if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+      HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+      HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, T, plan, keys, c->stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
+    partials = static_cast<double*>(c->partials.ptr);
+    HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, partials, d_sums, c->stream));
+  }
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.ptr, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_sums, d_sums, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   SweepTimes t;
   HIP_TRY(c, hipEventElapsedTime(&t.nn_ms, c->ev[0], c->ev[1]));
   HIP_TRY(c, hipEventElapsedTime(&t.reduce_ms, c->ev[1], c->ev[2]));
-  c->prof.nn_launches += (n_s > 0);
-  c->prof.nn_ms += t.nn_ms;
-  c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
-  c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  if (use_grid) {
+    c->prof.grid_launches += 1;
+    c->prof.grid_ms += t.nn_ms;
+    c->prof.grid_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + (open_range ? 8ull * (uint64_t)n_s : 136ull * (uint64_t)grid_search_blocks(n_s));
+  } else {
+    c->prof.nn_launches += (n_s > 0);
+    c->prof.nn_ms += t.nn_ms;
+    c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
+    c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  }
   c->prof.reduce_launches += 1;
   c->prof.reduce_ms += t.reduce_ms;
-  c->prof.reduce_bytes += 40ull * (uint64_t)n_s + 136;
+  c->prof.reduce_bytes += (use_grid && !open_range) ? 136ull * (uint64_t)grid_search_blocks(n_s) : 40ull * (uint64_t)n_s + 136;
   if (times) *times = t;
   return ICPGPU_OK;
 }
@@ -242,6 +461,10 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   ConvergenceCriteria crit(P.max_iterations, P.transformation_epsilon, P.euclidean_fitness_epsilon,
                            P.force_iterations != 0);
   const float thr = threshold_from(P.max_correspondence_distance * P.max_correspondence_distance);
+  {
+    int rc = ensure_grid(c, thr);
+    if (rc) return rc;
+  }
 
   int nr_iter = 0, state = ICPGPU_NOT_CONVERGED;
   bool converged = false;
@@ -249,7 +472,7 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   double mse = 0.0;
   for (;;) {
     SweepTimes st;
-    int rc = nn_and_reduce(c, to_xform(final_T), thr, &st);
+    int rc = nn_and_reduce(c, to_xform(final_T), thr, false, &st);
     if (rc) return rc;
     dev_ms += st.nn_ms + st.reduce_ms;
     const double* sums = c->h_sums;
@@ -283,7 +506,7 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   const Xform Tf = to_xform(final_T);
   if (want_fitness) {
     SweepTimes st;
-    int rc = nn_and_reduce(c, Tf, FLT_MAX, &st);
+    int rc = nn_and_reduce(c, Tf, FLT_MAX, true, &st);
     if (rc) return rc;
     dev_ms += st.nn_ms + st.reduce_ms;
     res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
@@ -339,7 +562,7 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   icpgpu_default_params(&c->params);
-  if (const char* v = std::getenv("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v) == 1 ? 1 : 0;
+  if (const char* v = std::getenv("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
 
   auto bail = [&](const char* what, hipError_t err) {
     std::string msg = std::string(what) + ": " + hipGetErrorString(err);
@@ -352,6 +575,8 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), kReduceTerms * sizeof(double), hipHostMallocDefault)) !=
       hipSuccess)
+    return bail("hipHostMalloc", e);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ints), 8 * sizeof(int), hipHostMallocDefault)) != hipSuccess)
     return bail("hipHostMalloc", e);
   if ((e = hipMalloc(&c->partials.ptr, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double))) != hipSuccess)
     return bail("hipMalloc(partials)", e);
@@ -374,7 +599,22 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->out);
   release(c->idx);
   release(c->d2);
+  release(c->grid.sorted);
+  release(c->grid.cell_start);
+  release(c->grid.cell_of_point);
+  release(c->grid.rank);
+  release(c->grid.block_sums);
+  release(c->grid.ints);
+  release(c->grid.unmatched);
+  release(c->grid.leftover);
+  release(c->order.ordered);
+  release(c->order.table);
+  release(c->order.cell_of_point);
+  release(c->order.rank);
+  release(c->order.block_sums);
+  release(c->order.ints);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -404,18 +644,22 @@ int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
 
 int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
+  c->src_version++;
   return set_cloud_host(c, c->src, xyzw, n);
 }
 int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
+  c->tgt_version++;
   return set_cloud_host(c, c->tgt, xyzw, n);
 }
 int icpgpu_set_source_device(icpgpu_ctx* c, const void* d, size_t n) {
   ENTER(c);
+  c->src_version++;
   return set_cloud_device(c, c->src, d, n);
 }
 int icpgpu_set_target_device(icpgpu_ctx* c, const void* d, size_t n) {
   ENTER(c);
+  c->tgt_version++;
   return set_cloud_device(c, c->tgt, d, n);
 }
 
@@ -423,6 +667,8 @@ int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
   ENTER(c);
   if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "promote_source_to_target: no source set");
   std::swap(c->src, c->tgt);
+  c->tgt_version++;
+  c->src_version++;
   c->src.n = 0;
   c->src.set = false;
   if (c->src.buf.external) c->src.buf = DeviceBuf{};
@@ -443,7 +689,9 @@ int icpgpu_fitness(icpgpu_ctx* c, double max_range, double* out) {
   if (!out) return fail(c, ICPGPU_ERR_INVALID_ARG, "out is null");
   if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "fitness: source and target must be set first");
   const Mat4d T = c->have_final ? c->final_T : mat4_identity();
-  int rc = nn_and_reduce(c, to_xform(T), threshold_from(max_range), nullptr);
+  int rc = ensure_grid(c, threshold_from(c->params.max_correspondence_distance * c->params.max_correspondence_distance));
+  if (rc) return rc;
+  rc = nn_and_reduce(c, to_xform(T), threshold_from(max_range), true, nullptr);
   if (rc) return rc;
   *out = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   return ICPGPU_OK;
@@ -454,8 +702,10 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   ENTER(c);
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   for (size_t k = 0; k < n_pairs; ++k) {
+      c->src_version++;
     int rc = set_cloud_host(c, c->src, src[k], n_src[k]);
     if (rc) return rc;
+    c->tgt_version++;
     rc = set_cloud_host(c, c->tgt, tgt[k], n_tgt[k]);
     if (rc) return rc;
     rc = align_p2p(c, nullptr, nullptr, want_fitness, &results[k]);
@@ -474,11 +724,21 @@ int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {
   if (rc) return rc;
   if ((rc = ensure(c, c->idx, (size_t)n_s * sizeof(int32_t)))) return rc;
   if ((rc = ensure(c, c->d2, (size_t)n_s * sizeof(float)))) return rc;
+  if ((rc = ensure_grid(c, threshold_from(c->params.max_correspondence_distance * c->params.max_correspondence_distance))))
+    return rc;
   auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
-  const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
-  if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+  const Xform X = to_xform(T);
+  const bool use_grid = grid_ready(c);
+  if (use_grid && (rc = ensure_source_order(c, X))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, to_xform(T), plan, keys, c->stream));
+  if (use_grid) {
+    if ((rc = nn_keys_grid(c, X, keys))) return rc;
+  } else {
+    const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
+    if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, X, plan, keys, c->stream));
+  }
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(c, launch_unpack_keys(keys, n_s, static_cast<int32_t*>(c->idx.ptr), static_cast<float*>(c->d2.ptr), c->stream));
   HIP_TRY(c, hipMemcpyAsync(idx, c->idx.ptr, (size_t)n_s * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -486,10 +746,16 @@ int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;
   HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-  c->prof.nn_launches += 1;
-  c->prof.nn_ms += ms;
-  c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
-  c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  if (use_grid) {
+    c->prof.grid_launches += 1;
+    c->prof.grid_ms += ms;
+    c->prof.grid_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  } else {
+    c->prof.nn_launches += 1;
+    c->prof.nn_ms += ms;
+    c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
+    c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
+  }
   return ICPGPU_OK;
 }
 
@@ -499,6 +765,10 @@ int icpgpu_reduce(icpgpu_ctx* c, const float* T, double max_dist, double sums[17
   if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "reduce: source and target must be set first");
   if (!c->keys.ptr || c->keys.cap < c->src.n * sizeof(unsigned long long))
     return fail(c, ICPGPU_ERR_NO_INPUT, "reduce: no nearest-neighbour sweep to reduce (call icpgpu_nn first)");
+  {
+    int rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double));
+    if (rc) return rc;
+  }
   HIP_TRY(c, launch_reduce(c->src.data(), (int)c->src.n, c->tgt.data(), static_cast<unsigned long long*>(c->keys.ptr),
                            to_xform(T), threshold_from(max_dist * max_dist), static_cast<double*>(c->partials.ptr),
                            static_cast<double*>(c->sums.ptr), c->stream));

@@ -100,7 +100,7 @@ typedef struct {
 /* Kernel-level accounting since the last icpgpu_profile_reset(); times are HIP-event times on the
  * context's own stream (this is what bench.py's roofline object is computed from). */
 typedef struct {
-  uint64_t nn_launches;       /* correspondence-search launches (a2) */
+  uint64_t nn_launches;       /* brute-force correspondence-search launches (a2) */
   double nn_ms;               /* their summed duration */
   uint64_t nn_pairs;          /* point pairs evaluated by those launches */
   uint64_t nn_bytes;          /* algorithmic bytes: 16*(N_s+N_t) + 8*N_s per launch */
@@ -112,6 +112,12 @@ typedef struct {
   uint64_t transform_bytes;
   uint64_t iterations;        /* ICP iterations executed */
   uint64_t aligns;            /* align calls */
+  uint64_t grid_launches;     /* grid-accelerated correspondence launches (a2, with a3+a4 fused inside ICP iterations) */
+  double grid_ms;
+  uint64_t grid_bytes;        /* algorithmic bytes: 16*(N_s+N_t) + output per launch */
+  uint64_t grid_builds;       /* target grid (re)builds: bbox + counting sort */
+  double grid_build_ms;
+  uint64_t grid_fallback_points; /* points finished by the brute-force kernel (no neighbour within the cutoff) */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

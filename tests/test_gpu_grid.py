@@ -1,0 +1,126 @@
+"""GPU parity of the grid-accelerated correspondence search: it must return exactly what brute force returns
+(same keys bit for bit) and the same alignment, on ordinary scans and on inputs that stress the grid."""
+import numpy as np
+import pytest
+
+import oracle
+from icpslam_amd import NN_AUTO, NN_BRUTE, NN_GRID, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _nn(ctx, src, tgt, T, mode, r=1.0):
+    ctx.set_params(ctx.default_params(), nn_mode=mode, max_correspondence_distance=r)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    ctx.profile_reset()
+    idx, d2 = ctx.nn(T)
+    return idx, d2, ctx.profile()
+
+
+@pytest.mark.parametrize("n_s,n_t,seed", [(5000, 5000, 1), (20000, 30000, 2), (50000, 50000, 3), (3000, 100000, 4)])
+def test_grid_nn_equals_brute_and_oracle(ctx, n_s, n_t, seed):
+    src, tgt, Tgt = synth.make_pair(n_s, n_t, seed=seed)
+    T = Tgt.copy()
+    T[:3, 3] += 0.1
+    ig, dg, pg = _nn(ctx, src, tgt, T, NN_GRID)
+    ib, db, pb = _nn(ctx, src, tgt, T, NN_BRUTE)
+    assert pg.grid_launches == 1 and pg.nn_launches == 0 and pb.grid_launches == 0 and pb.nn_launches == 1
+    assert np.array_equal(ig, ib) and np.array_equal(dg.view(np.uint32), db.view(np.uint32))
+    io, do = oracle.nn(src, tgt, T)
+    assert np.array_equal(ig, io) and np.array_equal(dg.view(np.uint32), do.view(np.uint32))
+
+
+@pytest.mark.parametrize("r", [0.05, 0.3, 2.5, 30.0])
+def test_grid_nn_other_cutoffs(ctx, r):
+    src, tgt, _ = synth.make_pair(8000, 8000, seed=11)
+    ig, dg, _ = _nn(ctx, src, tgt, np.eye(4), NN_GRID, r)
+    ib, db, _ = _nn(ctx, src, tgt, np.eye(4), NN_BRUTE, r)
+    assert np.array_equal(ig, ib) and np.array_equal(dg.view(np.uint32), db.view(np.uint32))
+
+
+def test_grid_with_far_outlier_duplicates_and_nonfinite(ctx):
+    src, tgt, _ = synth.make_pair(6000, 6000, seed=12)
+    tgt = tgt.copy()
+    tgt[10, :3] = (4000.0, -3000.0, 900.0)      # stretches the bounding box -> coarse cells
+    tgt[11, :3] = np.nan                          # never binned, never matched
+    tgt[100:400, :3] = tgt[99, :3]                # 300 duplicates in one cell: ties resolve to the lowest index
+    src = src.copy()
+    src[5, :3] = (1e6, 1e6, 1e6)                 # far outside the grid -> brute-force completion
+    src[6, :3] = np.inf
+    ig, dg, pg = _nn(ctx, src, tgt, np.eye(4), NN_GRID)
+    ib, db, _ = _nn(ctx, src, tgt, np.eye(4), NN_BRUTE)
+    assert np.array_equal(ig, ib) and np.array_equal(dg.view(np.uint32), db.view(np.uint32))
+    assert ig[6] == -1
+    assert not ((ig >= 100) & (ig < 400)).any()
+
+
+def test_grid_degenerate_target_falls_back(ctx):
+    src, _, _ = synth.make_pair(5000, 10, seed=13)
+    tgt = np.ones((6000, 4), np.float32)
+    tgt[:, :3] = (1.0, 2.0, 3.0)                  # every target point identical: one cell holds everything
+    ig, dg, pg = _nn(ctx, src, tgt, np.eye(4), NN_GRID)
+    assert pg.grid_launches == 0 and pg.nn_launches == 1          # max cell population guard -> brute force
+    assert (ig == 0).all()
+
+
+@pytest.mark.parametrize("mode", [NN_BRUTE, NN_GRID, NN_AUTO])
+@pytest.mark.parametrize("n,seed,iters", [(5000, 1, 10), (30000, 21, 30)])
+def test_align_all_modes_match_oracle(ctx, mode, n, seed, iters):
+    src, tgt, _ = synth.make_pair(n, n, seed=seed)
+    ctx.set_params(ctx.default_params(), max_iterations=iters, nn_mode=mode)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    got = ctx.align(want_fitness=True, want_cloud=True)
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=iters), want_fitness=True, want_cloud=True)
+    assert (got["converged"], got["iterations"], got["state"], got["n_corr"]) == \
+           (ref["converged"], ref["iterations"], ref["state"], ref["n_corr"])
+    assert np.abs(got["T"][:3, :3] - ref["T"][:3, :3]).max() <= 1e-4
+    assert np.linalg.norm(got["T"][:3, 3] - ref["T"][:3, 3]) <= 1e-3
+    assert abs(got["mse"] - ref["mse"]) <= 1e-9 * max(1.0, ref["mse"])
+    assert abs(got["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+
+
+def test_grid_rebuilds_when_target_or_cutoff_changes(ctx):
+    a, b, _ = synth.make_pair(6000, 6000, seed=31)
+    c, d, _ = synth.make_pair(6000, 7000, seed=32)
+    ctx.set_params(ctx.default_params(), nn_mode=NN_GRID)
+    ctx.profile_reset()
+    ctx.set_source(a)
+    ctx.set_target(b)
+    r1 = ctx.align()
+    r1b = ctx.align()                              # same target, same cutoff: no rebuild
+    assert ctx.profile().grid_builds == 1
+    ctx.set_target(d)
+    ctx.set_source(c)
+    r2 = ctx.align()
+    assert ctx.profile().grid_builds == 2
+    ctx.set_params(max_correspondence_distance=0.5)
+    r3 = ctx.align()
+    assert ctx.profile().grid_builds == 3
+    assert np.array_equal(r1["T"], r1b["T"])
+    ref2 = oracle.icp_align(c, d)
+    ref3 = oracle.icp_align(c, d, oracle.default_params(max_correspondence_distance=0.5))
+    for got, ref in ((r2, ref2), (r3, ref3)):
+        assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"]
+        assert np.abs(got["T"] - ref["T"]).max() <= 1e-4
+
+
+def test_promote_source_to_target_sequence(ctx):
+    """The odometer's loop: register scan k+1 against scan k, then `*prev_cloud_ = *curr_cloud_` (icp_odometer.cpp:209)."""
+    rng = np.random.default_rng(5)
+    scene = synth.make_scene(77)
+    poses = [np.eye(4)]
+    for _ in range(3):
+        poses.append(poses[-1] @ synth.random_motion(rng))
+    scans = [synth.scan(scene, P, 8000, seed=100 + k) for k, P in enumerate(poses)]
+    ctx.set_params(ctx.default_params())
+    ctx.set_source(scans[0])
+    ctx.promote_source_to_target()
+    for k in range(1, 4):
+        ctx.set_source(scans[k])
+        got = ctx.align()
+        ref = oracle.icp_align(scans[k], scans[k - 1])
+        assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"]
+        assert np.abs(got["T"] - ref["T"]).max() <= 1e-4
+        ctx.promote_source_to_target()
