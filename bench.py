@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="200kx200k", choices=sorted(WORKLOADS))
     ap.add_argument("--iters", type=int, default=10, help="forced ICP iterations per scan pair")
+    ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid"],
+                    help="correspondence search: auto (grid-accelerated exact NN where it helps), brute (LDS-tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
     return ap.parse_args()
@@ -95,11 +97,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from icpslam_amd import Context
+    from icpslam_amd import NN_AUTO, NN_BRUTE, NN_GRID, Context
 
+    nn_mode = {"auto": NN_AUTO, "brute": NN_BRUTE, "grid": NN_GRID}[a.nn]
     src, tgt = make_workload(a.workload, seed=4 + rank)
     ctx = Context(local_rank)
-    ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1)
+    ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1, nn_mode=nn_mode)
     ctx.set_source(src)      # inputs resident in HBM before the timed region
     ctx.set_target(tgt)
 
@@ -140,20 +143,57 @@ def main():
     torch.cuda.synchronize()
     pair_s = (time.perf_counter() - t1) / n_pair_runs
 
+    # the brute-force kernel (north_star's design) measured in the same process for its own roofline line
+    brute = None
+    if rank == 0:
+        ctx.set_params(nn_mode=NN_BRUTE, max_iterations=2)
+        ctx.align()
+        ctx.profile_reset()
+        ctx.align()
+        pb = ctx.profile()
+        brute = {"avg_launch_ms": pb.nn_ms / max(1, pb.nn_launches), "launches": int(pb.nn_launches)}
+        ctx.set_params(nn_mode=nn_mode, max_iterations=a.iters)
+
     if rank == 0:
         n_s, n_t = src.shape[0], tgt.shape[0]
-        nn_ms = prof.nn_ms / max(1, prof.nn_launches)
-        flops = 8.0 * n_s * n_t                      # F_iter = 8 * N_s * N_t
-        alg_bytes = 16.0 * (n_s + n_t) + 8.0 * n_s    # both clouds once + 8 B key per source point
-        tf = flops / (nn_ms * 1e-3) / 1e12
-        gbs = alg_bytes / (nn_ms * 1e-3) / 1e9
-        traffic = None
+        flops = 8.0 * n_s * n_t                      # F_iter = 8 * N_s * N_t (brute force)
+        alg_bytes_keys = 16.0 * (n_s + n_t) + 8.0 * n_s   # both clouds once + 8 B key per source point
+        alg_bytes_fused = 16.0 * (n_s + n_t) + 64.0       # fused design lower bound
+        used_grid = prof.grid_launches > 0
+        traffic = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(a.workload, {}).get("nn_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(a.workload, {})
             except Exception:
-                traffic = None
+                traffic = {}
+        b_ms = brute["avg_launch_ms"]
+        b_tf = flops / (b_ms * 1e-3) / 1e12
+        brute_roofline = {
+            "kernel": "nn_brute_kernel<0,4> (LDS-tiled brute force)", "bound": "mfma", "achieved": b_tf,
+            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": b_tf / FP32_PEAK_TFLOPS,
+            "traffic": traffic.get("nn_brute_hbm_bytes_per_launch"), "avg_launch_ms": b_ms,
+            "hbm": {"achieved": alg_bytes_keys / (b_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": alg_bytes_keys / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": alg_bytes_keys},
+            "note": "brute-force NN is FP32-compute-bound (8*Ns*Nt flop per launch); peak = f32 dense MFMA peak = f32 "
+                    "vector peak (157.3 TFLOP/s)"}
+        if used_grid:
+            g_ms = prof.grid_ms / max(1, prof.grid_launches)
+            gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
+            roofline = {
+                "kernel": "nn_wave_kernel<fused> (uniform-grid exact NN + rejection + 17-term reduction)",
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": traffic.get("nn_grid_hbm_bytes_per_launch"), "avg_launch_ms": g_ms,
+                "launches": int(prof.grid_launches), "algorithmic_bytes_per_launch": alg_bytes_fused,
+                "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
+                        "(SURVEY.md 8(d) fused lower bound); the kernel is latency/issue-bound, not bandwidth-bound",
+                "brute_force_kernel": brute_roofline}
+        else:
+            nn_ms = prof.nn_ms / max(1, prof.nn_launches)
+            tf = flops / (nn_ms * 1e-3) / 1e12
+            roofline = dict(brute_roofline, achieved=tf, frac=tf / FP32_PEAK_TFLOPS, avg_launch_ms=nn_ms,
+                            launches=int(prof.nn_launches))
         out = {
             "metric": "icp_iterations_per_sec",
             "value": world * a.steps * a.iters / elapsed,
@@ -169,30 +209,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload} synthetic Velodyne-shaped scan pair per GPU (seed 4+rank), "
                                    f"{a.iters} forced point-to-point ICP iterations per step, clouds resident in HBM",
-                       "n_src": n_s, "n_tgt": n_t, "iters_per_step": a.iters, "nn": "brute-force LDS-tiled",
+                       "n_src": n_s, "n_tgt": n_t, "iters_per_step": a.iters,
+                       "nn": ("uniform-grid exact NN (fused reduce)" if used_grid else "brute-force LDS-tiled") + f" [--nn {a.nn}]",
                        "parallelism": f"{world} independent scan pair(s), one per GPU; result all_gather only"},
             "scan_pairs_per_sec": world / pair_s,
-            "scan_pair_def": f"align({a.iters} iterations) + getFitnessScore, as icp_odometer.cpp:198-201",
+            "scan_pair_def": f"align({a.iters} iterations) + getFitnessScore, as icp_odometer.cpp:198-201 "
+                             "(target index reused; set_target + index build are outside)",
             "iterations_timed": iters_done,
-            "roofline": {
-                "kernel": "nn_brute_kernel",
-                "bound": "mfma",
-                "achieved": tf,
-                "peak": FP32_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": tf / FP32_PEAK_TFLOPS,
-                "traffic": traffic,
-                "avg_launch_ms": nn_ms,
-                "launches": int(prof.nn_launches),
-                "note": "brute-force NN is FP32-compute-bound (8*Ns*Nt flop vs 16*(Ns+Nt)+8*Ns bytes per launch); "
-                        "peak is the f32 dense MFMA peak = the f32 vector peak (157.3 TFLOP/s). hbm sub-object gives "
-                        "the algorithmic-bytes rate the metric asks for.",
-                "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": alg_bytes},
-            },
-            "reduce_kernel": {"avg_ms": prof.reduce_ms / max(1, prof.reduce_launches),
-                              "hbm_gbs": (prof.reduce_bytes / max(1, prof.reduce_launches)) /
-                                         max(1e-9, prof.reduce_ms / max(1, prof.reduce_launches) * 1e-3) / 1e9},
+            "roofline": roofline,
+            "reduce_kernel": {"avg_ms": prof.reduce_ms / max(1, prof.reduce_launches)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, a.iters, a.cpu_seconds)

@@ -13,7 +13,6 @@
 // contiguous range (9 range lookups for a 3x3x3 block); `cell_start` = int32 per cell (+1).
 #include <math.h>
 
-#include <cstdlib>
 #include <cstring>
 
 #include "icp_device.h"
@@ -64,12 +63,22 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
       hi[a] = max(hi[a], __shfl_down(hi[a], off, 64));
     }
   }
-  if ((threadIdx.x & 63) == 0) {
+  // one set of atomics per workgroup (same-address atomics cost ~12 ns each on this part: keep them few)
+  __shared__ int wmm[4][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      atomicMin(&mm[a], lo[a]);
-      atomicMax(&mm[3 + a], hi[a]);
+      wmm[wave][a] = lo[a];
+      wmm[wave][3 + a] = hi[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    int v = wmm[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, wmm[w][threadIdx.x]) : max(v, wmm[w][threadIdx.x]);
+    if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], v);
+    else atomicMax(&mm[threadIdx.x], v);
   }
 }
 
@@ -83,30 +92,17 @@ __device__ __forceinline__ void cell_of(const GridDesc& g, float x, float y, flo
   cz = (int)fminf(fmaxf(fz, -lim), lim);
 }
 
-// CLAMP = false: bin the target cloud (points outside the grid / non-finite are dropped: c = -1)
-// CLAMP = true : order the SOURCE cloud by the target cell of T*s, every point keeps a slot (outside -> border cell,
-//                non-finite -> cell 0), so that a wave's 64 consecutive queries share their candidate rows
-template <bool CLAMP>
-__global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restrict__ pts, int n, GridDesc g, Xform T,
+__global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restrict__ pts, int n, GridDesc g,
                                                          int* __restrict__ cell_of_point, int* __restrict__ rank,
                                                          int* __restrict__ counts) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float4 s = pts[i];
-  float x = s.x, y = s.y, z = s.z;
-  if (CLAMP) xform_point(T, s.x, s.y, s.z, x, y, z);
-  int c = -1;
-  if (finite3(x, y, z)) {
+  const float4 p = pts[i];
+  int c = -1;  // non-finite points and points outside the grid are never binned
+  if (finite3(p.x, p.y, p.z)) {
     int cx, cy, cz;
-    cell_of(g, x, y, z, cx, cy, cz);
-    if (CLAMP) {
-      cx = min(max(cx, 0), g.nx - 1);
-      cy = min(max(cy, 0), g.ny - 1);
-      cz = min(max(cz, 0), g.nz - 1);
-    }
+    cell_of(g, p.x, p.y, p.z, cx, cy, cz);
     if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) c = (cz * g.ny + cy) * g.nx + cx;
-  } else if (CLAMP) {
-    c = 0;
   }
   cell_of_point[i] = c;
   rank[i] = c >= 0 ? atomicAdd(&counts[c], 1) : 0;
@@ -216,8 +212,7 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restr
 }
 
 // ---- correspondence search over the grid: one wave per query ------------------------------------------------------
-// A 64-lane wave owns one source point at a time (WQ_PER_WAVE consecutive points of the cell-ordered source, so
-// successive queries hit the same cache lines).  For the cube of Chebyshev radius rho around the query's cell the lanes
+// A 64-lane wave owns one source point at a time (up to 16 consecutive points per wave).  For the cube of Chebyshev radius rho around the query's cell the lanes
 // fetch the (2*rho+1)^2 cell-row ranges in parallel (a row = fixed y,z and a contiguous x run = ONE range of `sorted`),
 // then the wave walks the non-empty rows two at a time (two independent coalesced 1 KiB reads in flight), 64
 // candidates per row step, 6 flops + one 64-bit compare per candidate.  Each lane keeps a (d2, original index)
@@ -291,8 +286,8 @@ __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, in
   }
 }
 
-template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool ORDERED>
-__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src_ordered, int n_s, int qpw, Xform T,
+template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
+__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpw, Xform T,
                                                            const float4* __restrict__ sorted,
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
@@ -310,10 +305,9 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
 
   const int k0 = (blockIdx.x * WQ_WAVES + wave) * qpw;
   for (int qq = 0; qq < qpw; ++qq) {
-    const int k = k0 + qq;
-    if (k >= n_s) break;  // wave-uniform
-    const float4 s = src_ordered[k];  // ORDERED: w = original index of the source point
-    const int i = ORDERED ? __float_as_int(s.w) : k;
+    const int i = k0 + qq;
+    if (i >= n_s) break;  // wave-uniform
+    const float4 s = src[i];
     float px, py, pz;
     xform_point(T, s.x, s.y, s.z, px, py, pz);
     LaneBest b{kEmptyKey, 0.f, 0.f, 0.f};
@@ -380,7 +374,7 @@ hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t str
   hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, stream, d_minmax6);
   if (n > 0) {
     int blocks = (n + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, stream, pts, n, d_minmax6);
   }
   return hipGetLastError();
@@ -393,22 +387,16 @@ void decode_bbox(const int enc[6], float lo[3], float hi[3]) {
   }
 }
 
-static hipError_t grid_sort(const float4* pts, int n, const GridDesc& g, const Xform* T, int* cell_of_point,
-                            int* rank_in_cell, int* counts, int* block_sums, int* d_stats2, float4* sorted,
-                            hipStream_t stream) {
+hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
+                             int* counts, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream) {
   const int ncells = g.nx * g.ny * g.nz;
   hipError_t e = hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), stream);
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(d_stats2, 0, 2 * sizeof(int), stream);
   if (e != hipSuccess) return e;
-  if (n > 0) {
-    if (T)
-      hipLaunchKernelGGL(grid_count_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, *T, cell_of_point,
-                         rank_in_cell, counts);
-    else
-      hipLaunchKernelGGL(grid_count_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, Xform{},
-                         cell_of_point, rank_in_cell, counts);
-  }
+  if (n > 0)
+    hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, cell_of_point,
+                       rank_in_cell, counts);
   const int nb = (ncells + kScanItems - 1) / kScanItems;
   hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats2);
   hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nb, d_stats2);
@@ -419,21 +407,8 @@ static hipError_t grid_sort(const float4* pts, int n, const GridDesc& g, const X
   return hipGetLastError();
 }
 
-hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
-                             int* counts, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream) {
-  return grid_sort(pts, n, g, nullptr, cell_of_point, rank_in_cell, counts, block_sums, d_stats2, sorted, stream);
-}
-
-hipError_t launch_order_source(const float4* src, int n, const GridDesc& g_coarse, const Xform& T0, int* cell_of_point,
-                               int* rank_in_cell, int* counts, int* block_sums, int* d_stats2, float4* ordered,
-                               hipStream_t stream) {
-  return grid_sort(src, n, g_coarse, &T0, cell_of_point, rank_in_cell, counts, block_sums, d_stats2, ordered, stream);
-}
-
 // queries per wave: 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
 static int queries_per_wave(int n_s) {
-  static const int forced = [] { const char* v = std::getenv("ICPGPU_QPW"); return v ? std::atoi(v) : 0; }();
-  if (forced > 0) return forced;
   int qpw = n_s / 8192;
   if (qpw < 1) qpw = 1;
   if (qpw > WQ_MAX_QPW) qpw = WQ_MAX_QPW;
@@ -445,22 +420,16 @@ int grid_search_blocks(int n_s) {
   return (n_s + per_block - 1) / per_block;
 }
 
-hipError_t launch_nn_grid_search(const float4* src_ordered, bool ordered, int n_s, const Xform& T, const float4* sorted,
+hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream) {
   const int blocks = grid_search_blocks(n_s);
   if (blocks == 0) return hipSuccess;
   const int qpw = queries_per_wave(n_s);
   dim3 grid(blocks), block(WQ_BLOCK);
-#define ICP_LAUNCH_WQ(K, F, U)                                                                                          \
-  do {                                                                                                                  \
-    if (ordered)                                                                                                        \
-      hipLaunchKernelGGL((nn_wave_kernel<K, F, U, true>), grid, block, 0, stream, src_ordered, n_s, qpw, T, sorted,     \
-                         cell_start, g, accept_thr, keys, partials, unmatched, unmatched_count);                        \
-    else                                                                                                                \
-      hipLaunchKernelGGL((nn_wave_kernel<K, F, U, false>), grid, block, 0, stream, src_ordered, n_s, qpw, T, sorted,    \
-                         cell_start, g, accept_thr, keys, partials, unmatched, unmatched_count);                        \
-  } while (0)
+#define ICP_LAUNCH_WQ(K, F, U)                                                                                     \
+  hipLaunchKernelGGL((nn_wave_kernel<K, F, U>), grid, block, 0, stream, src, n_s, qpw, T, sorted, cell_start, g, accept_thr, \
+                     keys, partials, unmatched, unmatched_count)
   const bool k = keys != nullptr, f = partials != nullptr, u = unmatched != nullptr;
   if (k && !f && u) ICP_LAUNCH_WQ(true, false, true);
   else if (k && !f) ICP_LAUNCH_WQ(true, false, false);

@@ -75,20 +75,14 @@ void decode_bbox(const int enc[6], float lo[3], float hi[3]);  // host
 hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
                              int* counts_then_start, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream);
 
-// Order the SOURCE cloud by the (coarse) target cell of T0*s so that consecutive queries share candidate rows.
-// `ordered` = float4 {x, y, z (untransformed), original-index bits}; every point keeps a slot.
-hipError_t launch_order_source(const float4* src, int n, const GridDesc& g_coarse, const Xform& T0, int* cell_of_point,
-                               int* rank_in_cell, int* counts, int* block_sums, int* d_stats2, float4* ordered,
-                               hipStream_t stream);
-
-// Exact NN of T*s among the grid's points for every point of `src_ordered` (ordered = false: the plain source cloud), guaranteed whenever the NN lies within the
-// cutoff the grid was built for; otherwise the point is reported unmatched (empty key).  One wave per query.
-//   keys      : optional (nullptr to skip) 8-byte keys, written at the ORIGINAL source index, ORIGINAL target indices
+// Exact NN of T*src[i] among the grid's points, guaranteed whenever the NN lies within the cutoff the grid was built
+// for; otherwise the point is reported unmatched (empty key).  One wave per query (see icp_grid.hip).
+//   keys      : optional (nullptr to skip) 8-byte keys with ORIGINAL target indices
 //   partials  : optional fused a3+a4 reduction: grid_search_blocks(n_s) partials of 17 doubles
-//   unmatched : optional compaction of unmatched original source indices (count at unmatched_count[0], pre-zeroed)
-hipError_t launch_nn_grid_search(const float4* src_ordered, bool ordered, int n_s, const Xform& T, const float4* sorted,
-                                 const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
-                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream);
+//   unmatched : optional compaction of unmatched source indices (count at unmatched_count[0], pre-zeroed)
+hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, const float4* sorted, const int* cell_start,
+                                 const GridDesc& g, float accept_thr, unsigned long long* keys, double* partials,
+                                 int* unmatched, int* unmatched_count, hipStream_t stream);
 int grid_search_blocks(int n_s);
 
 // brute force for a list of source indices (fallback for points the grid could not match); keys pre-filled empty.

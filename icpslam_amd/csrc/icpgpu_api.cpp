@@ -52,14 +52,6 @@ struct GridIndex {
   DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
 };
 
-// Source cloud re-ordered by (coarse) target cell so that the 64 queries of a wave share candidate rows.
-struct SourceOrder {
-  bool usable = false;
-  uint64_t src_version = 0, grid_version = 0;
-  float cutoff = 0.f;
-  DeviceBuf ordered, table, cell_of_point, rank, block_sums, ints;
-};
-
 constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
 constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
 constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-force kernel is launch-latency bound anyway
@@ -75,8 +67,6 @@ struct icpgpu_ctx {
   Cloud src, tgt;
   DeviceBuf keys, partials, sums, out, idx, d2;
   GridIndex grid;            // acceleration structure over the current target
-  SourceOrder order;         // source cloud in target-cell order
-  uint64_t src_version = 1;  // bumped whenever the source cloud changes
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
   double* h_sums = nullptr;  // pinned (17 doubles)
   int* h_ints = nullptr;     // pinned (8 ints: bbox / stats / counters)
@@ -222,11 +212,9 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
   decode_bbox(c->h_ints, lo, hi);
   if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite target point
 
-  // cell size: cutoff / ICPGPU_GRID_DIV (default 4; cube radii double, so an unmatched point costs 4 cubes), grown
-  // until the dense table fits
-  double div = 4.0;
-  if (const char* v = std::getenv("ICPGPU_GRID_DIV")) div = std::max(1.0, std::atof(v));
-  double h = cut / div;
+  // cell size: a quarter of the cutoff (cube radii 1, 2, 4, 5 cells for an unmatched point), grown until the dense
+  // table fits.  Measured on 200k-point scans: /3 and /6 are both slower (more candidates / more rows per cube).
+  double h = cut / 4.0;
   long long nx, ny, nz;
   for (;;) {
     nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
@@ -273,58 +261,6 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
   return ICPGPU_OK;
 }
 
-// Order the source by target cell under T0 (once per source/grid pair: later transforms of an ICP run stay close to
-// T0, and the ordering only affects speed, never results).
-int ensure_source_order(icpgpu_ctx* c, const Xform& T0) {
-  SourceOrder& S = c->order;
-  const GridIndex& G = c->grid;
-  const int n_s = (int)c->src.n;
-  // Off by default: with one wave per query the caller's order measures no slower than cell order, and skipping the
-  // re-ordering keeps the fused reduction's summation order (hence the result bits) independent of atomic ranks.
-  static const bool enabled = std::getenv("ICPGPU_ORDER_SOURCE") != nullptr;
-  if (!enabled || !G.usable || n_s <= 0) {
-    S.usable = false;
-    return ICPGPU_OK;
-  }
-  if (S.usable && S.src_version == c->src_version && S.grid_version == G.version && S.cutoff == G.cutoff) return ICPGPU_OK;
-  S.usable = false;
-  // coarsen the target grid until the count table is small (ordering needs locality, not exact cells)
-  GridDesc g = G.g;
-
-  while ((long long)g.nx * g.ny * g.nz > (2ll << 20)) {
-    g.h *= 2.0f;
-    g.inv_h = 1.0f / g.h;
-    g.nx = (g.nx + 1) / 2;
-    g.ny = (g.ny + 1) / 2;
-    g.nz = (g.nz + 1) / 2;
-  }
-  const long long ncells = (long long)g.nx * g.ny * g.nz;
-  const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
-  int rc;
-  if ((rc = ensure(c, S.ordered, (size_t)n_s * sizeof(float4)))) return rc;
-  if ((rc = ensure(c, S.table, (size_t)(ncells + 1) * sizeof(int)))) return rc;
-  if ((rc = ensure(c, S.cell_of_point, (size_t)n_s * sizeof(int)))) return rc;
-  if ((rc = ensure(c, S.rank, (size_t)n_s * sizeof(int)))) return rc;
-  if ((rc = ensure(c, S.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
-  if ((rc = ensure(c, S.ints, 2 * sizeof(int)))) return rc;
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(c, launch_order_source(c->src.data(), n_s, g, T0, static_cast<int*>(S.cell_of_point.ptr), static_cast<int*>(S.rank.ptr),
-                                 static_cast<int*>(S.table.ptr), static_cast<int*>(S.block_sums.ptr), static_cast<int*>(S.ints.ptr),
-                                 static_cast<float4*>(S.ordered.ptr), c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints, S.ints.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  float ms = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-  c->prof.grid_build_ms += ms;
-  if (c->h_ints[0] != n_s) return fail(c, ICPGPU_ERR_HIP, "source ordering lost points (%d of %d)", c->h_ints[0], n_s);
-  S.usable = true;
-  S.src_version = c->src_version;
-  S.grid_version = G.version;
-  S.cutoff = G.cutoff;
-  return ICPGPU_OK;
-}
-
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
 // the brute-force kernel. Does not synchronise except for the 4-byte unmatched count.
 int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys) {
@@ -335,9 +271,7 @@ int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys) {
   int* d_list = static_cast<int*>(G.unmatched.ptr);
   int* d_count = d_list + n_s;
   HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
-  if ((rc = ensure_source_order(c, T))) return rc;
-  HIP_TRY(c, launch_nn_grid_search(c->order.usable ? static_cast<const float4*>(c->order.ordered.ptr) : c->src.data(),
-                                   c->order.usable, n_s, T, static_cast<const float4*>(G.sorted.ptr),
+  HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, T, static_cast<const float4*>(G.sorted.ptr),
                                    static_cast<const int*>(G.cell_start.ptr), G.g, 0.f, keys, nullptr, d_list, d_count,
                                    c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -363,14 +297,12 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Swe
   auto* partials = static_cast<double*>(c->partials.ptr);
   auto* d_sums = static_cast<double*>(c->sums.ptr);
   const bool use_grid = grid_ready(c) && n_s > 0 && (open_range || thr <= c->grid.cutoff * c->grid.cutoff);
-  if (use_grid && (rc = ensure_source_order(c, T))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (use_grid && !open_range) {
     const int blocks = grid_search_blocks(n_s);
     if ((rc = ensure(c, c->partials, (size_t)blocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    HIP_TRY(c, launch_nn_grid_search(c->order.usable ? static_cast<const float4*>(c->order.ordered.ptr) : c->src.data(),
-                                     c->order.usable, n_s, T, static_cast<const float4*>(c->grid.sorted.ptr),
+    HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, T, static_cast<const float4*>(c->grid.sorted.ptr),
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
                                      nullptr, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
@@ -607,12 +539,6 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->grid.ints);
   release(c->grid.unmatched);
   release(c->grid.leftover);
-  release(c->order.ordered);
-  release(c->order.table);
-  release(c->order.cell_of_point);
-  release(c->order.rank);
-  release(c->order.block_sums);
-  release(c->order.ints);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)
@@ -644,7 +570,6 @@ int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
 
 int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
-  c->src_version++;
   return set_cloud_host(c, c->src, xyzw, n);
 }
 int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
@@ -654,7 +579,6 @@ int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
 }
 int icpgpu_set_source_device(icpgpu_ctx* c, const void* d, size_t n) {
   ENTER(c);
-  c->src_version++;
   return set_cloud_device(c, c->src, d, n);
 }
 int icpgpu_set_target_device(icpgpu_ctx* c, const void* d, size_t n) {
@@ -668,7 +592,6 @@ int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
   if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "promote_source_to_target: no source set");
   std::swap(c->src, c->tgt);
   c->tgt_version++;
-  c->src_version++;
   c->src.n = 0;
   c->src.set = false;
   if (c->src.buf.external) c->src.buf = DeviceBuf{};
@@ -702,8 +625,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   ENTER(c);
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   for (size_t k = 0; k < n_pairs; ++k) {
-      c->src_version++;
-    int rc = set_cloud_host(c, c->src, src[k], n_src[k]);
+        int rc = set_cloud_host(c, c->src, src[k], n_src[k]);
     if (rc) return rc;
     c->tgt_version++;
     rc = set_cloud_host(c, c->tgt, tgt[k], n_tgt[k]);
@@ -729,7 +651,6 @@ int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {
   auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
   const Xform X = to_xform(T);
   const bool use_grid = grid_ready(c);
-  if (use_grid && (rc = ensure_source_order(c, X))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (use_grid) {
     if ((rc = nn_keys_grid(c, X, keys))) return rc;
