@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/icpgpu.h"
@@ -74,6 +76,7 @@ struct icpgpu_ctx {
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
   int nn_variant = 0;
+  std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   std::string err;
 };
 
@@ -521,6 +524,8 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
 
 int icpgpu_destroy(icpgpu_ctx* c) {
   if (!c) return ICPGPU_OK;
+  for (icpgpu_ctx* w : c->workers) icpgpu_destroy(w);
+  c->workers.clear();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   release(c->src.buf);
@@ -620,20 +625,62 @@ int icpgpu_fitness(icpgpu_ctx* c, double max_range, double* out) {
   return ICPGPU_OK;
 }
 
+// Independent scan pairs: a few host worker threads, each with its own sub-context (stream, scratch, grid), pull
+// pair indices from a shared counter.  While one pair waits for its per-iteration 136-byte D2H + host SVD, the
+// kernels of the others keep the GPU busy; every pair is solved exactly as icpgpu_align would solve it.
 int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src,
                        const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
   ENTER(c);
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
-  for (size_t k = 0; k < n_pairs; ++k) {
-        int rc = set_cloud_host(c, c->src, src[k], n_src[k]);
-    if (rc) return rc;
-    c->tgt_version++;
-    rc = set_cloud_host(c, c->tgt, tgt[k], n_tgt[k]);
-    if (rc) return rc;
-    rc = align_p2p(c, nullptr, nullptr, want_fitness, &results[k]);
-    if (rc) return rc;
+  if (c->params.method == ICPGPU_GICP) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP mode is not built yet");
+  if (n_pairs == 0) return ICPGPU_OK;
+  size_t n_workers = 8;
+  if (const char* v = std::getenv("ICPGPU_BATCH_WORKERS")) n_workers = (size_t)std::max(1, std::atoi(v));
+  n_workers = std::min(n_workers, n_pairs);
+  while (c->workers.size() < n_workers) {
+    icpgpu_ctx* w = nullptr;
+    const int rc = icpgpu_create(&w, c->device);
+    if (rc != ICPGPU_OK) return fail(c, rc, "align_batch: worker context: %s", icpgpu_last_error(nullptr));
+    c->workers.push_back(w);
   }
-  return ICPGPU_OK;
+  std::atomic<size_t> next{0};
+  std::atomic<int> first_error{ICPGPU_OK};
+  auto work = [&](icpgpu_ctx* w) {
+    if (hipSetDevice(w->device) != hipSuccess) {
+      first_error = ICPGPU_ERR_HIP;
+      return;
+    }
+    w->params = c->params;
+    w->nn_variant = c->nn_variant;
+    for (;;) {
+      const size_t k = next.fetch_add(1);
+      if (k >= n_pairs || first_error.load() != ICPGPU_OK) return;
+      int rc = set_cloud_host(w, w->src, src[k], n_src[k]);
+      w->tgt_version++;
+      if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k]);
+      if (!rc) rc = align_p2p(w, nullptr, nullptr, want_fitness, &results[k]);
+      if (rc) {
+        int expected = ICPGPU_OK;
+        if (first_error.compare_exchange_strong(expected, rc)) c->err = "align_batch pair " + std::to_string(k) + ": " + w->err;
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t i = 1; i < n_workers; ++i) threads.emplace_back(work, c->workers[i]);
+  work(c->workers[0]);
+  for (auto& th : threads) th.join();
+  for (size_t i = 0; i < n_workers; ++i) {  // fold the workers' kernel accounting into the parent's profile
+    icpgpu_profile& p = c->workers[i]->prof;
+    c->prof.nn_launches += p.nn_launches; c->prof.nn_ms += p.nn_ms; c->prof.nn_pairs += p.nn_pairs; c->prof.nn_bytes += p.nn_bytes;
+    c->prof.reduce_launches += p.reduce_launches; c->prof.reduce_ms += p.reduce_ms; c->prof.reduce_bytes += p.reduce_bytes;
+    c->prof.transform_launches += p.transform_launches; c->prof.transform_ms += p.transform_ms; c->prof.transform_bytes += p.transform_bytes;
+    c->prof.iterations += p.iterations; c->prof.aligns += p.aligns;
+    c->prof.grid_launches += p.grid_launches; c->prof.grid_ms += p.grid_ms; c->prof.grid_bytes += p.grid_bytes;
+    c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
+    std::memset(&p, 0, sizeof(p));
+  }
+  return first_error.load();
 }
 
 int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {

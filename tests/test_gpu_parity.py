@@ -220,3 +220,22 @@ def test_pcl_shaped_front_end(built):
     assert aligned.shape == curr.shape
     assert _dR(T, ref["T"]) <= R_TOL and _dt(T, ref["T"]) <= T_TOL
     assert abs(icp.getFitnessScore() - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+
+
+def test_align_batch_matches_single_aligns(ctx):
+    """BASELINE config 4 in miniature: independent pairs through icpgpu_align_batch == one icpgpu_align per pair."""
+    pairs = [synth.make_pair(6000 + 500 * k, 7000, seed=300 + k)[:2] for k in range(7)]
+    pairs.append((np.zeros((0, 4), np.float32), pairs[0][1]))          # empty source inside a batch
+    ctx.set_params(ctx.default_params(), max_iterations=10)
+    batch = ctx.align_batch([p[0] for p in pairs], [p[1] for p in pairs], want_fitness=True)
+    assert len(batch) == len(pairs)
+    for (s, t), got in zip(pairs, batch):
+        ctx.set_source(s)
+        ctx.set_target(t)
+        one = ctx.align(want_fitness=True)
+        assert (got["converged"], got["iterations"], got["state"], got["n_corr"]) == \
+               (one["converged"], one["iterations"], one["state"], one["n_corr"])
+        assert np.array_equal(got["T"], one["T"])
+        assert got["fitness"] == one["fitness"] or (np.isnan(got["fitness"]) and np.isnan(one["fitness"]))
+    ref = oracle.icp_align(pairs[3][0], pairs[3][1], oracle.default_params(max_iterations=10))
+    assert _dR(batch[3]["T"], ref["T"]) <= R_TOL and _dt(batch[3]["T"], ref["T"]) <= T_TOL
