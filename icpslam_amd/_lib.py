@@ -34,7 +34,8 @@ class Profile(C.Structure):
                 ("reduce_bytes", C.c_uint64), ("transform_launches", C.c_uint64), ("transform_ms", C.c_double),
                 ("transform_bytes", C.c_uint64), ("iterations", C.c_uint64), ("aligns", C.c_uint64),
                 ("grid_launches", C.c_uint64), ("grid_ms", C.c_double), ("grid_bytes", C.c_uint64),
-                ("grid_builds", C.c_uint64), ("grid_build_ms", C.c_double), ("grid_fallback_points", C.c_uint64)]
+                ("grid_builds", C.c_uint64), ("grid_build_ms", C.c_double), ("grid_fallback_points", C.c_uint64),
+                ("voxel_launches", C.c_uint64), ("voxel_ms", C.c_double), ("voxel_bytes", C.c_uint64)]
 
 
 # every symbol include/icpgpu.h declares (tests/test_abi.py checks the header against this list)
@@ -44,6 +45,7 @@ EXPORTS = [
     "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_get_stream", "icpgpu_synchronize",
+    "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered",
 ]
 
 _lib = None
@@ -92,6 +94,8 @@ def load():
     L.icpgpu_reduce.argtypes = [vp, fp, C.c_double, dp]
     L.icpgpu_solve.argtypes = [dp, dp]
     L.icpgpu_transform.argtypes = [vp, fp, fp]
+    L.icpgpu_voxel_grid.argtypes = [vp, fp, C.c_size_t, C.c_float, fp, C.POINTER(C.c_size_t)]
+    L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]
     L.icpgpu_profile_reset.argtypes = [vp]
     L.icpgpu_profile_get.argtypes = [vp, C.POINTER(Profile)]
     L.icpgpu_get_stream.argtypes = [vp, C.POINTER(vp)]

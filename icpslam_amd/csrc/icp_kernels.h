@@ -89,4 +89,11 @@ int grid_search_blocks(int n_s);
 hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,
                                 const Xform& T, int num_cus, unsigned long long* keys, hipStream_t stream);
 
+// ---- voxel-grid down-sampling (icp_voxel.hip), SURVEY.md 8(f2) -------------------------------------------------
+size_t voxel_temp_bytes(int n);
+// keys/vals: 2*n ints each, flags/slots: n ints each, d_n_out: 2 ints whose sum is the number of cells written to `out`.
+hipError_t launch_voxel_grid(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* keys,
+                             int* vals, int* flags, int* slots, void* temp, size_t temp_bytes, float4* out, int* d_n_out,
+                             hipStream_t stream);
+
 }  // namespace icpgpu

@@ -76,6 +76,7 @@ struct icpgpu_ctx {
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
   int nn_variant = 0;
+  DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   std::string err;
 };
@@ -365,6 +366,60 @@ int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {
   return ICPGPU_OK;
 }
 
+// pcl::VoxelGrid<PointXYZ>::filter on a device-resident cloud (icp_odometer.cpp:96-101). out receives *n_out points
+// (ascending cell index). *passthrough = PCL's "leaf size too small for the input dataset" case: input returned as is.
+int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough) {
+  *n_out = 0;
+  *passthrough = false;
+  if (!(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel filter: leaf size must be positive");
+  if (n <= 0) return ICPGPU_OK;
+  int rc = ensure(c, c->vox_ints, 8 * sizeof(int));
+  if (rc) return rc;
+  int* d_ints = static_cast<int*>(c->vox_ints.ptr);
+  HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float lo[3], hi[3];
+  decode_bbox(c->h_ints, lo, hi);
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
+  const float inv = 1.0f / leaf;  // PCL: inverse_leaf_size_ = 1 / leaf_size_ in float
+  int minb[3], divb[3];
+  long long d[3];
+  for (int a = 0; a < 3; ++a) {
+    d[a] = (long long)((hi[a] - lo[a]) * inv) + 1;
+    minb[a] = (int)std::floor(lo[a] * inv);
+    divb[a] = (int)std::floor(hi[a] * inv) - minb[a] + 1;
+  }
+  if ((rc = ensure(c, out, (size_t)n * sizeof(float4)))) return rc;
+  if (d[0] * d[1] * d[2] > (long long)INT32_MAX) {  // PCL warns and returns the input unchanged
+    HIP_TRY(c, hipMemcpyAsync(out.ptr, d_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    *passthrough = true;
+    return ICPGPU_OK;
+  }
+  const size_t tb = voxel_temp_bytes(n);
+  if ((rc = ensure(c, c->vox_keys, (size_t)2 * n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, c->vox_vals, (size_t)2 * n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, c->vox_flags, (size_t)n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, c->vox_slots, (size_t)n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, c->vox_temp, tb))) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_voxel_grid(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_vals.ptr),
+                               static_cast<int*>(c->vox_flags.ptr), static_cast<int*>(c->vox_slots.ptr), c->vox_temp.ptr, tb,
+                               static_cast<float4*>(out.ptr), d_ints + 6, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  *n_out = c->h_ints[6] + c->h_ints[7];
+  c->prof.voxel_launches += 1;
+  c->prof.voxel_ms += ms;
+  c->prof.voxel_bytes += 16ull * (uint64_t)n + 16ull * (uint64_t)*n_out;
+  return ICPGPU_OK;
+}
+
 void init_result(icpgpu_result* r) {
   std::memset(r, 0, sizeof(*r));
   for (int i = 0; i < 16; ++i) r->T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
@@ -534,6 +589,14 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->partials);
   release(c->sums);
   release(c->out);
+  release(c->vox_in);
+  release(c->vox_out);
+  release(c->vox_keys);
+  release(c->vox_vals);
+  release(c->vox_flags);
+  release(c->vox_slots);
+  release(c->vox_temp);
+  release(c->vox_ints);
   release(c->idx);
   release(c->d2);
   release(c->grid.sorted);
@@ -678,6 +741,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.iterations += p.iterations; c->prof.aligns += p.aligns;
     c->prof.grid_launches += p.grid_launches; c->prof.grid_ms += p.grid_ms; c->prof.grid_bytes += p.grid_bytes;
     c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
+    c->prof.voxel_launches += p.voxel_launches; c->prof.voxel_ms += p.voxel_ms; c->prof.voxel_bytes += p.voxel_bytes;
     std::memset(&p, 0, sizeof(p));
   }
   return first_error.load();
@@ -759,6 +823,42 @@ int icpgpu_transform(icpgpu_ctx* c, const float* T, float* out_xyzw) {
   if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "transform: no source set");
   if (c->src.n && !out_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "out is null");
   return write_output_cloud(c, to_xform(T), out_xyzw);
+}
+
+int icpgpu_voxel_grid(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, float* out_xyzw, size_t* n_out) {
+  ENTER(c);
+  if (!n_out || (n && (!xyzw || !out_xyzw))) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  *n_out = 0;
+  int rc = ensure(c, c->vox_in, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  int m = 0;
+  bool pass = false;
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass))) return rc;
+  if (m) {
+    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  *n_out = (size_t)m;
+  return ICPGPU_OK;
+}
+
+int icpgpu_set_source_voxel_filtered(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, size_t* n_out) {
+  ENTER(c);
+  if (n && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  int rc = ensure(c, c->vox_in, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  int m = 0;
+  bool pass = false;
+  if (c->src.buf.external) c->src.buf = DeviceBuf{};
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->src.buf, &m, &pass))) return rc;
+  c->src.n = (size_t)m;
+  c->src.set = true;
+  if (n_out) *n_out = (size_t)m;
+  return ICPGPU_OK;
 }
 
 int icpgpu_profile_reset(icpgpu_ctx* c) {

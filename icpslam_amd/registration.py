@@ -173,6 +173,21 @@ class Context:
         self._check(self._L.icpgpu_transform(self._h, _fp(Tb), _fp(out)))
         return out
 
+    # the step before the path (icp_odometer.cpp:96-101) ---------------------------------------------------------
+    def voxel_grid(self, cloud, leaf: float) -> np.ndarray:
+        cloud = _as_cloud(cloud)
+        out = np.empty_like(cloud)
+        n_out = C.c_size_t()
+        self._check(self._L.icpgpu_voxel_grid(self._h, _fp(cloud), cloud.shape[0], float(leaf), _fp(out), C.byref(n_out)))
+        return out[: n_out.value].copy()
+
+    def set_source_voxel_filtered(self, cloud, leaf: float) -> int:
+        cloud = _as_cloud(cloud)
+        n_out = C.c_size_t()
+        self._check(self._L.icpgpu_set_source_voxel_filtered(self._h, _fp(cloud), cloud.shape[0], float(leaf), C.byref(n_out)))
+        self.n_source = int(n_out.value)
+        return self.n_source
+
     # measurement -----------------------------------------------------------------------------------------------
     def profile_reset(self):
         self._check(self._L.icpgpu_profile_reset(self._h))

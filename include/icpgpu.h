@@ -118,6 +118,9 @@ typedef struct {
   uint64_t grid_builds;       /* target grid (re)builds: bbox + counting sort */
   double grid_build_ms;
   uint64_t grid_fallback_points; /* points finished by the brute-force kernel (no neighbour within the cutoff) */
+  uint64_t voxel_launches;    /* voxel-grid filter runs */
+  double voxel_ms;            /* key + sort + flag/scan + centroid kernels */
+  uint64_t voxel_bytes;       /* algorithmic bytes: 16*N in + 16*N_out */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -178,6 +181,17 @@ int icpgpu_reduce(icpgpu_ctx* ctx, const float* T, double max_dist, double sums[
 int icpgpu_solve(const double sums[17], double Tk[16]);
 /* a6: out = T * source (w = 1), pcl::transformPointCloud (icp_odometer.cpp:205). */
 int icpgpu_transform(icpgpu_ctx* ctx, const float* T, float* out_xyzw);
+
+/* ---- the step before the path: voxel-grid down-sampling -------------------- */
+/* replaces IcpOdometer::voxelFilterCloud = pcl::VoxelGrid<PointXYZ>::filter with leaf (L, L, L)
+ * (/root/reference/src/icpslam/icp_odometer.cpp:96-101,177; leaf 0.2 m in config/icpslam.yaml:14):
+ * one output point per occupied cell = mean of its points, ascending cell-index order, pad = 1.0f;
+ * non-finite points are skipped; if the cell index space overflows int32 the input is returned
+ * unchanged (PCL's "leaf size is too small" behaviour). out_xyzw must hold n points. */
+int icpgpu_voxel_grid(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, float* out_xyzw, size_t* n_out);
+/* the odometer's pre-step fused with setInputSource: upload, filter on the device, and make the
+ * filtered cloud the source without a round trip to the host (icp_odometer.cpp:177 then :193). */
+int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, size_t* n_out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 int icpgpu_profile_reset(icpgpu_ctx* ctx);

@@ -153,4 +153,34 @@ class IterativeClosestPoint {
   bool aligned_ = false;
 };
 
+// pcl::VoxelGrid<PointT>-shaped front end for the odometer's pre-step
+// (/root/reference/src/icpslam/icp_odometer.cpp:96-101):
+//   pcl::VoxelGrid<pcl::PointXYZ> voxel_filter;  ->  icpgpu::VoxelGrid<pcl::PointCloud<pcl::PointXYZ>> voxel_filter;
+//   voxel_filter.setInputCloud(in); voxel_filter.setLeafSize(l, l, l); voxel_filter.filter(out);
+template <class CloudT>
+class VoxelGrid {
+ public:
+  explicit VoxelGrid(int device = 0) : ctx_(detail::thread_context(device)) {}
+  template <class CloudPtr>
+  void setInputCloud(const CloudPtr& cloud) { input_ = &*cloud; }
+  void setLeafSize(float lx, float ly, float lz) {
+    if (lx != ly || ly != lz) throw std::invalid_argument("icpgpu::VoxelGrid: only cubic leaves (the reference passes one size)");
+    leaf_ = lx;
+  }
+  void filter(CloudT& output) {
+    if (!input_) return;
+    const std::size_t n = input_->points.size();
+    output.points.resize(n);
+    std::size_t m = 0;
+    const int rc = icpgpu_voxel_grid(ctx_, n ? reinterpret_cast<const float*>(&input_->points[0]) : nullptr, n, leaf_,
+                                     n ? reinterpret_cast<float*>(&output.points[0]) : nullptr, &m);
+    output.points.resize(rc == ICPGPU_OK ? m : 0);
+  }
+
+ private:
+  icpgpu_ctx* ctx_;
+  const CloudT* input_ = nullptr;
+  float leaf_ = 0.1f;
+};
+
 }  // namespace icpgpu
