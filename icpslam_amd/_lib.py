@@ -38,6 +38,10 @@ class Profile(C.Structure):
                 ("voxel_launches", C.c_uint64), ("voxel_ms", C.c_double), ("voxel_bytes", C.c_uint64)]
 
 
+class Pose(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("quat", C.c_double * 4)]
+
+
 # every symbol include/icpgpu.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
     "icpgpu_create", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params",
@@ -46,6 +50,10 @@ EXPORTS = [
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_get_stream", "icpgpu_synchronize",
     "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered",
+    "icpgpu_pose_from_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
+    "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
+    "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
+    "icpgpu_posegraph_get_keyframe", "icpgpu_posegraph_get_edge", "icpgpu_posegraph_write_g2o",
 ]
 
 _lib = None
@@ -96,13 +104,29 @@ def load():
     L.icpgpu_transform.argtypes = [vp, fp, fp]
     L.icpgpu_voxel_grid.argtypes = [vp, fp, C.c_size_t, C.c_float, fp, C.POINTER(C.c_size_t)]
     L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]
+    pp, lp = C.POINTER(Pose), C.POINTER(C.c_long)
+    L.icpgpu_pose_from_matrix.argtypes = [fp, pp]
+    L.icpgpu_pose_compose.argtypes = [pp, pp, pp]
+    L.icpgpu_pose_inverse.argtypes = [pp, pp]
+    L.icpgpu_posegraph_create.argtypes = [C.POINTER(vp), C.c_double, dp]
+    L.icpgpu_posegraph_destroy.argtypes = [vp]
+    L.icpgpu_posegraph_set_initial_pose.argtypes = [vp, pp]
+    L.icpgpu_posegraph_push.argtypes = [vp, fp, C.c_int, lp]
+    L.icpgpu_posegraph_num_poses.argtypes = [vp]
+    L.icpgpu_posegraph_num_keyframes.argtypes = [vp]
+    L.icpgpu_posegraph_get_pose.argtypes = [vp, C.c_long, pp]
+    L.icpgpu_posegraph_get_keyframe.argtypes = [vp, C.c_long, pp, lp]
+    L.icpgpu_posegraph_get_edge.argtypes = [vp, C.c_long, pp]
+    L.icpgpu_posegraph_write_g2o.argtypes = [vp, C.c_char_p]
     L.icpgpu_profile_reset.argtypes = [vp]
     L.icpgpu_profile_get.argtypes = [vp, C.POINTER(Profile)]
     L.icpgpu_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.icpgpu_synchronize.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("icpgpu_last_error", "icpgpu_default_params"):
+        if name in ("icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes"):
+            fn.restype = C.c_long
+        elif name not in ("icpgpu_last_error", "icpgpu_default_params"):
             fn.restype = C.c_int
     _lib = L
     return L

@@ -1,0 +1,164 @@
+"""Sequence layer around the hot path (BASELINE config 5): the odometer's per-scan
+bookkeeping and the pose graph handed to the unchanged CPU g2o stage.
+
+Mirrors, call for call:
+  IcpOdometer::laserCloudCallback  /root/reference/src/icpslam/icp_odometer.cpp:147-210  (voxel filter -> ICP against the
+      previous accepted cloud -> gate `hasConverged() && getFitnessScore() < 20` -> pose chain -> prev = curr)
+  IcpSlam::mainLoop / addNewKeyframe  /root/reference/src/icpslam/icpslam.cpp:143-152, 70-89  (keyframes, edges)
+The SE(3) arithmetic and the g2o writer live in the native library (icp_posegraph.cpp); this module only sequences calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import IcpGpuError, Pose
+
+FITNESS_GATE = 20.0   # the literal at icp_odometer.cpp:201
+
+
+def pose_from_matrix(T) -> Pose:
+    L = _lib.load()
+    buf = np.ascontiguousarray(np.asarray(T, np.float32).reshape(4, 4).T).reshape(16)
+    p = Pose()
+    L.icpgpu_pose_from_matrix(buf.ctypes.data_as(C.POINTER(C.c_float)), C.byref(p))
+    return p
+
+
+def pose_compose(a: Pose, b: Pose) -> Pose:
+    out = Pose()
+    _lib.load().icpgpu_pose_compose(C.byref(a), C.byref(b), C.byref(out))
+    return out
+
+
+def pose_inverse(a: Pose) -> Pose:
+    out = Pose()
+    _lib.load().icpgpu_pose_inverse(C.byref(a), C.byref(out))
+    return out
+
+
+def pose_tuple(p: Pose):
+    return np.array(p.pos), np.array(p.quat)
+
+
+class PoseGraph:
+    """ctypes wrapper of icpgpu_posegraph_* (pose chain + keyframes + g2o export)."""
+
+    def __init__(self, keyframe_distance: float = 0.3, information_diag=None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        info = None
+        if information_diag is not None:
+            self._info = np.ascontiguousarray(information_diag, np.float64)
+            info = self._info.ctypes.data_as(C.POINTER(C.c_double))
+        rc = self._L.icpgpu_posegraph_create(C.byref(h), float(keyframe_distance), info)
+        if rc != 0:
+            raise IcpGpuError(rc, "posegraph_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.icpgpu_posegraph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, T, accepted: bool) -> int:
+        buf = np.ascontiguousarray(np.asarray(T, np.float32).reshape(4, 4).T).reshape(16)
+        kf = C.c_long(-1)
+        rc = self._L.icpgpu_posegraph_push(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), int(bool(accepted)), C.byref(kf))
+        if rc != 0:
+            raise IcpGpuError(rc, "posegraph_push")
+        return int(kf.value)
+
+    @property
+    def num_poses(self) -> int:
+        return int(self._L.icpgpu_posegraph_num_poses(self._h))
+
+    @property
+    def num_keyframes(self) -> int:
+        return int(self._L.icpgpu_posegraph_num_keyframes(self._h))
+
+    def pose(self, i: int):
+        p = Pose()
+        if self._L.icpgpu_posegraph_get_pose(self._h, i, C.byref(p)) != 0:
+            raise IndexError(i)
+        return pose_tuple(p)
+
+    def keyframe(self, i: int):
+        p, s = Pose(), C.c_long()
+        if self._L.icpgpu_posegraph_get_keyframe(self._h, i, C.byref(p), C.byref(s)) != 0:
+            raise IndexError(i)
+        return pose_tuple(p) + (int(s.value),)
+
+    def edge(self, new_kf: int):
+        p = Pose()
+        if self._L.icpgpu_posegraph_get_edge(self._h, new_kf, C.byref(p)) != 0:
+            raise IndexError(new_kf)
+        return pose_tuple(p)
+
+    def write_g2o(self, path: str):
+        if self._L.icpgpu_posegraph_write_g2o(self._h, str(path).encode()) != 0:
+            raise IOError(path)
+
+
+def run_odometry(ctx, scans, voxel_leaf: float | None = None, graph: PoseGraph | None = None, fitness_gate=FITNESS_GATE):
+    """The reference's online loop, one scan at a time (a failed registration keeps the older cloud as target).
+
+    Returns (graph, per-scan records). Scan 0 only seeds the target (icp_odometer.cpp:179-182)."""
+    graph = graph or PoseGraph()
+    records = []
+    have_prev = False
+    for k, scan in enumerate(scans):
+        if voxel_leaf:
+            ctx.set_source_voxel_filtered(scan, voxel_leaf)
+        else:
+            ctx.set_source(scan)
+        if not have_prev:
+            ctx.promote_source_to_target()
+            have_prev = True
+            continue
+        res = ctx.align(want_fitness=True)
+        ok = bool(res["converged"]) and res["fitness"] < fitness_gate
+        kf = graph.push(res["T"], ok)
+        records.append(dict(scan=k, accepted=ok, keyframe=kf, **{x: res[x] for x in ("T", "iterations", "n_corr", "fitness")}))
+        if ok:
+            ctx.promote_source_to_target()      # *prev_cloud_ = *curr_cloud_ (icp_odometer.cpp:209)
+    return graph, records
+
+
+def run_odometry_batched(ctx, scans, rank: int = 0, world: int = 1, device=None, graph: PoseGraph | None = None,
+                         fitness_gate=FITNESS_GATE):
+    """Offline variant for a recorded sequence (BASELINE config 5): the N-1 consecutive pairs are independent ICP
+    problems, sharded across ranks (icpslam_amd.sharding), solved with icpgpu_align_batch, gathered, then chained on the
+    host.  A pair that fails the gate is re-solved against the last accepted scan, which reproduces the online loop."""
+    from . import sharding
+    n_pairs = len(scans) - 1
+    mine = sharding.shard_range(n_pairs, rank, world)
+    res = ctx.align_batch([scans[k + 1] for k in mine], [scans[k] for k in mine], want_fitness=True) if len(mine) else []
+    local = np.stack([sharding.make_record(k, r) for k, r in zip(mine, res)]) if len(mine) else np.zeros((0, sharding.RECORD_LEN))
+    allrec = sharding.gather_records(local, n_pairs, rank, world, device)
+    graph = graph or PoseGraph()
+    records = []
+    last_ok = 0                                   # index of the scan currently playing "prev_cloud_"
+    for k in range(n_pairs):
+        r = sharding.parse_record(allrec[k])
+        if last_ok != k:                          # an earlier failure: this scan must register against the older cloud
+            ctx.set_source(scans[k + 1])
+            ctx.set_target(scans[last_ok])
+            one = ctx.align(want_fitness=True)
+            r.update(T=one["T"], converged=one["converged"], fitness=one["fitness"], iterations=one["iterations"],
+                     n_corr=one["n_corr"])
+        ok = bool(r["converged"]) and r["fitness"] < fitness_gate
+        kf = graph.push(r["T"], ok)
+        records.append(dict(scan=k + 1, accepted=ok, keyframe=kf, T=np.asarray(r["T"], np.float32),
+                            iterations=r["iterations"], n_corr=r["n_corr"], fitness=r["fitness"]))
+        if ok:
+            last_ok = k + 1
+    return graph, records

@@ -193,6 +193,41 @@ int icpgpu_voxel_grid(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, 
  * filtered cloud the source without a round trip to the host (icp_odometer.cpp:177 then :193). */
 int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, size_t* n_out);
 
+/* ---- the data contract after the path: pose chain, keyframes, pose graph ---- */
+/* SE(3) pose as the reference's Pose6DOF keeps it (/root/reference/include/utils/pose6DOF.h):
+ * position + unit quaternion (x, y, z, w). Host-only arithmetic in double; no GPU involved. */
+typedef struct {
+  double pos[3];
+  double quat[4]; /* x, y, z, w */
+} icpgpu_pose;
+typedef struct icpgpu_posegraph icpgpu_posegraph; /* opaque */
+
+/* Pose6DOF(T): pose6DOF.cpp:185-190 (T = float[16] column-major as returned in icpgpu_result.T). */
+int icpgpu_pose_from_matrix(const float* T, icpgpu_pose* out);
+/* Pose6DOF::compose (operator+): pose6DOF.cpp:98-105.  Pose6DOF::inverse: pose6DOF.cpp:117-122. */
+int icpgpu_pose_compose(const icpgpu_pose* a, const icpgpu_pose* b, icpgpu_pose* out);
+int icpgpu_pose_inverse(const icpgpu_pose* a, icpgpu_pose* out);
+
+/* Sequence bookkeeping of IcpOdometer::updateICPOdometry (icp_odometer.cpp:109-113) + the keyframe and
+ * edge rules of IcpSlam::mainLoop / addNewKeyframe (icpslam.cpp:143-152, 70-89).
+ *   keyframe_distance  : KFS_DIST_THRESH (icpslam.h:36, 0.3 m); < 0 = default
+ *   information_diag6  : icp_information_matrix (config/icpslam.yaml:21); NULL = that default */
+int icpgpu_posegraph_create(icpgpu_posegraph** out, double keyframe_distance, const double* information_diag6);
+int icpgpu_posegraph_destroy(icpgpu_posegraph* g);
+int icpgpu_posegraph_set_initial_pose(icpgpu_posegraph* g, const icpgpu_pose* p); /* IcpOdometer::setInitialPose */
+/* one registration result per scan, in scan order. accepted = hasConverged() && fitness < 20
+ * (icp_odometer.cpp:201); rejected scans leave the chain untouched. *keyframe_id = new keyframe or -1. */
+int icpgpu_posegraph_push(icpgpu_posegraph* g, const float* T, int accepted, long* keyframe_id);
+long icpgpu_posegraph_num_poses(const icpgpu_posegraph* g);
+long icpgpu_posegraph_num_keyframes(const icpgpu_posegraph* g);
+int icpgpu_posegraph_get_pose(const icpgpu_posegraph* g, long i, icpgpu_pose* out);
+int icpgpu_posegraph_get_keyframe(const icpgpu_posegraph* g, long i, icpgpu_pose* out, long* scan_index);
+/* edge measurement between keyframe new_kf and new_kf - 1: new^-1 (+) prev (icpslam.cpp:82). */
+int icpgpu_posegraph_get_edge(const icpgpu_posegraph* g, long new_kf, icpgpu_pose* out);
+/* g2o text file: VERTEX_SE3:QUAT id x y z qx qy qz qw / EDGE_SE3:QUAT from to x y z qx qy qz qw + the 21
+ * upper-triangular information entries -- what PoseGraphG2O::addSe3Node/addSe3Edge would have built. */
+int icpgpu_posegraph_write_g2o(const icpgpu_posegraph* g, const char* path);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 int icpgpu_profile_reset(icpgpu_ctx* ctx);
 int icpgpu_profile_get(icpgpu_ctx* ctx, icpgpu_profile* out);
