@@ -35,7 +35,8 @@ class Profile(C.Structure):
                 ("transform_bytes", C.c_uint64), ("iterations", C.c_uint64), ("aligns", C.c_uint64),
                 ("grid_launches", C.c_uint64), ("grid_ms", C.c_double), ("grid_bytes", C.c_uint64),
                 ("grid_builds", C.c_uint64), ("grid_build_ms", C.c_double), ("grid_fallback_points", C.c_uint64),
-                ("voxel_launches", C.c_uint64), ("voxel_ms", C.c_double), ("voxel_bytes", C.c_uint64)]
+                ("voxel_launches", C.c_uint64), ("voxel_ms", C.c_double), ("voxel_bytes", C.c_uint64),
+                ("gicp_cov_launches", C.c_uint64), ("gicp_cov_ms", C.c_double), ("gicp_cost_launches", C.c_uint64)]
 
 
 class Pose(C.Structure):
@@ -49,7 +50,7 @@ EXPORTS = [
     "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_get_stream", "icpgpu_synchronize",
-    "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered",
+    "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
     "icpgpu_pose_from_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
     "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
@@ -102,6 +103,7 @@ def load():
     L.icpgpu_reduce.argtypes = [vp, fp, C.c_double, dp]
     L.icpgpu_solve.argtypes = [dp, dp]
     L.icpgpu_transform.argtypes = [vp, fp, fp]
+    L.icpgpu_gicp_covariances.argtypes = [vp, C.c_int, dp]
     L.icpgpu_voxel_grid.argtypes = [vp, fp, C.c_size_t, C.c_float, fp, C.POINTER(C.c_size_t)]
     L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]
     pp, lp = C.POINTER(Pose), C.POINTER(C.c_long)

@@ -1,0 +1,339 @@
+// icp_gicp.hip -- device side of the GICP mode: what
+// pcl::GeneralizedIterativeClosestPoint does per point / per correspondence, reached in the reference through
+// `icp.align()` at /root/reference/src/icpslam/icp_odometer.cpp:188-198 and src/icpslam/octree_mapper.cpp:104-114.
+//
+//   gicp_cov_kernel   computeCovariances: 20 nearest neighbours of every point in its own cloud (the 20 smallest
+//                     (d2, index) keys), covariance in double from float products, smallest singular direction u,
+//                     C = I - (1 - 1e-3) u u^T  (== U diag(1, 1, 1e-3) U^T).  One wave per point over the cloud's own
+//                     uniform grid: lanes 0..19 hold the running top-20, candidates stream in 64 at a time.
+//   gicp_maha_kernel  per accepted correspondence (d2 < r^2, strict): M_i = (C_t[j] + R C_s[i] R^T)^-1, symmetric 6.
+//   gicp_cost_kernel  one BFGS function/gradient evaluation: sum over correspondences of r^T M r, M r and
+//                     (base p)(M r)^T with r = T(x) p - q -- 14 float64 terms, fixed-order two-stage reduction.
+//                     HBM-bound: 16 B source + 8 B key + 16 B gathered target + 48 B M per correspondence.
+#include <math.h>
+
+#include "icp_device.h"
+#include "icp_kernels.h"
+
+namespace icpgpu {
+namespace {
+
+constexpr int GK = kGicpK;  // 20
+
+__device__ __forceinline__ bool finite3g(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+
+__device__ __forceinline__ void cell_of_g(const GridDesc& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+  const float fx = floorf((x - g.ox) * g.inv_h), fy = floorf((y - g.oy) * g.inv_h), fz = floorf((z - g.oz) * g.inv_h);
+  const float lim = 1048576.0f;
+  cx = (int)fminf(fmaxf(fx, -lim), lim);
+  cy = (int)fminf(fmaxf(fy, -lim), lim);
+  cz = (int)fminf(fmaxf(fz, -lim), lim);
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// direction of the smallest singular value of a symmetric 3x3 (row-major): one-sided Jacobi on W = A V, the column of
+// W with the smallest norm, completed by the cross product of the other two when it vanishes (perfectly planar patch)
+__device__ void smallest_singular_direction(const double A[9], double u[3]) {
+  double w[3][3];  // w[j] = column j
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) w[j][r] = A[r * 3 + j];
+  for (int sweep = 0; sweep < 64; ++sweep) {
+    bool rotated = false;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const double aa = w[p][0] * w[p][0] + w[p][1] * w[p][1] + w[p][2] * w[p][2];
+      const double bb = w[q][0] * w[q][0] + w[q][1] * w[q][1] + w[q][2] * w[q][2];
+      const double ab = w[p][0] * w[q][0] + w[p][1] * w[q][1] + w[p][2] * w[q][2];
+      if (ab == 0.0 || fabs(ab) <= 1e-17 * sqrt(aa * bb)) continue;
+      const double zeta = (bb - aa) / (2.0 * ab);
+      const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double x = w[p][r], y = w[q][r];
+        w[p][r] = c * x - sn * y;
+        w[q][r] = sn * x + c * y;
+      }
+      rotated = true;
+    }
+    if (!rotated) break;
+  }
+  double n[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) n[j] = sqrt(w[j][0] * w[j][0] + w[j][1] * w[j][1] + w[j][2] * w[j][2]);
+  int lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 1; j < 3; ++j) {
+    if (n[j] < n[lo]) lo = j;
+    if (n[j] > n[hi]) hi = j;
+  }
+  const double tiny = 1e-13 * (n[hi] > 0.0 ? n[hi] : 1.0);
+  if (n[hi] <= tiny) {  // zero matrix: any direction (svd3x3 returns the identity basis -> third axis)
+    u[0] = 0.0; u[1] = 0.0; u[2] = 1.0;
+    return;
+  }
+  if (n[lo] > tiny) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) u[r] = w[lo][r] / n[lo];
+    return;
+  }
+  const int mid = 3 - lo - hi;
+  double a[3], b[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) a[r] = w[hi][r] / n[hi];
+  if (n[mid] > tiny) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) b[r] = w[mid][r] / n[mid];
+  } else {  // rank 1: any unit vector orthogonal to a (least-aligned axis, Gram-Schmidt)
+    int k = 0;
+    if (fabs(a[1]) < fabs(a[k])) k = 1;
+    if (fabs(a[2]) < fabs(a[k])) k = 2;
+    double e[3] = {0.0, 0.0, 0.0};
+    e[k] = 1.0;
+    const double d = a[k];
+    double nn = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      b[r] = e[r] - d * a[r];
+      nn += b[r] * b[r];
+    }
+    nn = sqrt(nn);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) b[r] /= nn;
+  }
+  u[0] = a[1] * b[2] - a[2] * b[1];
+  u[1] = a[2] * b[0] - a[0] * b[2];
+  u[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// ---- computeCovariances -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict__ cloud, int n,
+                                                       const float4* __restrict__ sorted,
+                                                       const int* __restrict__ cell_start, GridDesc g,
+                                                       double* __restrict__ cov6) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per point
+  if (i >= n) return;
+  const float4 s = cloud[i];
+  double C[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
+  if (finite3g(s.x, s.y, s.z)) {
+    int cx, cy, cz;
+    cell_of_g(g, s.x, s.y, s.z, cx, cy, cz);
+    const int span = max(g.nx, max(g.ny, g.nz));
+    unsigned long long mykey = kEmptyKey;  // lanes 0..19: the running top-20 (unordered)
+    int mypos = -1;
+    for (int rho = 1;; rho *= 2) {
+      mykey = kEmptyKey;
+      mypos = -1;
+      unsigned long long kth = kEmptyKey;  // largest key among the 20 slots
+      const int side = 2 * rho + 1, nrows = side * side;
+      const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
+      const float inv_side = 1.0f / (float)side;
+      for (int rb = 0; rb < nrows; rb += 64) {
+        const int r = rb + lane;
+        const int zr = (int)(((float)r + 0.5f) * inv_side), yr = r - zr * side;
+        const int yy = cy + yr - rho, zz = cz + zr - rho;
+        int lo = 0, len = 0;
+        if (r < nrows && x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+          const int row = (zz * g.ny + yy) * g.nx;
+          lo = cell_start[row + x0];
+          len = cell_start[row + x1 + 1] - lo;
+        }
+        unsigned long long rows = __ballot(len > 0);
+        while (rows) {  // wave-uniform
+          const int rl = __ffsll((long long)rows) - 1;
+          rows &= rows - 1;
+          const int rlo = __shfl(lo, rl, 64), rlen = __shfl(len, rl, 64);
+          for (int k0 = 0; k0 < rlen; k0 += 64) {
+            unsigned long long ckey = kEmptyKey;
+            const int cpos = rlo + k0 + lane;
+            if (k0 + lane < rlen) {
+              const float4 q = sorted[cpos];
+              const float d = dist2(q.x, q.y, q.z, s.x, s.y, s.z);
+              ckey = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
+            }
+            unsigned long long better = __ballot(ckey < kth);
+            while (better) {  // wave-uniform: insert one candidate at a time
+              const int cl = __ffsll((long long)better) - 1;
+              better &= better - 1;
+              const unsigned long long c = __shfl(ckey, cl, 64);
+              if (c >= kth) continue;  // kth shrank since the ballot
+              const int cp = __shfl(cpos, cl, 64);
+              const unsigned long long holders = __ballot(lane < GK && mykey == kth);
+              const int hl = __ffsll((long long)holders) - 1;  // a slot holding the current maximum (or an empty one)
+              if (lane == hl) {
+                mykey = c;
+                mypos = cp;
+              }
+              kth = wave_max_u64(lane < GK ? mykey : 0ull);
+            }
+          }
+        }
+      }
+      const float safe = (float)rho * g.h * kGridSafety;
+      const bool full = kth != kEmptyKey;  // all 20 slots filled
+      if ((full && __uint_as_float((unsigned int)(kth >> 32)) <= safe * safe) || rho >= span) break;
+    }
+    // lanes 0..19 hold the neighbours: mean and second moments (float products, double sums), wave-reduced
+    double sx = 0, sy = 0, sz = 0, xx = 0, yx = 0, yy2 = 0, zx = 0, zy = 0, zz2 = 0;
+    int have = 0;
+    if (lane < GK && mypos >= 0) {
+      const float4 q = sorted[mypos];
+      sx = q.x; sy = q.y; sz = q.z;
+      xx = (double)(q.x * q.x);
+      yx = (double)(q.y * q.x);
+      yy2 = (double)(q.y * q.y);
+      zx = (double)(q.z * q.x);
+      zy = (double)(q.z * q.y);
+      zz2 = (double)(q.z * q.z);
+      have = 1;
+    }
+    const int cnt = __popcll(__ballot(have));
+    sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
+    xx = wave_sum_d(xx); yx = wave_sum_d(yx); yy2 = wave_sum_d(yy2);
+    zx = wave_sum_d(zx); zy = wave_sum_d(zy); zz2 = wave_sum_d(zz2);
+    if (cnt == GK) {
+      const double k = (double)GK;
+      const double mx = sx / k, my = sy / k, mz = sz / k;
+      double A[9];
+      A[0] = xx / k - mx * mx;
+      A[3] = A[1] = yx / k - my * mx;
+      A[4] = yy2 / k - my * my;
+      A[6] = A[2] = zx / k - mz * mx;
+      A[7] = A[5] = zy / k - mz * my;
+      A[8] = zz2 / k - mz * mz;
+      double u[3];
+      smallest_singular_direction(A, u);
+      const double f = 1.0 - kGicpEpsilon;
+      C[0] = 1.0 - f * u[0] * u[0];
+      C[1] = -f * u[0] * u[1];
+      C[2] = -f * u[0] * u[2];
+      C[3] = 1.0 - f * u[1] * u[1];
+      C[4] = -f * u[1] * u[2];
+      C[5] = 1.0 - f * u[2] * u[2];
+    }
+  }
+  if (lane < 6) cov6[(size_t)i * 6 + lane] = C[lane];
+}
+
+// ---- Mahalanobis matrices --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned long long* __restrict__ keys, float thr,
+                                                        Rot3d R, const double* __restrict__ cov_s,
+                                                        const double* __restrict__ cov_t, double* __restrict__ maha6) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_s) return;
+  const unsigned long long key = keys[i];
+  const unsigned int j = (unsigned int)key;
+  const float d2 = __uint_as_float((unsigned int)(key >> 32));
+  if (j == 0xFFFFFFFFu || !(d2 < thr)) return;
+  const double* a = cov_s + (size_t)i * 6;
+  const double* b = cov_t + (size_t)j * 6;
+  const double C1[9] = {a[0], a[1], a[2], a[1], a[3], a[4], a[2], a[4], a[5]};
+  double RC[9], S[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) RC[3 * r + c] = R.m[3 * r] * C1[c] + R.m[3 * r + 1] * C1[3 + c] + R.m[3 * r + 2] * C1[6 + c];
+  const double C2[9] = {b[0], b[1], b[2], b[1], b[3], b[4], b[2], b[4], b[5]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      S[3 * r + c] = RC[3 * r] * R.m[3 * c] + RC[3 * r + 1] * R.m[3 * c + 1] + RC[3 * r + 2] * R.m[3 * c + 2] + C2[3 * r + c];
+  // inverse by adjugate; the result of inverting a (numerically) symmetric matrix is stored as its upper triangle
+  const double c00 = S[4] * S[8] - S[5] * S[7], c01 = S[5] * S[6] - S[3] * S[8], c02 = S[3] * S[7] - S[4] * S[6];
+  const double id = 1.0 / (S[0] * c00 + S[1] * c01 + S[2] * c02);
+  double* M = maha6 + (size_t)i * 6;
+  M[0] = c00 * id;
+  M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
+  M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
+  M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
+  M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
+  M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
+}
+
+// ---- one BFGS evaluation ---------------------------------------------------------------------------------------
+// terms: 0 = m, 1 = sum r^T M r, 2..4 = sum M r, 5..13 = sum (base p)(M r)^T (row-major), 14 = sum d2 of the NN sweep
+__global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict__ src, int n_s,
+                                                        const float4* __restrict__ tgt,
+                                                        const unsigned long long* __restrict__ keys, float thr, Xform T,
+                                                        Xform base, const double* __restrict__ maha6,
+                                                        double* __restrict__ partials) {
+  double acc[kReduceTerms];
+#pragma unroll
+  for (int k = 0; k < kReduceTerms; ++k) acc[k] = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_s; i += gridDim.x * 256) {
+    const unsigned long long key = keys[i];
+    const unsigned int j = (unsigned int)key;
+    const float d2 = __uint_as_float((unsigned int)(key >> 32));
+    if (j == 0xFFFFFFFFu || !(d2 < thr)) continue;
+    const float4 s = src[i];
+    const float4 q = tgt[j];
+    float px, py, pz, bx, by, bz;
+    xform_point(T, s.x, s.y, s.z, px, py, pz);
+    xform_point(base, s.x, s.y, s.z, bx, by, bz);
+    const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);
+    const double* M = maha6 + (size_t)i * 6;
+    const double t0 = M[0] * r0 + M[1] * r1 + M[2] * r2;
+    const double t1 = M[1] * r0 + M[3] * r1 + M[4] * r2;
+    const double t2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
+    acc[0] += 1.0;
+    acc[1] += r0 * t0 + r1 * t1 + r2 * t2;
+    acc[2] += t0;
+    acc[3] += t1;
+    acc[4] += t2;
+    const double pb[3] = {(double)bx, (double)by, (double)bz};
+    const double tt[3] = {t0, t1, t2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[5 + 3 * r + c] += pb[r] * tt[c];
+    acc[14] += (double)d2;
+  }
+  block_reduce_store<4>(acc, partials);
+}
+
+}  // namespace
+
+hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
+                                   const GridDesc& g, double* cov6, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6);
+  return hipGetLastError();
+}
+
+hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, float thr, const Rot3d& R, const double* cov_s,
+                                   const double* cov_t, double* maha6, hipStream_t stream) {
+  if (n_s <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gicp_maha_kernel, dim3((n_s + 255) / 256), dim3(256), 0, stream, n_s, keys, thr, R, cov_s, cov_t, maha6);
+  return hipGetLastError();
+}
+
+hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                            const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
+                            hipStream_t stream) {
+  int blocks = (n_s + 255) / 256;
+  if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials);
+  return launch_reduce_final(partials, blocks, sums_out, stream);
+}
+
+}  // namespace icpgpu

@@ -89,6 +89,23 @@ int grid_search_blocks(int n_s);
 hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,
                                 const Xform& T, int num_cus, unsigned long long* keys, hipStream_t stream);
 
+// ---- GICP mode (icp_gicp.hip), SURVEY.md 8(f1) ----------------------------------------------------------------
+static constexpr int kGicpK = 20;              // PCL k_correspondences_
+static constexpr double kGicpEpsilon = 1e-3;   // PCL gicp_epsilon_
+struct Rot3d {
+  double m[9];  // row-major
+};
+// cov6[i] = upper triangle (xx, xy, xz, yy, yz, zz) of the regularised covariance of point i's 20 nearest neighbours
+hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
+                                   const GridDesc& g, double* cov6, hipStream_t stream);
+// maha6[i] = upper triangle of (C_t[j] + R C_s[i] R^T)^-1 for every source point whose key passes d2 < thr
+hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, float thr, const Rot3d& R, const double* cov_s,
+                                   const double* cov_t, double* maha6, hipStream_t stream);
+// sums_out[0..14] = {m, sum r^T M r, sum M r (3), sum (base p)(M r)^T (9), sum d2}; partials: kMaxReduceBlocks x 17
+hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                            const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
+                            hipStream_t stream);
+
 // ---- voxel-grid down-sampling (icp_voxel.hip), SURVEY.md 8(f2) -------------------------------------------------
 size_t voxel_temp_bytes(int n);
 // keys/vals: 2*n ints each, flags/slots: n ints each, d_n_out: 2 ints whose sum is the number of cells written to `out`.

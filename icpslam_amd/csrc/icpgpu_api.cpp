@@ -23,6 +23,7 @@
 
 #include "../../include/icpgpu.h"
 #include "icp_kernels.h"
+#include "icp_gicp_solver.h"
 #include "icp_solver.h"
 
 using namespace icpgpu;
@@ -70,6 +71,11 @@ struct icpgpu_ctx {
   DeviceBuf keys, partials, sums, out, idx, d2;
   GridIndex grid;            // acceleration structure over the current target
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
+  uint64_t src_version = 1;  // bumped whenever the source cloud changes
+  // GICP mode: grids used for the 20-NN covariances, per-point covariances (6 doubles), Mahalanobis matrices
+  GridIndex cov_grid_src, cov_grid_tgt;
+  DeviceBuf cov_src, cov_tgt, maha;
+  uint64_t cov_src_version = 0, cov_tgt_version = 0;
   double* h_sums = nullptr;  // pinned (17 doubles)
   int* h_ints = nullptr;     // pinned (8 ints: bbox / stats / counters)
   bool have_final = false;
@@ -185,36 +191,27 @@ struct SweepTimes {
   float nn_ms = 0.f, reduce_ms = 0.f;
 };
 
-// (Re)build the grid over the target if the parameters ask for it. Leaves c->grid.usable = false when the grid
-// cannot help (tiny / degenerate / too dense a target): the caller then uses the brute-force kernel.
-int ensure_grid(icpgpu_ctx* c, float accept_thr) {
-  GridIndex& G = c->grid;
-  const int n_t = (int)c->tgt.n;
-  const int mode = c->params.nn_mode;
-  const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && c->tgt.n >= kGridMinTarget);
-  double cut = std::sqrt((double)accept_thr) * (1.0 + 1e-6);
-  if (!want || n_t <= 0 || !(accept_thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
-    G.usable = false;
-    G.built = false;
-    return ICPGPU_OK;
-  }
+// (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
+// cannot help (no finite point, one cell holding > kMaxCellPopulation points).
+int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, GridIndex& G) {
+  const int n_t = (int)cloud.n;
   const float cutoff = (float)cut;
-  if (G.built && G.version == c->tgt_version && G.cutoff == cutoff) return ICPGPU_OK;
+  if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;
   G.built = true;
   G.usable = false;
-  G.version = c->tgt_version;
+  G.version = version;
   G.cutoff = cutoff;
 
   int rc = ensure(c, G.ints, 8 * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(G.ints.ptr);
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(c, launch_bbox(c->tgt.data(), n_t, d_ints, c->stream));
+  HIP_TRY(c, launch_bbox(cloud.data(), n_t, d_ints, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float lo[3], hi[3];
   decode_bbox(c->h_ints, lo, hi);
-  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite target point
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
 
   // cell size: a quarter of the cutoff (cube radii 1, 2, 4, 5 cells for an unmatched point), grown until the dense
   // table fits.  Measured on 200k-point scans: /3 and /6 are both slower (more candidates / more rows per cube).
@@ -248,7 +245,7 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
   if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
   if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
   if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
-  HIP_TRY(c, launch_grid_build(c->tgt.data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
+  HIP_TRY(c, launch_grid_build(cloud.data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
                                static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6,
                                static_cast<float4*>(G.sorted.ptr), c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -263,6 +260,20 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
   G.max_pop = c->h_ints[7];
   G.usable = G.n_binned > 0 && G.max_pop <= kMaxCellPopulation;
   return ICPGPU_OK;
+}
+
+// The target's grid, if the parameters ask for it; otherwise (or when it cannot help) the brute-force kernel is used.
+int ensure_grid(icpgpu_ctx* c, float accept_thr) {
+  GridIndex& G = c->grid;
+  const int mode = c->params.nn_mode;
+  const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && c->tgt.n >= kGridMinTarget);
+  const double cut = std::sqrt((double)accept_thr) * (1.0 + 1e-6);
+  if (!want || c->tgt.n == 0 || !(accept_thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
+    G.usable = false;
+    G.built = false;
+    return ICPGPU_OK;
+  }
+  return build_grid(c, c->tgt, c->tgt_version, cut, G);
 }
 
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
@@ -508,6 +519,219 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   return ICPGPU_OK;
 }
 
+// ---- GICP mode: pcl::GeneralizedIterativeClosestPoint::computeTransformation ----------------------
+void mat4f_identity(float m[16]) {
+  for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f;
+}
+void mat4f_mul(const float a[16], const float b[16], float out[16]) {  // column-major, float accumulate (Eigen Matrix4f)
+  float r[16];
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 4; ++row) {
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += a[k * 4 + row] * b[col * 4 + k];
+      r[col * 4 + row] = s;
+    }
+  std::memcpy(out, r, sizeof(r));
+}
+Xform xform_from_f16(const float f[16]) {
+  Xform x;
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 4; ++cc) x.m[4 * r + cc] = f[cc * 4 + r];
+  return x;
+}
+
+// per-point covariances of `cloud` (20-NN in its own grid); cached per cloud version
+int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version) {
+  if (cov_version == version && cov.ptr) return ICPGPU_OK;
+  // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
+  const double cut = std::max(1e-3, c->params.max_correspondence_distance);
+  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, G);
+  if (rc) return rc;
+  if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
+  if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_gicp_covariances(cloud.data(), (int)cloud.n, static_cast<const float4*>(G.sorted.ptr),
+                                     static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.gicp_cov_launches += 1;
+  c->prof.gicp_cov_ms += ms;
+  cov_version = version;
+  return ICPGPU_OK;
+}
+
+int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  const auto t_start = std::chrono::steady_clock::now();
+  init_result(res);
+  c->prof.aligns += 1;
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  const icpgpu_params& P = c->params;
+  float guess[16];
+  if (guess_in) std::memcpy(guess, guess_in, sizeof(guess));
+  else mat4f_identity(guess);
+
+  auto finish_early = [&]() {  // empty target / clouds smaller than k_correspondences_: PCL leaves converged_ = false, T = I
+    c->final_T = mat4_identity();
+    c->have_final = true;
+    int rc = write_output_cloud(c, to_xform(c->final_T), out_xyzw);
+    res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    return rc;
+  };
+  if (n_t == 0 || n_s < kGicpK || n_t < kGicpK) return finish_early();
+
+  int rc;
+  if ((rc = ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version))) return rc;
+  if ((rc = ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version))) return rc;
+  // GICP keeps d2 < r^2 (strict): the largest float below r^2
+  const double r2 = P.max_correspondence_distance * P.max_correspondence_distance;
+  float thr = threshold_from(r2);
+  if ((double)thr >= r2) thr = std::nextafterf(thr, -INFINITY);
+  const float thr_excl = std::nextafterf(thr, INFINITY);  // d2 < thr_excl  <=>  d2 <= thr
+  if ((rc = ensure_grid(c, thr))) return rc;
+  if ((rc = ensure(c, c->keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(c, c->maha, (size_t)n_s * 6 * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  auto* maha = static_cast<double*>(c->maha.ptr);
+  const Xform base = xform_from_f16(guess);
+
+  float transformation[16], previous[16];
+  mat4f_identity(transformation);
+  mat4f_identity(previous);
+  int nr = 0, state = ICPGPU_NOT_CONVERGED;
+  bool converged = false;
+  unsigned n_corr = 0;
+  double mse = 0.0, dev_ms = 0.0;
+  const double rot_eps = 2e-3;  // PCL rotation_epsilon_ (never set by the reference)
+
+  while (!converged) {
+    float TG[16];
+    mat4f_mul(transformation, guess, TG);
+    const Xform Tq = xform_from_f16(TG);
+    Rot3d R;
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += (double)transformation[k * 4 + r] * (double)guess[cc * 4 + k];
+        R.m[3 * r + cc] = s;
+      }
+    // correspondences: exact NN keys (only those with d2 < r^2 are used, so the grid's cutoff search is complete)
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (grid_ready(c)) {
+      HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, Tq, static_cast<const float4*>(c->grid.sorted.ptr),
+                                       static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, keys, nullptr, nullptr,
+                                       nullptr, c->stream));
+    } else {
+      const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
+      if (plan.splits > 1) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+      HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, Tq, plan, keys, c->stream));
+    }
+    HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                       static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+    // rigid_transformation_estimation_: BFGS over x = (t, roll, pitch, yaw), every evaluation one reduction on the device
+    double m_count = 0.0;
+    auto eval = [&](const Vec6& x, bool want_gradient, GicpEval& out) -> bool {
+      float T[16];
+      std::memcpy(T, guess, sizeof(T));
+      gicp_apply_state(T, x);
+      if (launch_gicp_cost(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
+                           static_cast<double*>(c->partials.ptr), static_cast<double*>(c->sums.ptr), c->stream) != hipSuccess)
+        return false;
+      if (hipMemcpyAsync(c->h_sums, c->sums.ptr, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        return false;
+      if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+      c->prof.gicp_cost_launches += 1;
+      const double* s = c->h_sums;
+      m_count = s[0];
+      mse = s[0] > 0 ? s[14] / s[0] : 0.0;
+      if (!(s[0] >= 1.0)) {
+        out.f = 0.0;
+        out.g.fill(0.0);
+        return true;
+      }
+      out.f = s[1] / s[0];
+      if (want_gradient) {
+        const double sc = 2.0 / s[0];
+        double Rm[9];
+        for (int k = 0; k < 3; ++k) out.g[k] = s[2 + k] * sc;
+        for (int k = 0; k < 9; ++k) Rm[k] = s[5 + k] * sc;
+        gicp_rotation_gradient(x, Rm, out.g);
+      }
+      return true;
+    };
+    // number of correspondences (one evaluation at the current state; it is also the BFGS start, cached by the solver)
+    Vec6 x = gicp_state_from_matrix(transformation);
+    GicpEval probe;
+    if (!eval(x, false, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+    n_corr = (unsigned)m_count;
+    std::memcpy(previous, transformation, sizeof(previous));
+    if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+      state = ICPGPU_CONV_NO_CORRESPONDENCES;
+      break;
+    }
+    const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2);
+    if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+    if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
+      state = ICPGPU_NOT_CONVERGED;
+      break;
+    }
+    mat4f_identity(transformation);
+    gicp_apply_state(transformation, x);
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    dev_ms += ms;
+    c->prof.grid_launches += grid_ready(c) ? 1 : 0;
+    c->prof.grid_ms += grid_ready(c) ? ms : 0.0;
+    double delta = 0.0;
+    for (int k = 0; k < 4; ++k)
+      for (int l = 0; l < 4; ++l) {
+        const double ratio = (k < 3 && l < 3) ? 1.0 / rot_eps : 1.0 / P.transformation_epsilon;
+        delta = std::max(delta, ratio * std::fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]));
+      }
+    ++nr;
+    c->prof.iterations += 1;
+    if (nr >= P.max_iterations || (delta < 1 && !P.force_iterations)) {
+      converged = true;
+      state = nr >= P.max_iterations ? ICPGPU_CONV_ITERATIONS : ICPGPU_CONV_TRANSFORM;
+      std::memcpy(previous, transformation, sizeof(previous));
+    }
+  }
+  // PCL's own composition of the result: R = previous.R * guess.R, t = previous.t + guess.t
+  float fin[16];
+  mat4f_identity(fin);
+  for (int r = 0; r < 3; ++r) {
+    for (int cc = 0; cc < 3; ++cc) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += previous[k * 4 + r] * guess[cc * 4 + k];
+      fin[cc * 4 + r] = s;
+    }
+    fin[12 + r] = previous[12 + r] + guess[12 + r];
+  }
+  std::memcpy(res->T, fin, sizeof(fin));
+  for (int i = 0; i < 16; ++i) c->final_T[i] = (double)fin[i];
+  c->have_final = true;
+  res->converged = converged ? 1 : 0;
+  res->iterations = nr;
+  res->convergence_state = state;
+  res->n_correspondences = n_corr;
+  res->mse_last = mse;
+  const Xform Tf = xform_from_f16(fin);
+  if (want_fitness) {
+    SweepTimes st;
+    if ((rc = nn_and_reduce(c, Tf, FLT_MAX, true, &st))) return rc;
+    dev_ms += st.nn_ms + st.reduce_ms;
+    res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
+  }
+  if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
+  res->t_device_ms = dev_ms;
+  res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  return ICPGPU_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
@@ -589,6 +813,19 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->partials);
   release(c->sums);
   release(c->out);
+  for (GridIndex* G : {&c->cov_grid_src, &c->cov_grid_tgt}) {
+    release(G->sorted);
+    release(G->cell_start);
+    release(G->cell_of_point);
+    release(G->rank);
+    release(G->block_sums);
+    release(G->ints);
+    release(G->unmatched);
+    release(G->leftover);
+  }
+  release(c->cov_src);
+  release(c->cov_tgt);
+  release(c->maha);
   release(c->vox_in);
   release(c->vox_out);
   release(c->vox_keys);
@@ -638,6 +875,7 @@ int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
 
 int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
+  c->src_version++;
   return set_cloud_host(c, c->src, xyzw, n);
 }
 int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
@@ -647,6 +885,7 @@ int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
 }
 int icpgpu_set_source_device(icpgpu_ctx* c, const void* d, size_t n) {
   ENTER(c);
+  c->src_version++;
   return set_cloud_device(c, c->src, d, n);
 }
 int icpgpu_set_target_device(icpgpu_ctx* c, const void* d, size_t n) {
@@ -659,7 +898,13 @@ int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
   ENTER(c);
   if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "promote_source_to_target: no source set");
   std::swap(c->src, c->tgt);
+  // the source's GICP covariances stay valid for the cloud that is now the target
+  std::swap(c->cov_src, c->cov_tgt);
+  std::swap(c->cov_grid_src, c->cov_grid_tgt);
   c->tgt_version++;
+  c->cov_tgt_version = (c->cov_src_version == c->src_version) ? c->tgt_version : 0;
+  c->cov_src_version = 0;
+  c->src_version++;
   c->src.n = 0;
   c->src.set = false;
   if (c->src.buf.external) c->src.buf = DeviceBuf{};
@@ -671,7 +916,7 @@ int icpgpu_align(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fi
   ENTER(c);
   if (!res) return fail(c, ICPGPU_ERR_INVALID_ARG, "result is null");
   if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "align: source and target must be set first");
-  if (c->params.method == ICPGPU_GICP) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP mode is not built yet");
+  if (c->params.method == ICPGPU_GICP) return align_gicp(c, guess, out_xyzw, want_fitness, res);
   return align_p2p(c, guess, out_xyzw, want_fitness, res);
 }
 
@@ -695,7 +940,6 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
                        const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
   ENTER(c);
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
-  if (c->params.method == ICPGPU_GICP) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP mode is not built yet");
   if (n_pairs == 0) return ICPGPU_OK;
   size_t n_workers = 8;
   if (const char* v = std::getenv("ICPGPU_BATCH_WORKERS")) n_workers = (size_t)std::max(1, std::atoi(v));
@@ -718,10 +962,12 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     for (;;) {
       const size_t k = next.fetch_add(1);
       if (k >= n_pairs || first_error.load() != ICPGPU_OK) return;
+      w->src_version++;
       int rc = set_cloud_host(w, w->src, src[k], n_src[k]);
       w->tgt_version++;
       if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k]);
-      if (!rc) rc = align_p2p(w, nullptr, nullptr, want_fitness, &results[k]);
+      if (!rc) rc = w->params.method == ICPGPU_GICP ? align_gicp(w, nullptr, nullptr, want_fitness, &results[k])
+                                                     : align_p2p(w, nullptr, nullptr, want_fitness, &results[k]);
       if (rc) {
         int expected = ICPGPU_OK;
         if (first_error.compare_exchange_strong(expected, rc)) c->err = "align_batch pair " + std::to_string(k) + ": " + w->err;
@@ -742,6 +988,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.grid_launches += p.grid_launches; c->prof.grid_ms += p.grid_ms; c->prof.grid_bytes += p.grid_bytes;
     c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
     c->prof.voxel_launches += p.voxel_launches; c->prof.voxel_ms += p.voxel_ms; c->prof.voxel_bytes += p.voxel_bytes;
+    c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;
     std::memset(&p, 0, sizeof(p));
   }
   return first_error.load();
@@ -854,10 +1101,26 @@ int icpgpu_set_source_voxel_filtered(icpgpu_ctx* c, const float* xyzw, size_t n,
   int m = 0;
   bool pass = false;
   if (c->src.buf.external) c->src.buf = DeviceBuf{};
+  c->src_version++;
   if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->src.buf, &m, &pass))) return rc;
   c->src.n = (size_t)m;
   c->src.set = true;
   if (n_out) *n_out = (size_t)m;
+  return ICPGPU_OK;
+}
+
+int icpgpu_gicp_covariances(icpgpu_ctx* c, int of_target, double* out6) {
+  ENTER(c);
+  Cloud& cl = of_target ? c->tgt : c->src;
+  if (!cl.set) return fail(c, ICPGPU_ERR_NO_INPUT, "gicp_covariances: cloud not set");
+  if (cl.n && !out6) return fail(c, ICPGPU_ERR_INVALID_ARG, "null output");
+  if (cl.n < (size_t)kGicpK) return fail(c, ICPGPU_ERR_INVALID_ARG, "GICP needs at least %d points per cloud", kGicpK);
+  int rc = of_target ? ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version)
+                     : ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version);
+  if (rc) return rc;
+  const DeviceBuf& cov = of_target ? c->cov_tgt : c->cov_src;
+  HIP_TRY(c, hipMemcpyAsync(out6, cov.ptr, cl.n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return ICPGPU_OK;
 }
 

@@ -173,6 +173,17 @@ class Context:
         self._check(self._L.icpgpu_transform(self._h, _fp(Tb), _fp(out)))
         return out
 
+    def gicp_covariances(self, of_target: bool = False) -> np.ndarray:
+        """(n, 3, 3) regularised neighbourhood covariances of the source (or target) cloud -- GICP row a11."""
+        n = self.n_target if of_target else self.n_source
+        out = np.zeros((n, 6), np.float64)
+        self._check(self._L.icpgpu_gicp_covariances(self._h, int(of_target), out.ctypes.data_as(C.POINTER(C.c_double))))
+        full = np.empty((n, 3, 3))
+        full[:, 0, 0], full[:, 0, 1], full[:, 0, 2] = out[:, 0], out[:, 1], out[:, 2]
+        full[:, 1, 0], full[:, 1, 1], full[:, 1, 2] = out[:, 1], out[:, 3], out[:, 4]
+        full[:, 2, 0], full[:, 2, 1], full[:, 2, 2] = out[:, 2], out[:, 4], out[:, 5]
+        return full
+
     # the step before the path (icp_odometer.cpp:96-101) ---------------------------------------------------------
     def voxel_grid(self, cloud, leaf: float) -> np.ndarray:
         cloud = _as_cloud(cloud)

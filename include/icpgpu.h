@@ -121,6 +121,9 @@ typedef struct {
   uint64_t voxel_launches;    /* voxel-grid filter runs */
   double voxel_ms;            /* key + sort + flag/scan + centroid kernels */
   uint64_t voxel_bytes;       /* algorithmic bytes: 16*N in + 16*N_out */
+  uint64_t gicp_cov_launches; /* GICP: per-cloud 20-NN covariance passes */
+  double gicp_cov_ms;
+  uint64_t gicp_cost_launches; /* GICP: BFGS function/gradient evaluations (one device reduction each) */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -181,6 +184,10 @@ int icpgpu_reduce(icpgpu_ctx* ctx, const float* T, double max_dist, double sums[
 int icpgpu_solve(const double sums[17], double Tk[16]);
 /* a6: out = T * source (w = 1), pcl::transformPointCloud (icp_odometer.cpp:205). */
 int icpgpu_transform(icpgpu_ctx* ctx, const float* T, float* out_xyzw);
+
+/* a11 (GICP mode): per-point regularised covariances U diag(1,1,1e-3) U^T of the 20 nearest neighbours
+ * (pcl::GeneralizedIterativeClosestPoint::computeCovariances); out6 = n x {xx, xy, xz, yy, yz, zz}. */
+int icpgpu_gicp_covariances(icpgpu_ctx* ctx, int of_target, double* out6);
 
 /* ---- the step before the path: voxel-grid down-sampling -------------------- */
 /* replaces IcpOdometer::voxelFilterCloud = pcl::VoxelGrid<PointXYZ>::filter with leaf (L, L, L)

@@ -75,6 +75,7 @@ def lib():
                                     C.POINTER(Result), C.POINTER(IterTrace)]
         L.orc_voxel_grid.argtypes = [fp, C.c_size_t, C.c_float, fp]
         L.orc_voxel_grid.restype = C.c_long
+        L.orc_gicp_covariances.argtypes = [fp, C.c_size_t, C.c_int, dp]
         L.orc_svd3.argtypes = [dp, dp, dp, dp]
         L.orc_svd3.restype = None
         _lib = L
@@ -180,6 +181,15 @@ def voxel_grid(cloud, leaf: float):
     if n < 0:
         return cloud.copy()
     return out[:n].copy()
+
+
+def gicp_covariances(cloud, arith=ARITH_FMA) -> np.ndarray:
+    cloud, pc = _f32(cloud)
+    out = np.zeros((cloud.shape[0], 9), np.float64)
+    rc = lib().orc_gicp_covariances(pc, cloud.shape[0], arith, out.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise RuntimeError("orc_gicp_covariances: cloud smaller than k = 20")
+    return out.reshape(-1, 3, 3)
 
 
 def svd3(A):

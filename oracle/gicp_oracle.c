@@ -1,11 +1,702 @@
 /*
- * gicp_oracle.c -- CPU ORACLE for the GICP mode (SURVEY.md §8(f1), Appendix A.2).  TEST INFRASTRUCTURE ONLY.
- * PARITY UNPINNED (see icp_oracle.h).  Placeholder until the GICP row is built.
+ * gicp_oracle.c -- CPU ORACLE for the GICP mode (SURVEY.md section 8(f1), Appendix A.2).  TEST INFRASTRUCTURE ONLY.
+ *
+ *      ***  PARITY UNPINNED  ***   (see icp_oracle.h)
+ *
+ * Restates pcl::GeneralizedIterativeClosestPoint<PointXYZ,PointXYZ> of PCL 1.8.x -- the class the reference literally
+ * instantiates at /root/reference/src/icpslam/icp_odometer.cpp:188 and src/icpslam/octree_mapper.cpp:104 with
+ * max iterations 10 / 30, transformation epsilon 1e-6, correspondence distance 1.0 (icp_odometer.h:63-65):
+ *   computeCovariances   : 20 nearest neighbours (incl. the point), covariance in double from float products,
+ *                          SVD, singular values replaced by (1, 1, gicp_epsilon = 1e-3)
+ *   computeTransformation: per outer iteration 1-NN of (transformation * guess * p) in the target, keep d2 < r^2,
+ *                          M_i = (C_t[j] + R C_s[i] R^T)^-1, minimise (1/m) sum r^T M r over x = (t, roll, pitch, yaw)
+ *                          with PCL's BFGS (a port of GSL's vector_bfgs2 + Fletcher line search), <= 20 inner steps,
+ *                          gradient tolerance 1e-2; stop when nr >= max_iterations or delta < 1
+ *                          (rotation entries scaled by 1/rotation_epsilon = 1/2e-3, the rest by 1/transformation_epsilon)
+ * PCL is not in /root/reference; the constants above are PCL's constructor defaults the reference leaves untouched.
+ *
+ * Arithmetic choices shared with the HIP implementation: point transforms use the fmaf chain of
+ * icp_oracle.c; NN keys are (d2, lowest index); the 20-NN set is the 20 smallest (d2, index) keys.
  */
-#include "icp_oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
-int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, const orc_params* P,
-                   const float* guess, float* out_xyzw, int want_fitness, orc_result* res, orc_iter_trace* trace) {
-  (void)src; (void)n_s; (void)tgt; (void)n_t; (void)P; (void)guess; (void)out_xyzw; (void)want_fitness; (void)res; (void)trace;
-  return -2; /* not implemented yet */
+#include "icp_oracle.h"
+#include "oracle_internal.h"
+
+#define GICP_K 20
+#define GICP_EPSILON 1e-3
+#define GICP_ROTATION_EPSILON 2e-3
+#define GICP_MAX_INNER 20
+#define GICP_GRADIENT_TOL 1e-2
+
+/* ------------------------------------------------------------------------------------------ */
+/* small helpers                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static inline void xform_point(const float T[16], const float* s, float* p) {
+  p[0] = fmaf(T[8], s[2], fmaf(T[4], s[1], fmaf(T[0], s[0], T[12])));
+  p[1] = fmaf(T[9], s[2], fmaf(T[5], s[1], fmaf(T[1], s[0], T[13])));
+  p[2] = fmaf(T[10], s[2], fmaf(T[6], s[1], fmaf(T[2], s[0], T[14])));
+}
+
+static void mat4f_mul(const float A[16], const float B[16], float C[16]) { /* column-major, float accumulate */
+  float R[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      float s = 0.0f;
+      for (int k = 0; k < 4; ++k) s += A[k * 4 + r] * B[c * 4 + k];
+      R[c * 4 + r] = s;
+    }
+  memcpy(C, R, sizeof(R));
+}
+
+static void mat4f_identity(float M[16]) {
+  memset(M, 0, 16 * sizeof(float));
+  M[0] = M[5] = M[10] = M[15] = 1.0f;
+}
+
+/* 3x3 symmetric-positive inverse via adjugate (Eigen's fixed-size 3x3 inverse), row-major */
+static void inv3(const double A[9], double Inv[9]) {
+  const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  const double id = 1.0 / det;
+  Inv[0] = c00 * id;
+  Inv[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+  Inv[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Inv[3] = c01 * id;
+  Inv[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+  Inv[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Inv[6] = c02 * id;
+  Inv[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+  Inv[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* computeCovariances                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_out /* n x 9 row-major */) {
+  if (n < GICP_K) return -1; /* PCL: "Number or points in cloud is less than k_correspondences_" */
+  void* tree = orc_kd_build(cloud, n, arith);
+  int32_t idx[GICP_K];
+  float d2[GICP_K];
+  for (size_t i = 0; i < n; ++i) {
+    orc_kd_knn(tree, cloud + 4 * i, GICP_K, idx, d2);
+    double mean[3] = {0, 0, 0}, cov[9] = {0};
+    for (int j = 0; j < GICP_K; ++j) {
+      const float* pt = cloud + 4 * (size_t)idx[j];
+      mean[0] += pt[0];
+      mean[1] += pt[1];
+      mean[2] += pt[2];
+      /* float * float products (rounded to float), accumulated in double -- as the C++ expression evaluates */
+      cov[0] += (double)(pt[0] * pt[0]);
+      cov[3] += (double)(pt[1] * pt[0]);
+      cov[4] += (double)(pt[1] * pt[1]);
+      cov[6] += (double)(pt[2] * pt[0]);
+      cov[7] += (double)(pt[2] * pt[1]);
+      cov[8] += (double)(pt[2] * pt[2]);
+    }
+    for (int a = 0; a < 3; ++a) mean[a] /= (double)GICP_K;
+    for (int k = 0; k < 3; ++k)
+      for (int l = 0; l <= k; ++l) {
+        cov[3 * k + l] /= (double)GICP_K;
+        cov[3 * k + l] -= mean[k] * mean[l];
+        cov[3 * l + k] = cov[3 * k + l];
+      }
+    double U[9], s[3], V[9];
+    orc_svd3(cov, U, s, V);
+    double* C = cov_out + 9 * i;
+    for (int e = 0; e < 9; ++e) C[e] = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const double v = (k == 2) ? GICP_EPSILON : 1.0;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C[3 * r + c] += v * U[3 * r + k] * U[3 * c + k];
+    }
+  }
+  orc_kd_free(tree);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* applyState / cost / gradient                                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* t <- Rz(x5) Ry(x4) Rx(x3) * t.R ; t.col(3) += (x0, x1, x2).  float, like Eigen's Matrix4f/AngleAxisf path:
+ * each AngleAxis becomes a quaternion (cos a/2, sin a/2 * axis), the product is converted to a rotation matrix. */
+static void apply_state(float t[16], const double x[6]) {
+  const float hx = 0.5f * (float)x[3], hy = 0.5f * (float)x[4], hz = 0.5f * (float)x[5];
+  const float qx[4] = {cosf(hx), sinf(hx), 0.f, 0.f}; /* w, x, y, z */
+  const float qy[4] = {cosf(hy), 0.f, sinf(hy), 0.f};
+  const float qz[4] = {cosf(hz), 0.f, 0.f, sinf(hz)};
+  float a[4], q[4];
+  /* a = qz * qy */
+  a[0] = qz[0] * qy[0] - qz[1] * qy[1] - qz[2] * qy[2] - qz[3] * qy[3];
+  a[1] = qz[0] * qy[1] + qz[1] * qy[0] + qz[2] * qy[3] - qz[3] * qy[2];
+  a[2] = qz[0] * qy[2] - qz[1] * qy[3] + qz[2] * qy[0] + qz[3] * qy[1];
+  a[3] = qz[0] * qy[3] + qz[1] * qy[2] - qz[2] * qy[1] + qz[3] * qy[0];
+  /* q = a * qx */
+  q[0] = a[0] * qx[0] - a[1] * qx[1] - a[2] * qx[2] - a[3] * qx[3];
+  q[1] = a[0] * qx[1] + a[1] * qx[0] + a[2] * qx[3] - a[3] * qx[2];
+  q[2] = a[0] * qx[2] - a[1] * qx[3] + a[2] * qx[0] + a[3] * qx[1];
+  q[3] = a[0] * qx[3] + a[1] * qx[2] - a[2] * qx[1] + a[3] * qx[0];
+  const float tx = 2.f * q[1], ty = 2.f * q[2], tz = 2.f * q[3];
+  const float twx = tx * q[0], twy = ty * q[0], twz = tz * q[0];
+  const float txx = tx * q[1], txy = ty * q[1], txz = tz * q[1];
+  const float tyy = ty * q[2], tyz = tz * q[2], tzz = tz * q[3];
+  float R[9]; /* row-major */
+  R[0] = 1.f - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.f - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.f - (txx + tyy);
+  float nr[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += R[3 * r + k] * t[c * 4 + k];
+      nr[3 * r + c] = s;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) t[c * 4 + r] = nr[3 * r + c];
+  t[12] += (float)x[0];
+  t[13] += (float)x[1];
+  t[14] += (float)x[2];
+}
+
+typedef struct {
+  const float* src; /* the source cloud (PCL's `output`, a copy of the input) */
+  const float* tgt;
+  const int32_t* si;
+  const int32_t* ti;
+  int m;
+  const double* maha; /* indexed by SOURCE index, 9 doubles each */
+  float base[16];     /* base_transformation_ = guess */
+} gicp_problem;
+
+/* f and the 12 raw gradient sums (g_t(3), R(9)) at x */
+static void eval_sums(const gicp_problem* P, const double x[6], double* f, double gt[3], double Rm[9]) {
+  float T[16];
+  memcpy(T, P->base, sizeof(T));
+  apply_state(T, x);
+  double acc = 0.0;
+  gt[0] = gt[1] = gt[2] = 0.0;
+  for (int k = 0; k < 9; ++k) Rm[k] = 0.0;
+  for (int i = 0; i < P->m; ++i) {
+    const float* ps = P->src + 4 * (size_t)P->si[i];
+    const float* pt = P->tgt + 4 * (size_t)P->ti[i];
+    float pp[3], pb[3];
+    xform_point(T, ps, pp);
+    const double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]), (double)(pp[2] - pt[2])};
+    const double* M = P->maha + 9 * (size_t)P->si[i];
+    double temp[3];
+    for (int r = 0; r < 3; ++r) temp[r] = M[3 * r] * res[0] + M[3 * r + 1] * res[1] + M[3 * r + 2] * res[2];
+    acc += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
+    for (int r = 0; r < 3; ++r) gt[r] += temp[r];
+    xform_point(P->base, ps, pb); /* PCL uses base_transformation_ * p_src for the rotation gradient */
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rm[3 * r + c] += (double)pb[r] * temp[c];
+  }
+  *f = acc;
+}
+
+static void r_derivative(const double x[6], const double R[9], double g[6]) {
+  const double phi = x[3], theta = x[4], psi = x[5];
+  const double cphi = cos(phi), sphi = sin(phi), cth = cos(theta), sth = sin(theta), cpsi = cos(psi), spsi = sin(psi);
+  double dphi[9], dth[9], dpsi[9]; /* row-major */
+  dphi[0] = 0; dphi[3] = 0; dphi[6] = 0;
+  dphi[1] = sphi * spsi + cphi * cpsi * sth;
+  dphi[4] = -cpsi * sphi + cphi * spsi * sth;
+  dphi[7] = cphi * cth;
+  dphi[2] = cphi * spsi - cpsi * sphi * sth;
+  dphi[5] = -cphi * cpsi - sphi * spsi * sth;
+  dphi[8] = -cth * sphi;
+  dth[0] = -cpsi * sth; dth[3] = -spsi * sth; dth[6] = -cth;
+  dth[1] = cpsi * cth * sphi; dth[4] = cth * sphi * spsi; dth[7] = -sphi * sth;
+  dth[2] = cphi * cpsi * cth; dth[5] = cphi * cth * spsi; dth[8] = -cphi * sth;
+  dpsi[0] = -cth * spsi; dpsi[3] = cpsi * cth; dpsi[6] = 0;
+  dpsi[1] = -cphi * cpsi - sphi * spsi * sth; dpsi[4] = -cphi * spsi + cpsi * sphi * sth; dpsi[7] = 0;
+  dpsi[2] = cpsi * sphi - cphi * spsi * sth; dpsi[5] = sphi * spsi + cphi * cpsi * sth; dpsi[8] = 0;
+  /* matricesInnerProd(mat1, mat2) = sum_ij mat1(j,i) * mat2(i,j) */
+  double a = 0, b = 0, c = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      a += dphi[3 * j + i] * R[3 * i + j];
+      b += dth[3 * j + i] * R[3 * i + j];
+      c += dpsi[3 * j + i] * R[3 * i + j];
+    }
+  g[3] = a;
+  g[4] = b;
+  g[5] = c;
+}
+
+static double cost_f(const gicp_problem* P, const double x[6]) {
+  double f, gt[3], Rm[9];
+  eval_sums(P, x, &f, gt, Rm);
+  return f / (double)P->m;
+}
+
+static void cost_fdf(const gicp_problem* P, const double x[6], double* f, double g[6]) {
+  double fs, gt[3], Rm[9];
+  eval_sums(P, x, &fs, gt, Rm);
+  *f = fs / (double)P->m;
+  const double sc = 2.0 / (double)P->m;
+  for (int r = 0; r < 3; ++r) g[r] = gt[r] * sc;
+  for (int k = 0; k < 9; ++k) Rm[k] *= sc;
+  r_derivative(x, Rm, g);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PCL BFGS (pcl/registration/bfgs.h) = GSL vector_bfgs2 + linear_minimize                      */
+/* ------------------------------------------------------------------------------------------ */
+enum { BFGS_RUNNING = -1, BFGS_SUCCESS = 0, BFGS_NOPROGRESS = 1 };
+
+typedef struct {
+  const gicp_problem* P;
+  double rho, sigma, tau1, tau2, tau3, step_size;
+  int order, bracket_iters, section_iters;
+  int iter;
+  double f, g0norm, pnorm, delta_f, fp0;
+  double x0[6], g0[6], p[6], dx0[6], dg0[6], gradient[6];
+  /* line-function wrapper with caches */
+  double x_alpha[6], g_alpha[6], f_alpha, df_alpha;
+  double f_cache_key, df_cache_key, x_cache_key, g_cache_key;
+} bfgs_t;
+
+static double dot6(const double* a, const double* b) {
+  double s = 0;
+  for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+  return s;
+}
+static double nrm6(const double* a) { return sqrt(dot6(a, a)); }
+
+static void w_moveto(bfgs_t* B, double alpha) {
+  if (alpha == B->x_cache_key) return;
+  for (int i = 0; i < 6; ++i) B->x_alpha[i] = B->x0[i] + alpha * B->p[i];
+  B->x_cache_key = alpha;
+}
+static double w_slope(const bfgs_t* B) { return dot6(B->g_alpha, B->p); }
+static double w_f(bfgs_t* B, double alpha) {
+  if (alpha == B->f_cache_key) return B->f_alpha;
+  w_moveto(B, alpha);
+  B->f_alpha = cost_f(B->P, B->x_alpha);
+  B->f_cache_key = alpha;
+  return B->f_alpha;
+}
+static double w_df(bfgs_t* B, double alpha) {
+  if (alpha == B->df_cache_key) return B->df_alpha;
+  w_moveto(B, alpha);
+  if (alpha != B->g_cache_key) {
+    double f;
+    cost_fdf(B->P, B->x_alpha, &f, B->g_alpha); /* PCL's functor->df; f discarded */
+    B->g_cache_key = alpha;
+  }
+  B->df_alpha = w_slope(B);
+  B->df_cache_key = alpha;
+  return B->df_alpha;
+}
+static void w_fdf(bfgs_t* B, double alpha, double* f, double* df) {
+  if (alpha == B->f_cache_key && alpha == B->df_cache_key) {
+    *f = B->f_alpha;
+    *df = B->df_alpha;
+    return;
+  }
+  if (alpha == B->f_cache_key || alpha == B->df_cache_key) {
+    *f = w_f(B, alpha);
+    *df = w_df(B, alpha);
+    return;
+  }
+  w_moveto(B, alpha);
+  cost_fdf(B->P, B->x_alpha, &B->f_alpha, B->g_alpha);
+  B->f_cache_key = alpha;
+  B->g_cache_key = alpha;
+  B->df_alpha = w_slope(B);
+  B->df_cache_key = alpha;
+  *f = B->f_alpha;
+  *df = B->df_alpha;
+}
+
+static int poly_solve_quadratic(double a, double b, double c, double* x0, double* x1) {
+  if (a == 0) {
+    if (b == 0) return 0;
+    *x0 = -c / b;
+    return 1;
+  }
+  const double disc = b * b - 4 * a * c;
+  if (disc > 0) {
+    if (b == 0) {
+      const double r = sqrt(-c / a);
+      *x0 = -r;
+      *x1 = r;
+    } else {
+      const double sgnb = (b > 0 ? 1 : -1);
+      const double temp = -0.5 * (b + sgnb * sqrt(disc));
+      const double r1 = temp / a, r2 = c / temp;
+      if (r1 < r2) {
+        *x0 = r1;
+        *x1 = r2;
+      } else {
+        *x0 = r2;
+        *x1 = r1;
+      }
+    }
+    return 2;
+  } else if (disc == 0) {
+    *x0 = -0.5 * b / a;
+    *x1 = -0.5 * b / a;
+    return 2;
+  }
+  return 0;
+}
+
+static double interp_quad(double f0, double fp0, double f1, double zl, double zh) {
+  const double fl = f0 + zl * (fp0 + zl * (f1 - f0 - fp0));
+  const double fh = f0 + zh * (fp0 + zh * (f1 - f0 - fp0));
+  const double c = 2 * (f1 - f0 - fp0);
+  double zmin = zl, fmin = fl;
+  if (fh < fmin) {
+    zmin = zh;
+    fmin = fh;
+  }
+  if (c > 0) {
+    const double z = -fp0 / c;
+    if (z > zl && z < zh) {
+      const double f = f0 + z * (fp0 + z * (f1 - f0 - fp0));
+      if (f < fmin) {
+        zmin = z;
+        fmin = f;
+      }
+    }
+  }
+  return zmin;
+}
+static double cubic(double c0, double c1, double c2, double c3, double z) { return c0 + z * (c1 + z * (c2 + z * c3)); }
+static void check_extremum(double c0, double c1, double c2, double c3, double z, double* zmin, double* fmin) {
+  const double y = cubic(c0, c1, c2, c3, z);
+  if (y < *fmin) {
+    *zmin = z;
+    *fmin = y;
+  }
+}
+static double interp_cubic(double f0, double fp0, double f1, double fp1, double zl, double zh) {
+  const double eta = 3 * (f1 - f0) - 2 * fp0 - fp1;
+  const double xi = fp0 + fp1 - 2 * (f1 - f0);
+  const double c0 = f0, c1 = fp0, c2 = eta, c3 = xi;
+  double zmin = zl, fmin = cubic(c0, c1, c2, c3, zl), z0, z1;
+  check_extremum(c0, c1, c2, c3, zh, &zmin, &fmin);
+  const int n = poly_solve_quadratic(3 * c3, 2 * c2, c1, &z0, &z1);
+  if (n == 2) {
+    if (z0 > zl && z0 < zh) check_extremum(c0, c1, c2, c3, z0, &zmin, &fmin);
+    if (z1 > zl && z1 < zh) check_extremum(c0, c1, c2, c3, z1, &zmin, &fmin);
+  } else if (n == 1) {
+    if (z0 > zl && z0 < zh) check_extremum(c0, c1, c2, c3, z0, &zmin, &fmin);
+  }
+  return zmin;
+}
+static double interpolate(double a, double fa, double fpa, double b, double fb, double fpb, double xmin, double xmax,
+                          int order) {
+  double ymin = (xmin - a) / (b - a), ymax = (xmax - a) / (b - a);
+  if (ymin > ymax) {
+    const double tmp = ymin;
+    ymin = ymax;
+    ymax = tmp;
+  }
+  double y;
+  if (order > 2 && !(fpb != fpb))
+    y = interp_cubic(fa, fpa * (b - a), fb, fpb * (b - a), ymin, ymax);
+  else
+    y = interp_quad(fa, fpa * (b - a), fb, ymin, ymax);
+  return a + y * (b - a);
+}
+
+static int line_search(bfgs_t* B, double alpha1, double* alpha_new) {
+  double f0, fp0, falpha, falpha_prev, fpalpha = 0, fpalpha_prev, delta, alpha_next;
+  double alpha = alpha1, alpha_prev = 0.0;
+  double a = 0.0, b = alpha, fa, fb = 0.0, fpa, fpb = 0.0;
+  int i = 0;
+  w_fdf(B, 0.0, &f0, &fp0);
+  falpha_prev = f0;
+  fpalpha_prev = fp0;
+  fa = f0;
+  fpa = fp0;
+  while (i++ < B->bracket_iters) { /* bracketing */
+    falpha = w_f(B, alpha);
+    if (falpha > f0 + alpha * B->rho * fp0 || falpha >= falpha_prev) {
+      a = alpha_prev; fa = falpha_prev; fpa = fpalpha_prev;
+      b = alpha; fb = falpha; fpb = NAN;
+      break;
+    }
+    fpalpha = w_df(B, alpha);
+    if (fabs(fpalpha) <= -B->sigma * fp0) {
+      *alpha_new = alpha;
+      return BFGS_SUCCESS;
+    }
+    if (fpalpha >= 0) {
+      a = alpha; fa = falpha; fpa = fpalpha;
+      b = alpha_prev; fb = falpha_prev; fpb = fpalpha_prev;
+      break;
+    }
+    delta = alpha - alpha_prev;
+    {
+      const double lower = alpha + delta, upper = alpha + B->tau1 * delta;
+      alpha_next = interpolate(alpha_prev, falpha_prev, fpalpha_prev, alpha, falpha, fpalpha, lower, upper, B->order);
+    }
+    alpha_prev = alpha; falpha_prev = falpha; fpalpha_prev = fpalpha;
+    alpha = alpha_next;
+  }
+  while (i++ < B->section_iters) { /* sectioning */
+    delta = b - a;
+    {
+      const double lower = a + B->tau2 * delta, upper = b - B->tau3 * delta;
+      alpha = interpolate(a, fa, fpa, b, fb, fpb, lower, upper, B->order);
+    }
+    falpha = w_f(B, alpha);
+    if ((a - alpha) * fpa <= DBL_EPSILON) return BFGS_NOPROGRESS; /* roundoff prevents progress */
+    if (falpha > f0 + B->rho * alpha * fp0 || falpha >= fa) {
+      b = alpha; fb = falpha; fpb = NAN;
+    } else {
+      fpalpha = w_df(B, alpha);
+      if (fabs(fpalpha) <= -B->sigma * fp0) {
+        *alpha_new = alpha;
+        return BFGS_SUCCESS;
+      }
+      if (((b - a) >= 0 && fpalpha >= 0) || ((b - a) <= 0 && fpalpha <= 0)) {
+        b = a; fb = fa; fpb = fpa;
+        a = alpha; fa = falpha; fpa = fpalpha;
+      } else {
+        a = alpha; fa = falpha; fpa = fpalpha;
+      }
+    }
+  }
+  return BFGS_SUCCESS;
+}
+
+static void bfgs_init(bfgs_t* B, const gicp_problem* P, const double x[6]) {
+  memset(B, 0, sizeof(*B));
+  B->P = P;
+  B->rho = 0.01; B->sigma = 0.01; B->tau1 = 9; B->tau2 = 0.05; B->tau3 = 0.5; B->order = 3;
+  B->step_size = 1.0; B->bracket_iters = 100; B->section_iters = 100;
+  cost_fdf(P, x, &B->f, B->gradient);
+  memcpy(B->x0, x, sizeof(B->x0));
+  memcpy(B->g0, B->gradient, sizeof(B->g0));
+  B->g0norm = nrm6(B->g0);
+  for (int i = 0; i < 6; ++i) B->p[i] = B->gradient[i] * (-1.0 / B->g0norm);
+  B->pnorm = nrm6(B->p);
+  B->fp0 = -B->g0norm;
+  memcpy(B->x_alpha, B->x0, sizeof(B->x0));
+  memcpy(B->g_alpha, B->g0, sizeof(B->g0));
+  B->f_alpha = B->f;
+  B->df_alpha = w_slope(B);
+  B->f_cache_key = B->df_cache_key = B->x_cache_key = B->g_cache_key = 0.0;
+}
+
+static int bfgs_step(bfgs_t* B, double x[6]) {
+  double alpha = 0.0, alpha1;
+  const double f0 = B->f;
+  if (B->pnorm == 0.0 || B->g0norm == 0.0 || B->fp0 == 0) return BFGS_NOPROGRESS;
+  if (B->delta_f < 0) {
+    const double del = fmax(-B->delta_f, 10 * DBL_EPSILON * fabs(f0));
+    alpha1 = fmin(1.0, 2.0 * del / (-B->fp0));
+  } else
+    alpha1 = fabs(B->step_size);
+  const int status = line_search(B, alpha1, &alpha);
+  if (status != BFGS_SUCCESS) return status;
+  /* update_position */
+  {
+    double f, df;
+    w_fdf(B, alpha, &f, &df);
+    B->f = f;
+    memcpy(x, B->x_alpha, 6 * sizeof(double));
+    memcpy(B->gradient, B->g_alpha, 6 * sizeof(double));
+  }
+  B->delta_f = B->f - f0;
+  /* memoryless BFGS direction: p' = g1 - A dx - B dg */
+  for (int i = 0; i < 6; ++i) {
+    B->dx0[i] = x[i] - B->x0[i];
+    B->dg0[i] = B->gradient[i] - B->g0[i];
+  }
+  const double dxg = dot6(B->dx0, B->gradient), dgg = dot6(B->dg0, B->gradient), dxdg = dot6(B->dx0, B->dg0);
+  const double dgnorm = nrm6(B->dg0);
+  double A = 0, Bc = 0;
+  if (dxdg != 0) {
+    Bc = dxg / dxdg;
+    A = -(1.0 + dgnorm * dgnorm / dxdg) * Bc + dgg / dxdg;
+  }
+  for (int i = 0; i < 6; ++i) B->p[i] = B->gradient[i] - A * B->dx0[i] - Bc * B->dg0[i];
+  memcpy(B->g0, B->gradient, sizeof(B->g0));
+  memcpy(B->x0, x, sizeof(B->x0));
+  B->g0norm = nrm6(B->g0);
+  B->pnorm = nrm6(B->p);
+  const double pg = dot6(B->p, B->gradient);
+  const double dir = (pg >= 0.0) ? -1.0 : +1.0;
+  for (int i = 0; i < 6; ++i) B->p[i] *= dir / B->pnorm;
+  B->pnorm = nrm6(B->p);
+  B->fp0 = dot6(B->p, B->g0);
+  /* change_direction */
+  B->df_alpha = w_slope(B);
+  B->df_cache_key = 0.0;
+  /* the caches now refer to alpha = 0 of the new line: x_alpha = x0, f_alpha = f, g_alpha = g0 */
+  B->f_cache_key = 0.0;
+  B->x_cache_key = 0.0;
+  B->g_cache_key = 0.0;
+  return BFGS_SUCCESS;
+}
+
+/* estimateRigidTransformationBFGS: returns 0 ok, -1 not enough points, -2 solver did not converge */
+static int estimate_bfgs(const gicp_problem* P, float transformation[16]) {
+  if (P->m < 4) return -1;
+  double x[6];
+  x[0] = transformation[12];
+  x[1] = transformation[13];
+  x[2] = transformation[14];
+  x[3] = atan2((double)transformation[6], (double)transformation[10]);  /* (2,1), (2,2) */
+  x[4] = asin(-(double)transformation[2]);                                /* (2,0) */
+  x[5] = atan2((double)transformation[1], (double)transformation[0]);   /* (1,0), (0,0) */
+  bfgs_t B;
+  bfgs_init(&B, P, x);
+  int inner = 0, result = BFGS_RUNNING;
+  do {
+    inner++;
+    result = bfgs_step(&B, x);
+    if (result) break;
+    result = (nrm6(B.gradient) < GICP_GRADIENT_TOL) ? BFGS_SUCCESS : BFGS_RUNNING;
+  } while (result == BFGS_RUNNING && inner < GICP_MAX_INNER);
+  if (result == BFGS_NOPROGRESS || result == BFGS_SUCCESS || inner == GICP_MAX_INNER) {
+    mat4f_identity(transformation);
+    apply_state(transformation, x);
+    return 0;
+  }
+  return -2;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* computeTransformation                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, const orc_params* P, const float* guess_in,
+                   float* out_xyzw, int want_fitness, orc_result* res, orc_iter_trace* trace) {
+  memset(res, 0, sizeof(*res));
+  mat4f_identity(res->T);
+  res->fitness = NAN;
+  res->convergence_state = ORC_NOT_CONVERGED;
+  float guess[16];
+  if (guess_in) memcpy(guess, guess_in, sizeof(guess));
+  else mat4f_identity(guess);
+  if (n_t == 0 || !tgt) { /* setInputTarget refuses an empty cloud */
+    if (out_xyzw && n_s) orc_transform_cloud(src, n_s, res->T, out_xyzw);
+    return 0;
+  }
+  if (n_s < GICP_K || n_t < GICP_K) { /* computeCovariances refuses clouds smaller than k_correspondences_ */
+    if (out_xyzw && n_s) orc_transform_cloud(src, n_s, res->T, out_xyzw);
+    return 0;
+  }
+  double* Ct = (double*)malloc(n_t * 9 * sizeof(double));
+  double* Cs = (double*)malloc(n_s * 9 * sizeof(double));
+  double* maha = (double*)malloc(n_s * 9 * sizeof(double));
+  int32_t* si = (int32_t*)malloc(n_s * sizeof(int32_t));
+  int32_t* ti = (int32_t*)malloc(n_s * sizeof(int32_t));
+  orc_gicp_covariances(tgt, n_t, P->arith, Ct);
+  orc_gicp_covariances(src, n_s, P->arith, Cs);
+  void* tree = orc_kd_build(tgt, n_t, P->arith);
+  for (size_t i = 0; i < n_s; ++i) {
+    double* M = maha + 9 * i;
+    for (int e = 0; e < 9; ++e) M[e] = (e % 4 == 0) ? 1.0 : 0.0;
+  }
+  float transformation[16], previous[16];
+  mat4f_identity(transformation);
+  mat4f_identity(previous);
+  const double dist_threshold = P->max_correspondence_distance * P->max_correspondence_distance;
+  int nr = 0, converged = 0;
+  unsigned cnt = 0;
+  double mse = 0.0;
+  gicp_problem prob;
+  prob.src = src; prob.tgt = tgt; prob.si = si; prob.ti = ti; prob.maha = maha;
+  memcpy(prob.base, guess, sizeof(guess));
+  while (!converged) {
+    float TG[16];
+    mat4f_mul(transformation, guess, TG); /* query = transformation * (guess * p): applied as one float matrix */
+    double R[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += (double)transformation[k * 4 + r] * (double)guess[c * 4 + k];
+        R[3 * r + c] = s;
+      }
+    cnt = 0;
+    double d2sum = 0.0;
+    for (size_t i = 0; i < n_s; ++i) {
+      float q[4];
+      xform_point(TG, src + 4 * i, q);
+      int32_t j;
+      float d2;
+      orc_kd_nearest(tree, q, &j, &d2);
+      if (j >= 0 && (double)d2 < dist_threshold) { /* GICP: strict < */
+        const double* C1 = Cs + 9 * i;
+        const double* C2 = Ct + 9 * (size_t)j;
+        double RC[9], tmp[9];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) RC[3 * r + c] = R[3 * r] * C1[c] + R[3 * r + 1] * C1[3 + c] + R[3 * r + 2] * C1[6 + c];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c)
+            tmp[3 * r + c] = RC[3 * r] * R[3 * c] + RC[3 * r + 1] * R[3 * c + 1] + RC[3 * r + 2] * R[3 * c + 2] + C2[3 * r + c];
+        inv3(tmp, maha + 9 * i);
+        si[cnt] = (int32_t)i;
+        ti[cnt] = j;
+        d2sum += (double)d2;
+        cnt++;
+      }
+    }
+    prob.m = (int)cnt;
+    mse = cnt ? d2sum / cnt : 0.0;
+    memcpy(previous, transformation, sizeof(previous));
+    const int rc = estimate_bfgs(&prob, transformation);
+    if (rc != 0) { /* NotEnoughPoints / SolverDidntConverge: PCL catches the exception and breaks, converged_ stays false */
+      res->convergence_state = rc == -1 ? ORC_NO_CORRESPONDENCES : ORC_NOT_CONVERGED;
+      break;
+    }
+    double delta = 0.0;
+    for (int k = 0; k < 4; ++k)
+      for (int l = 0; l < 4; ++l) {
+        const double ratio = (k < 3 && l < 3) ? 1.0 / GICP_ROTATION_EPSILON : 1.0 / P->transformation_epsilon;
+        const double c_delta = ratio * fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]);
+        if (c_delta > delta) delta = c_delta;
+      }
+    if (trace) {
+      orc_iter_trace* tr = &trace[nr];
+      memset(tr, 0, sizeof(*tr));
+      for (int e = 0; e < 16; ++e) tr->Tk[e] = transformation[e];
+      for (int e = 0; e < 16; ++e) tr->final[e] = transformation[e];
+      tr->n_corr = cnt;
+      tr->mse = mse;
+    }
+    nr++;
+    if (nr >= P->max_iterations || (delta < 1 && !P->force_iterations)) {
+      converged = 1;
+      res->convergence_state = nr >= P->max_iterations ? ORC_ITERATIONS : ORC_TRANSFORM;
+      memcpy(previous, transformation, sizeof(previous));
+    }
+  }
+  /* final = previous.R * guess.R ; t = previous.t + guess.t  (PCL's own composition, not a matrix product) */
+  float final[16];
+  mat4f_identity(final);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += previous[k * 4 + r] * guess[c * 4 + k];
+      final[c * 4 + r] = s;
+    }
+    final[12 + r] = previous[12 + r] + guess[12 + r];
+  }
+  memcpy(res->T, final, sizeof(final));
+  res->converged = converged;
+  res->iterations = nr;
+  res->n_correspondences = cnt;
+  res->mse_last = mse;
+  if (out_xyzw) orc_transform_cloud(src, n_s, final, out_xyzw);
+  if (want_fitness) res->fitness = orc_fitness(src, n_s, tgt, n_t, final, DBL_MAX, ORC_NN_KDTREE, P->arith);
+  orc_kd_free(tree);
+  free(Ct); free(Cs); free(maha); free(si); free(ti);
+  return 0;
 }

@@ -401,6 +401,85 @@ static void kd_nearest(const kd_tree* t, const float* q, int32_t* idx, float* d2
   *d2 = Q.best;
 }
 
+/* ---- k nearest neighbours (GICP covariances): the k smallest (d2, index) keys, ascending ---- */
+typedef struct {
+  const kd_tree* t;
+  const float* q;
+  int k, n;
+  float* d2;     /* sorted ascending by (d2, idx) */
+  int32_t* idx;
+} kd_knn_query;
+
+static inline int knn_less(float da, int32_t ia, float db, int32_t ib) { return da < db || (da == db && ia < ib); }
+
+static inline void knn_insert(kd_knn_query* Q, float d, int32_t pi) {
+  if (Q->n == Q->k && !knn_less(d, pi, Q->d2[Q->k - 1], Q->idx[Q->k - 1])) return;
+  int pos = Q->n < Q->k ? Q->n : Q->k - 1;
+  while (pos > 0 && knn_less(d, pi, Q->d2[pos - 1], Q->idx[pos - 1])) {
+    Q->d2[pos] = Q->d2[pos - 1];
+    Q->idx[pos] = Q->idx[pos - 1];
+    --pos;
+  }
+  Q->d2[pos] = d;
+  Q->idx[pos] = pi;
+  if (Q->n < Q->k) Q->n++;
+}
+
+ORC_HOT static void kd_knn_rec(kd_knn_query* Q, int32_t id, double mindist, double offs[3]) {
+  const kd_tree* t = Q->t;
+  const kd_node* nd = &t->nodes[id];
+  if (nd->left < 0) {
+    for (int32_t i = nd->lo; i < nd->hi; ++i) {
+      const float* p = &t->packed[4 * (size_t)i];
+      float d = t->arith == ORC_ARITH_FLANN ? dist2_flann(p, Q->q) : dist2_fma(p, Q->q);
+      int32_t pi;
+      memcpy(&pi, &p[3], 4);
+      knn_insert(Q, d, pi);
+    }
+    return;
+  }
+  int axis = nd->axis;
+  double val = Q->q[axis];
+  double d_lo = val - (double)nd->divlow, d_hi = val - (double)nd->divhigh;
+  int32_t near, far;
+  double cut;
+  if (d_lo + d_hi < 0) {
+    near = nd->left;
+    far = nd->right;
+    cut = d_hi;
+  } else {
+    near = nd->right;
+    far = nd->left;
+    cut = d_lo;
+  }
+  kd_knn_rec(Q, near, mindist, offs);
+  double old = offs[axis];
+  double nd2 = mindist - old * old + cut * cut;
+  if (Q->n < Q->k || nd2 * (1.0 - 1e-6) <= (double)Q->d2[Q->k - 1]) {
+    offs[axis] = cut;
+    kd_knn_rec(Q, far, nd2, offs);
+    offs[axis] = old;
+  }
+}
+
+/* internal (oracle_internal.h): opaque kd-tree handle for gicp_oracle.c */
+void* orc_kd_build(const float* pts, size_t n, int arith) { return kd_build(pts, n, arith); }
+void orc_kd_free(void* t) { kd_free((kd_tree*)t); }
+void orc_kd_nearest(const void* t, const float* q, int32_t* idx, float* d2) { kd_nearest((const kd_tree*)t, q, idx, d2); }
+int orc_kd_knn(const void* tv, const float* q, int k, int32_t* idx, float* d2) {
+  const kd_tree* t = (const kd_tree*)tv;
+  kd_knn_query Q = {t, q, k, 0, d2, idx};
+  if (t->n == 0 || k <= 0) return 0;
+  double offs[3] = {0, 0, 0}, mind = 0.0;
+  for (int a = 0; a < 3; ++a) {
+    if (q[a] < t->bbox_lo[a]) offs[a] = (double)q[a] - (double)t->bbox_lo[a];
+    if (q[a] > t->bbox_hi[a]) offs[a] = (double)q[a] - (double)t->bbox_hi[a];
+    mind += offs[a] * offs[a];
+  }
+  kd_knn_rec(&Q, 0, mind, offs);
+  return Q.n;
+}
+
 ORC_HOT static void brute_nearest(const float* tgt, size_t n_t, const float* q, int arith, int32_t* idx, float* d2) {
   float best = INFINITY;
   int32_t bi = -1;
