@@ -13,6 +13,7 @@
 // contiguous range (9 range lookups for a 3x3x3 block); `cell_start` = int32 per cell (+1).
 #include <math.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "icp_device.h"
@@ -198,38 +199,40 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restr
   sorted[cell_start[c] + rank[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
 }
 
-// ---- correspondence search over the grid: one wave per query ------------------------------------------------------
-// A 64-lane wave owns one source point at a time (up to 16 consecutive points per wave).  For the cube of Chebyshev radius rho around the query's cell the lanes
-// fetch the (2*rho+1)^2 cell-row ranges in parallel (a row = fixed y,z and a contiguous x run = ONE range of `sorted`),
-// then the wave walks the non-empty rows two at a time (two independent coalesced 1 KiB reads in flight), 64
-// candidates per row step, 6 flops + one 64-bit compare per candidate.  Each lane keeps a (d2, original index)
-// minimum, merged by a 6-step shuffle tree; the cube radius doubles (1, 2, 4, ... r_max) until the best distance is
-// provably inside the cube.  The fused 17-term accumulation keeps one term per lane.
+// ---- correspondence search over the grid --------------------------------------------------------------------------
+// A group of W lanes (W = 64: one query per wave, the default; W = 32: two, an A/B variant that measured 25 % slower) owns one source point at a time and takes
+// `qpg` consecutive points.  For the cells around the query (first the 2x2x2 octant it leans towards, then cubes of
+// Chebyshev radius 1, 2, 4, ... r_max) the lanes fetch the cell-row ranges in parallel (a row = fixed y,z and a
+// contiguous x run = ONE range of `sorted`), then the group walks the non-empty rows two at a time (two independent
+// coalesced reads in flight), W candidates per row step, 6 flops + one 64-bit compare per candidate.  Each lane keeps a
+// (d2, original index) minimum, merged by a shuffle tree; the search stops as soon as the best distance is provably
+// inside the region searched.  The fused 17-term accumulation keeps one term per lane.
 constexpr int WQ_BLOCK = 256;  // 4 waves
-constexpr int WQ_WAVES = WQ_BLOCK / 64;
-constexpr int WQ_MAX_QPW = 16;  // queries per wave (fewer for small clouds so that the chip still fills)
+constexpr int WQ_MAX_QPG = 16;  // queries per group (fewer for small clouds so that the chip still fills)
 
-template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
-__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpw, Xform T,
+template <int W, bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
+__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpg, Xform T,
                                                            const float4* __restrict__ sorted,
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
                                                            int* __restrict__ unmatched_count) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int GROUPS = WQ_BLOCK / W;  // groups per workgroup
+  const int gl = threadIdx.x & (W - 1), grp = threadIdx.x / W;
+  const int gshift = (threadIdx.x & 63) & ~(W - 1);
 
-  // fused reduction: lane t < 17 owns term t = qsel * psel (term order of accumulate_pair)
+  // fused reduction: lane t < 17 of the group owns term t = qsel * psel (term order of accumulate_pair)
   double acc = 0.0;
   int qi = -1, pi = -1;  // which component of q / p this lane multiplies (-1 -> 1.0, qi 3 -> d2)
-  if (lane >= 1 && lane <= 3) pi = lane - 1;
-  else if (lane >= 4 && lane <= 6) qi = lane - 4;
-  else if (lane >= 7 && lane <= 15) { qi = (lane - 7) / 3; pi = (lane - 7) % 3; }
-  else if (lane == 16) qi = 3;
+  if (gl >= 1 && gl <= 3) pi = gl - 1;
+  else if (gl >= 4 && gl <= 6) qi = gl - 4;
+  else if (gl >= 7 && gl <= 15) { qi = (gl - 7) / 3; pi = (gl - 7) % 3; }
+  else if (gl == 16) qi = 3;
 
-  const int k0 = (blockIdx.x * WQ_WAVES + wave) * qpw;
-  for (int qq = 0; qq < qpw; ++qq) {
+  const int k0 = (blockIdx.x * GROUPS + grp) * qpg;
+  for (int qq = 0; qq < qpg; ++qq) {
     const int i = k0 + qq;
-    if (i >= n_s) break;  // wave-uniform
+    if (i >= n_s) break;  // uniform within the group
     const float4 s = src[i];
     float px, py, pz;
     xform_point(T, s.x, s.y, s.z, px, py, pz);
@@ -238,17 +241,17 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
     if (finite3(px, py, pz)) {
       int cx, cy, cz;
       cell_of(g, px, py, pz, cx, cy, cz);
-      found = grow_search(sorted, cell_start, g, px, py, pz, cx, cy, cz, 1, lane, b);
+      found = grow_search<W>(sorted, cell_start, g, px, py, pz, cx, cy, cz, 1, gl, gshift, b);
     }
     if constexpr (WRITE_KEYS) {
-      if (lane == 0) keys[i] = found ? b.key : kEmptyKey;
+      if (gl == 0) keys[i] = found ? b.key : kEmptyKey;
     }
     if constexpr (LIST_UNMATCHED) {
-      if (!found && lane == 0) unmatched[atomicAdd(unmatched_count, 1)] = i;
+      if (!found && gl == 0) unmatched[atomicAdd(unmatched_count, 1)] = i;
     }
     if constexpr (FUSE_REDUCE) {
       const float d2 = __uint_as_float((unsigned int)(b.key >> 32));
-      if (found && d2 <= accept_thr) {  // wave-uniform
+      if (found && d2 <= accept_thr) {  // uniform within the group
         const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)b.qx : qi == 1 ? (double)b.qy : qi == 2 ? (double)b.qz : (double)d2);
         const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
         acc += a * c;
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
     }
   }
   if constexpr (FUSE_REDUCE) {
-    __shared__ double wterm[WQ_WAVES][kReduceTerms];
-    if (lane < kReduceTerms) wterm[wave][lane] = acc;
+    __shared__ double gterm[GROUPS][kReduceTerms];
+    if (gl < kReduceTerms) gterm[grp][gl] = acc;
     __syncthreads();
     if (threadIdx.x < kReduceTerms) {
       double v = 0.0;
 #pragma unroll
-      for (int w = 0; w < WQ_WAVES; ++w) v += wterm[w][threadIdx.x];
+      for (int w = 0; w < GROUPS; ++w) v += gterm[w][threadIdx.x];
       partials[(size_t)blockIdx.x * kReduceTerms + threadIdx.x] = v;
     }
   }
@@ -307,29 +310,41 @@ hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* c
   return hipGetLastError();
 }
 
-// queries per wave: 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
-static int queries_per_wave(int n_s) {
-  int qpw = n_s / 8192;
-  if (qpw < 1) qpw = 1;
-  if (qpw > WQ_MAX_QPW) qpw = WQ_MAX_QPW;
-  return qpw;
+static int group_width() {  // lanes per query: 64 (measured faster everywhere); ICPGPU_GRID_WIDTH=32 -> two queries per wave
+  static const int w = [] { const char* v = std::getenv("ICPGPU_GRID_WIDTH"); return (v && std::atoi(v) == 32) ? 32 : 64; }();
+  return w;
+}
+
+// queries per group: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
+static int queries_per_group(int n_s) {
+  int q = n_s / (8192 * (64 / group_width()));
+  if (q < 1) q = 1;
+  if (q > WQ_MAX_QPG) q = WQ_MAX_QPG;
+  return q;
 }
 
 int grid_search_blocks(int n_s) {
-  const int per_block = WQ_WAVES * queries_per_wave(n_s);
+  const int per_block = (WQ_BLOCK / group_width()) * queries_per_group(n_s);
   return (n_s + per_block - 1) / per_block;
 }
 
-hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, const float4* sorted,
-                                 const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
-                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream) {
+hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, const float4* sorted, const int* cell_start,
+                                 const GridDesc& g, float accept_thr, unsigned long long* keys, double* partials,
+                                 int* unmatched, int* unmatched_count, hipStream_t stream) {
   const int blocks = grid_search_blocks(n_s);
   if (blocks == 0) return hipSuccess;
-  const int qpw = queries_per_wave(n_s);
+  const int qpg = queries_per_group(n_s);
+  const bool wide = group_width() == 64;
   dim3 grid(blocks), block(WQ_BLOCK);
-#define ICP_LAUNCH_WQ(K, F, U)                                                                                     \
-  hipLaunchKernelGGL((nn_wave_kernel<K, F, U>), grid, block, 0, stream, src, n_s, qpw, T, sorted, cell_start, g, accept_thr, \
-                     keys, partials, unmatched, unmatched_count)
+#define ICP_LAUNCH_WQ(K, F, U)                                                                                          \
+  do {                                                                                                                  \
+    if (wide)                                                                                                           \
+      hipLaunchKernelGGL((nn_wave_kernel<64, K, F, U>), grid, block, 0, stream, src, n_s, qpg, T, sorted, cell_start, g, \
+                         accept_thr, keys, partials, unmatched, unmatched_count);                                       \
+    else                                                                                                                \
+      hipLaunchKernelGGL((nn_wave_kernel<32, K, F, U>), grid, block, 0, stream, src, n_s, qpg, T, sorted, cell_start, g, \
+                         accept_thr, keys, partials, unmatched, unmatched_count);                                       \
+  } while (0)
   const bool k = keys != nullptr, f = partials != nullptr, u = unmatched != nullptr;
   if (k && !f && u) ICP_LAUNCH_WQ(true, false, true);
   else if (k && !f) ICP_LAUNCH_WQ(true, false, false);
