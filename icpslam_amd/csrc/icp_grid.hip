@@ -13,7 +13,6 @@
 // contiguous range (9 range lookups for a 3x3x3 block); `cell_start` = int32 per cell (+1).
 #include <math.h>
 
-#include <cstdlib>
 #include <cstring>
 
 #include "icp_device.h"
@@ -200,72 +199,99 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restr
 }
 
 // ---- correspondence search over the grid --------------------------------------------------------------------------
-// A group of W lanes (W = 64: one query per wave, the default; W = 32: two, an A/B variant that measured 25 % slower) owns one source point at a time and takes
-// `qpg` consecutive points.  For the cells around the query (first the 2x2x2 octant it leans towards, then cubes of
-// Chebyshev radius 1, 2, 4, ... r_max) the lanes fetch the cell-row ranges in parallel (a row = fixed y,z and a
-// contiguous x run = ONE range of `sorted`), then the group walks the non-empty rows two at a time (two independent
-// coalesced reads in flight), W candidates per row step, 6 flops + one 64-bit compare per candidate.  Each lane keeps a
-// (d2, original index) minimum, merged by a shuffle tree; the search stops as soon as the best distance is provably
-// inside the region searched.  The fused 17-term accumulation keeps one term per lane.
+// One wave owns up to 16 consecutive source points.
+//  * Preamble, lane-parallel: lane l works for point l/4 and octant row l%4 -- it loads the point, transforms it, bins it
+//    and fetches the (lo, len) range of one of the four cell rows of the 2x2x2 octant the point leans towards.  One
+//    coalesced read, ~60 VALU instructions and one memory round trip for all 16 points instead of one each.
+//  * Per point (wave-uniform values, pulled out of the preamble lanes with v_readlane): the wave walks the non-empty
+//    rows two at a time (two independent coalesced reads in flight), 64 candidates per step, 6 flops + one 64-bit
+//    compare per candidate; each lane keeps a (d2, original index) minimum, merged with DPP moves.  If the best
+//    distance is <= 63/64 * h/2 it is final (~91 % of the points of a converging scan pair); otherwise cubes of Chebyshev
+//    radius 1, 2, 4, ... r_max are searched until the best distance is provably inside the cube.
+//  * The fused 17-term accumulation keeps one term per lane; keys are written once per wave, coalesced.
 constexpr int WQ_BLOCK = 256;  // 4 waves
-constexpr int WQ_MAX_QPG = 16;  // queries per group (fewer for small clouds so that the chip still fills)
+constexpr int WQ_WAVES = WQ_BLOCK / 64;
+constexpr int WQ_MAX_QPW = 16;  // points per wave (fewer for small clouds so that the chip still fills)
 
-template <int W, bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
-__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpg, Xform T,
+template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
+__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpw, Xform T,
                                                            const float4* __restrict__ sorted,
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
                                                            int* __restrict__ unmatched_count) {
-  constexpr int GROUPS = WQ_BLOCK / W;  // groups per workgroup
-  const int gl = threadIdx.x & (W - 1), grp = threadIdx.x / W;
-  const int gshift = (threadIdx.x & 63) & ~(W - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = (blockIdx.x * WQ_WAVES + wave) * qpw;
 
-  // fused reduction: lane t < 17 of the group owns term t = qsel * psel (term order of accumulate_pair)
+  // fused reduction: lane t < 17 owns term t = qsel * psel (term order of accumulate_pair)
   double acc = 0.0;
   int qi = -1, pi = -1;  // which component of q / p this lane multiplies (-1 -> 1.0, qi 3 -> d2)
-  if (gl >= 1 && gl <= 3) pi = gl - 1;
-  else if (gl >= 4 && gl <= 6) qi = gl - 4;
-  else if (gl >= 7 && gl <= 15) { qi = (gl - 7) / 3; pi = (gl - 7) % 3; }
-  else if (gl == 16) qi = 3;
+  if (lane >= 1 && lane <= 3) pi = lane - 1;
+  else if (lane >= 4 && lane <= 6) qi = lane - 4;
+  else if (lane >= 7 && lane <= 15) { qi = (lane - 7) / 3; pi = (lane - 7) % 3; }
+  else if (lane == 16) qi = 3;
 
-  const int k0 = (blockIdx.x * GROUPS + grp) * qpg;
-  for (int qq = 0; qq < qpg; ++qq) {
-    const int i = k0 + qq;
-    if (i >= n_s) break;  // uniform within the group
-    const float4 s = src[i];
-    float px, py, pz;
-    xform_point(T, s.x, s.y, s.z, px, py, pz);
+  // preamble: lane -> (point lane/4, octant row lane%4)
+  float lpx = 0.f, lpy = 0.f, lpz = 0.f;
+  int lcx = 0, lcy = 0, lcz = 0, llo = 0, llen = 0;
+  bool lfin = false;
+  {
+    const int sub = lane >> 2, il = k0 + sub;
+    if (sub < qpw && il < n_s) {
+      const float4 s = src[il];
+      xform_point(T, s.x, s.y, s.z, lpx, lpy, lpz);
+      lfin = finite3(lpx, lpy, lpz);
+      if (lfin) {
+        cell_of(g, lpx, lpy, lpz, lcx, lcy, lcz);
+        octant_row(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, llo, llen);
+      }
+    }
+  }
+  const unsigned long long fin_mask = __ballot(lfin), row_mask = __ballot(llen > 0);
+  const float safe0 = 0.5f * g.h * kGridSafety, safe0_sq = safe0 * safe0;
+  unsigned long long my_key = kEmptyKey;  // lane q keeps the key of point k0 + q
+
+  for (int qq = 0; qq < qpw; ++qq) {
+    const int i = k0 + qq, l0 = qq * 4;
+    if (i >= n_s) break;
     LaneBest b{kEmptyKey, 0.f, 0.f, 0.f};
     bool found = false;
-    if (finite3(px, py, pz)) {
-      int cx, cy, cz;
-      cell_of(g, px, py, pz, cx, cy, cz);
-      found = grow_search<W>(sorted, cell_start, g, px, py, pz, cx, cy, cz, 1, gl, gshift, b);
+    const float px = readlane_f(lpx, l0), py = readlane_f(lpy, l0), pz = readlane_f(lpz, l0);
+    if ((fin_mask >> l0) & 1ull) {
+      sweep_rows(sorted, llo, llen, row_mask & (0xFull << l0), lane, px, py, pz, b);
+      found = merge_lanes(b) && __uint_as_float((unsigned int)(b.key >> 32)) <= safe0_sq;
+      if (!found) {
+        const int cx = __builtin_amdgcn_readlane(lcx, l0), cy = __builtin_amdgcn_readlane(lcy, l0),
+                  cz = __builtin_amdgcn_readlane(lcz, l0);
+        found = grow_cubes(sorted, cell_start, g, px, py, pz, cx, cy, cz, lane, b);
+      }
     }
     if constexpr (WRITE_KEYS) {
-      if (gl == 0) keys[i] = found ? b.key : kEmptyKey;
+      if (lane == qq) my_key = found ? b.key : kEmptyKey;
     }
     if constexpr (LIST_UNMATCHED) {
-      if (!found && gl == 0) unmatched[atomicAdd(unmatched_count, 1)] = i;
+      if (!found && lane == 0) unmatched[atomicAdd(unmatched_count, 1)] = i;
     }
     if constexpr (FUSE_REDUCE) {
       const float d2 = __uint_as_float((unsigned int)(b.key >> 32));
-      if (found && d2 <= accept_thr) {  // uniform within the group
+      if (found && d2 <= accept_thr) {  // wave-uniform
         const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)b.qx : qi == 1 ? (double)b.qy : qi == 2 ? (double)b.qz : (double)d2);
         const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
         acc += a * c;
       }
     }
   }
+  if constexpr (WRITE_KEYS) {
+    if (lane < qpw && k0 + lane < n_s) keys[k0 + lane] = my_key;
+  }
   if constexpr (FUSE_REDUCE) {
-    __shared__ double gterm[GROUPS][kReduceTerms];
-    if (gl < kReduceTerms) gterm[grp][gl] = acc;
+    __shared__ double wterm[WQ_WAVES][kReduceTerms];
+    if (lane < kReduceTerms) wterm[wave][lane] = acc;
     __syncthreads();
     if (threadIdx.x < kReduceTerms) {
       double v = 0.0;
 #pragma unroll
-      for (int w = 0; w < GROUPS; ++w) v += gterm[w][threadIdx.x];
+      for (int w = 0; w < WQ_WAVES; ++w) v += wterm[w][threadIdx.x];
       partials[(size_t)blockIdx.x * kReduceTerms + threadIdx.x] = v;
     }
   }
@@ -310,21 +336,16 @@ hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* c
   return hipGetLastError();
 }
 
-static int group_width() {  // lanes per query: 64 (measured faster everywhere); ICPGPU_GRID_WIDTH=32 -> two queries per wave
-  static const int w = [] { const char* v = std::getenv("ICPGPU_GRID_WIDTH"); return (v && std::atoi(v) == 32) ? 32 : 64; }();
-  return w;
-}
-
-// queries per group: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
-static int queries_per_group(int n_s) {
-  int q = n_s / (8192 * (64 / group_width()));
+// points per wave: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
+static int queries_per_wave(int n_s) {
+  int q = n_s / 8192;
   if (q < 1) q = 1;
-  if (q > WQ_MAX_QPG) q = WQ_MAX_QPG;
+  if (q > WQ_MAX_QPW) q = WQ_MAX_QPW;
   return q;
 }
 
 int grid_search_blocks(int n_s) {
-  const int per_block = (WQ_BLOCK / group_width()) * queries_per_group(n_s);
+  const int per_block = WQ_WAVES * queries_per_wave(n_s);
   return (n_s + per_block - 1) / per_block;
 }
 
@@ -333,18 +354,11 @@ hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, con
                                  int* unmatched, int* unmatched_count, hipStream_t stream) {
   const int blocks = grid_search_blocks(n_s);
   if (blocks == 0) return hipSuccess;
-  const int qpg = queries_per_group(n_s);
-  const bool wide = group_width() == 64;
+  const int qpw = queries_per_wave(n_s);
   dim3 grid(blocks), block(WQ_BLOCK);
-#define ICP_LAUNCH_WQ(K, F, U)                                                                                          \
-  do {                                                                                                                  \
-    if (wide)                                                                                                           \
-      hipLaunchKernelGGL((nn_wave_kernel<64, K, F, U>), grid, block, 0, stream, src, n_s, qpg, T, sorted, cell_start, g, \
-                         accept_thr, keys, partials, unmatched, unmatched_count);                                       \
-    else                                                                                                                \
-      hipLaunchKernelGGL((nn_wave_kernel<32, K, F, U>), grid, block, 0, stream, src, n_s, qpg, T, sorted, cell_start, g, \
-                         accept_thr, keys, partials, unmatched, unmatched_count);                                       \
-  } while (0)
+#define ICP_LAUNCH_WQ(K, F, U)                                                                                      \
+  hipLaunchKernelGGL((nn_wave_kernel<K, F, U>), grid, block, 0, stream, src, n_s, qpw, T, sorted, cell_start, g, \
+                     accept_thr, keys, partials, unmatched, unmatched_count)
   const bool k = keys != nullptr, f = partials != nullptr, u = unmatched != nullptr;
   if (k && !f && u) ICP_LAUNCH_WQ(true, false, true);
   else if (k && !f) ICP_LAUNCH_WQ(true, false, false);
