@@ -125,18 +125,27 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(const int* __restrict__ 
                                                         int* __restrict__ stats) {
   const int base = blockIdx.x * kScanItems + threadIdx.x * SCAN_PER_THREAD;
   int s = 0, m = 0;
+  unsigned long long sq = 0;  // sum of squared populations: sq / sum = the population a random POINT sees in its cell
 #pragma unroll
   for (int k = 0; k < SCAN_PER_THREAD; ++k) {
     const int v = (base + k < n) ? counts[base + k] : 0;
     s += v;
     m = max(m, v);
+    sq += (unsigned long long)v * (unsigned long long)v;
   }
   int tot;
   (void)block_exclusive_scan_256(s, &tot);
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, 64));
+  for (int off = 32; off > 0; off >>= 1) {
+    m = max(m, __shfl_down(m, off, 64));
+    sq += __shfl_down(sq, off, 64);
+  }
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-  if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], m);
+  if ((threadIdx.x & 63) == 0 && m > 0) {  // empty stretches of the table (most of it) skip the atomics
+    atomicMax(&stats[1], m);
+    atomicAdd(reinterpret_cast<unsigned long long*>(stats + 2), sq);
+  }
+  if (threadIdx.x == 0 && tot > 0) atomicAdd(&stats[4], tot);
 }
 
 __global__ __launch_bounds__(1024) void scan_top_kernel(int* __restrict__ block_sums, int nb, int* __restrict__ stats) {
@@ -316,20 +325,28 @@ void decode_bbox(const int enc[6], float lo[3], float hi[3]) {
   }
 }
 
-hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
-                             int* counts, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream) {
+hipError_t launch_grid_count(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
+                             int* counts, int* block_sums, int* d_stats, hipStream_t stream) {
   const int ncells = g.nx * g.ny * g.nz;
   hipError_t e = hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), stream);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(d_stats2, 0, 2 * sizeof(int), stream);
+  e = hipMemsetAsync(d_stats, 0, kGridStatInts * sizeof(int), stream);
   if (e != hipSuccess) return e;
   if (n > 0)
     hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, cell_of_point,
                        rank_in_cell, counts);
   const int nb = (ncells + kScanItems - 1) / kScanItems;
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats2);
-  hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nb, d_stats2);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats2);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const int* cell_of_point,
+                              const int* rank_in_cell, int* counts, int* block_sums, int* d_stats, float4* sorted,
+                              hipStream_t stream) {
+  const int ncells = g.nx * g.ny * g.nz;
+  const int nb = (ncells + kScanItems - 1) / kScanItems;
+  hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nb, d_stats);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats);
   if (n > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, cell_of_point,
                        rank_in_cell, counts, sorted);

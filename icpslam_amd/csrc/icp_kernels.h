@@ -22,6 +22,7 @@ struct Xform {
 
 // 64-bit correspondence key: (float bits of d2) << 32 | target index. For d2 >= 0 the unsigned order of
 // the key is (d2, index) lexicographic, so a u64 min merges partial searches and breaks ties on the lowest index.
+static constexpr int kGridStatInts = 6;
 static constexpr unsigned long long kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
 
 static constexpr int kReduceTerms = 17;   // n, Sp(3), Sq(3), Sqp(9), Sd2
@@ -72,8 +73,14 @@ void decode_bbox(const int enc[6], float lo[3], float hi[3]);  // host
 
 // Produces cell_start (exclusive scan of the per-cell counts, ncells+1 entries, in place in counts_then_start),
 // sorted[n_valid], d_stats2 = {n_valid, max cell population}.
-hipError_t launch_grid_build(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
-                             int* counts_then_start, int* block_sums, int* d_stats2, float4* sorted, hipStream_t stream);
+// Two halves so that the host can look at the occupancy statistics (and pick another cell size) before paying for the
+// scan and the scatter.  d_stats (kGridStatInts ints): [0] binned points (valid after finish), [1] largest cell
+// population, [2..3] u64 sum of squared populations, [4] binned points (valid after count).
+hipError_t launch_grid_count(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
+                             int* counts_then_start, int* block_sums, int* d_stats, hipStream_t stream);
+hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const int* cell_of_point,
+                              const int* rank_in_cell, int* counts_then_start, int* block_sums, int* d_stats,
+                              float4* sorted, hipStream_t stream);
 
 // Exact NN of T*src[i] among the grid's points, guaranteed whenever the NN lies within the cutoff the grid was built
 // for; otherwise the point is reported unmatched (empty key).  One wave per query (see icp_grid.hip).

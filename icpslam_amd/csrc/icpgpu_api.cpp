@@ -52,11 +52,14 @@ struct GridIndex {
   float cutoff = 0.f;        // correspondence distance it was built for
   GridDesc g{};
   int n_binned = 0, max_pop = 0;
+  double point_population = 0.0;  // cell population seen by a random point (sum c^2 / sum c)
   DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
 };
 
 constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
 constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
+constexpr double kDenseCellPopulation = 64.0;   // shrink the cells beyond this point-weighted population ...
+constexpr double kTargetCellPopulation = 18.0;  // ... down to about this one
 constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-force kernel is launch-latency bound anyway
 
 }  // namespace
@@ -77,7 +80,7 @@ struct icpgpu_ctx {
   DeviceBuf cov_src, cov_tgt, maha;
   uint64_t cov_src_version = 0, cov_tgt_version = 0;
   double* h_sums = nullptr;  // pinned (17 doubles)
-  int* h_ints = nullptr;     // pinned (8 ints: bbox / stats / counters)
+  int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
   bool have_final = false;
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
@@ -187,13 +190,23 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
   return ICPGPU_OK;
 }
 
+// cells per cutoff; 4 unless ICPGPU_GRID_DIV overrides it (tuning experiments only)
+static double grid_divisor() {
+  static const double d = [] {
+    const char* v = std::getenv("ICPGPU_GRID_DIV");
+    const double x = v ? std::atof(v) : 0.0;
+    return (x >= 1.0 && x <= 64.0) ? x : 4.0;
+  }();
+  return d;
+}
+
 struct SweepTimes {
   float nn_ms = 0.f, reduce_ms = 0.f;
 };
 
 // (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
 // cannot help (no finite point, one cell holding > kMaxCellPopulation points).
-int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, GridIndex& G) {
+int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G) {
   const int n_t = (int)cloud.n;
   const float cutoff = (float)cut;
   if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;
@@ -202,7 +215,7 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
   G.version = version;
   G.cutoff = cutoff;
 
-  int rc = ensure(c, G.ints, 8 * sizeof(int));
+  int rc = ensure(c, G.ints, (6 + kGridStatInts) * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(G.ints.ptr);
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
@@ -213,42 +226,67 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
   decode_bbox(c->h_ints, lo, hi);
   if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
 
-  // cell size: a quarter of the cutoff (cube radii 1, 2, 4, 5 cells for an unmatched point), grown until the dense
-  // table fits.  Measured on 200k-point scans: /3 and /6 are both slower (more candidates / more rows per cube).
-  double h = cut / 4.0;
-  long long nx, ny, nz;
-  for (;;) {
-    nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
-    ny = (long long)std::floor((hi[1] - lo[1]) / h) + 3;
-    nz = (long long)std::floor((hi[2] - lo[2]) / h) + 3;
-    if (nx * ny * nz <= kMaxGridCells && nx < (1 << 20) && ny < (1 << 20) && nz < (1 << 20)) break;
-    h *= 1.15;
-    if (!std::isfinite(h)) return ICPGPU_OK;
-  }
+  // Cell size: a quarter of the cutoff (cube radii 1, 2, 4, 5 cells for an unmatched point), grown until the dense
+  // table fits.  If that leaves a typical point sharing its cell with more than kDenseCellPopulation others (a submap
+  // of many scans), the cells shrink so that this population comes down to ~kTargetCellPopulation (populations of
+  // surface samples scale with h^2): the octant stage then still certifies most points (their neighbour is closer than
+  // h/2) and reads 4x fewer candidates.  Measured at 200k x 1M: 126 -> ~84 us per iteration.
+  double h = cut / grid_divisor();
   GridDesc g;
-  g.h = (float)h;
-  g.inv_h = 1.0f / g.h;
-  g.ox = lo[0] - g.h;
-  g.oy = lo[1] - g.h;
-  g.oz = lo[2] - g.h;
-  g.nx = (int)nx;
-  g.ny = (int)ny;
-  g.nz = (int)nz;
-  g.r_max = (int)std::ceil(cut / ((double)g.h * (double)kGridSafety));
-  if (g.r_max < 1) g.r_max = 1;
-  if (!std::isfinite(g.ox) || !std::isfinite(g.oy) || !std::isfinite(g.oz) || !(g.inv_h > 0.f) || !std::isfinite(g.inv_h))
-    return ICPGPU_OK;
-  const long long ncells = nx * ny * nz;
-  const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
+  long long ncells = 0;
+  for (int attempt = 0;; ++attempt) {
+    long long nx, ny, nz;
+    for (;;) {
+      nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
+      ny = (long long)std::floor((hi[1] - lo[1]) / h) + 3;
+      nz = (long long)std::floor((hi[2] - lo[2]) / h) + 3;
+      if (nx * ny * nz <= kMaxGridCells && nx < (1 << 20) && ny < (1 << 20) && nz < (1 << 20)) break;
+      h *= 1.15;
+      if (!std::isfinite(h)) return ICPGPU_OK;
+    }
+    g.h = (float)h;
+    g.inv_h = 1.0f / g.h;
+    g.ox = lo[0] - g.h;
+    g.oy = lo[1] - g.h;
+    g.oz = lo[2] - g.h;
+    g.nx = (int)nx;
+    g.ny = (int)ny;
+    g.nz = (int)nz;
+    g.r_max = (int)std::ceil(cut / ((double)g.h * (double)kGridSafety));
+    if (g.r_max < 1) g.r_max = 1;
+    if (!std::isfinite(g.ox) || !std::isfinite(g.oy) || !std::isfinite(g.oz) || !(g.inv_h > 0.f) || !std::isfinite(g.inv_h))
+      return ICPGPU_OK;
+    ncells = nx * ny * nz;
+    const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
+    if ((rc = ensure(c, G.cell_start, (size_t)(ncells + 1) * sizeof(int)))) return rc;
+    if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
+    if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
+    if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
+    HIP_TRY(c, launch_grid_count(cloud.data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
+                                 static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6,
+                                 c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, kGridStatInts * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long sumsq = 0;
+    std::memcpy(&sumsq, c->h_ints + 8, sizeof sumsq);
+    const int binned = c->h_ints[10];
+    const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
+    if (attempt == 0 && adapt && pop > kDenseCellPopulation) {
+      const double h_new = std::max(h * std::sqrt(kTargetCellPopulation / pop), cut / 16.0);
+      if (h_new < 0.9 * h) {
+        h = h_new;
+        continue;
+      }
+    }
+    G.n_binned = binned;
+    G.max_pop = c->h_ints[7];
+    G.point_population = pop;
+    break;
+  }
   if ((rc = ensure(c, G.sorted, (size_t)n_t * sizeof(float4)))) return rc;
-  if ((rc = ensure(c, G.cell_start, (size_t)(ncells + 1) * sizeof(int)))) return rc;
-  if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
-  if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
-  if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
-  HIP_TRY(c, launch_grid_build(cloud.data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
-                               static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6,
-                               static_cast<float4*>(G.sorted.ptr), c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, launch_grid_finish(cloud.data(), n_t, g, static_cast<const int*>(G.cell_of_point.ptr),
+                                static_cast<const int*>(G.rank.ptr), static_cast<int*>(G.cell_start.ptr),
+                                static_cast<int*>(G.block_sums.ptr), d_ints + 6, static_cast<float4*>(G.sorted.ptr), c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;
@@ -256,8 +294,6 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
   c->prof.grid_builds += 1;
   c->prof.grid_build_ms += ms;
   G.g = g;
-  G.n_binned = c->h_ints[6];
-  G.max_pop = c->h_ints[7];
   G.usable = G.n_binned > 0 && G.max_pop <= kMaxCellPopulation;
   return ICPGPU_OK;
 }
@@ -273,7 +309,7 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
     G.built = false;
     return ICPGPU_OK;
   }
-  return build_grid(c, c->tgt, c->tgt_version, cut, G);
+  return build_grid(c, c->tgt, c->tgt_version, cut, /*adapt=*/true, G);
 }
 
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
@@ -545,7 +581,7 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   if (cov_version == version && cov.ptr) return ICPGPU_OK;
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
-  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, G);
+  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G);
   if (rc) return rc;
   if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
   if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
@@ -790,7 +826,7 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), kReduceTerms * sizeof(double), hipHostMallocDefault)) !=
       hipSuccess)
     return bail("hipHostMalloc", e);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ints), 8 * sizeof(int), hipHostMallocDefault)) != hipSuccess)
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ints), 16 * sizeof(int), hipHostMallocDefault)) != hipSuccess)
     return bail("hipHostMalloc", e);
   if ((e = hipMalloc(&c->partials.ptr, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double))) != hipSuccess)
     return bail("hipMalloc(partials)", e);
