@@ -79,7 +79,8 @@ struct icpgpu_ctx {
   GridIndex cov_grid_src, cov_grid_tgt;
   DeviceBuf cov_src, cov_tgt, maha;
   uint64_t cov_src_version = 0, cov_tgt_version = 0;
-  double* h_sums = nullptr;  // pinned (17 doubles)
+  double* h_sums = nullptr;  // pinned, mapped (17 doubles)
+  double* h_sums_dev = nullptr;  // the device alias of h_sums: reductions store their result straight into host memory
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
   bool have_final = false;
   Mat4d final_T = mat4_identity();
@@ -346,7 +347,7 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Swe
   if (rc) return rc;
   auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
   auto* partials = static_cast<double*>(c->partials.ptr);
-  auto* d_sums = static_cast<double*>(c->sums.ptr);
+  double* d_sums = c->h_sums_dev;  // final sums land in pinned host memory: no copy engine on the per-iteration path
   const bool use_grid = grid_ready(c) && n_s > 0 && (open_range || thr <= c->grid.cutoff * c->grid.cutoff);
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   if (use_grid && !open_range) {
@@ -373,7 +374,6 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Swe
     HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, partials, d_sums, c->stream));
   }
   HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_sums, d_sums, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   SweepTimes t;
   HIP_TRY(c, hipEventElapsedTime(&t.nn_ms, c->ev[0], c->ev[1]));
@@ -823,9 +823,11 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), kReduceTerms * sizeof(double), hipHostMallocDefault)) !=
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), kReduceTerms * sizeof(double), hipHostMallocMapped)) !=
       hipSuccess)
     return bail("hipHostMalloc", e);
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_sums_dev), c->h_sums, 0)) != hipSuccess)
+    return bail("hipHostGetDevicePointer", e);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ints), 16 * sizeof(int), hipHostMallocDefault)) != hipSuccess)
     return bail("hipHostMalloc", e);
   if ((e = hipMalloc(&c->partials.ptr, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double))) != hipSuccess)
