@@ -230,7 +230,10 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
                                                            int* __restrict__ unmatched_count) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k0 = (blockIdx.x * WQ_WAVES + wave) * qpw;
+  // Point j of this wave is k0 + j * stride: consecutive points go to DIFFERENT waves.  Clouds usually arrive in firing
+  // or voxel order, where neighbours in memory are neighbours in space; waves that owned 16 consecutive points of a dense
+  // patch (hundreds of candidates each) would run 3x longer than the rest (measured), striding spreads them evenly.
+  const int k0 = blockIdx.x * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
 
   // fused reduction: lane t < 17 owns term t = qsel * psel (term order of accumulate_pair)
   double acc = 0.0;
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
   int lcx = 0, lcy = 0, lcz = 0, llo = 0, llen = 0;
   bool lfin = false;
   {
-    const int sub = lane >> 2, il = k0 + sub;
+    const int sub = lane >> 2, il = k0 + sub * stride;
     if (sub < qpw && il < n_s) {
       const float4 s = src[il];
       xform_point(T, s.x, s.y, s.z, lpx, lpy, lpz);
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
   unsigned long long my_key = kEmptyKey;  // lane q keeps the key of point k0 + q
 
   for (int qq = 0; qq < qpw; ++qq) {
-    const int i = k0 + qq, l0 = qq * 4;
+    const int i = k0 + qq * stride, l0 = qq * 4;
     if (i >= n_s) break;
     LaneBest b{kEmptyKey, 0.f, 0.f, 0.f};
     bool found = false;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
     }
   }
   if constexpr (WRITE_KEYS) {
-    if (lane < qpw && k0 + lane < n_s) keys[k0 + lane] = my_key;
+    if (lane < qpw && k0 + lane * stride < n_s) keys[k0 + lane * stride] = my_key;
   }
   if constexpr (FUSE_REDUCE) {
     __shared__ double wterm[WQ_WAVES][kReduceTerms];

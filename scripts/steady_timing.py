@@ -8,6 +8,12 @@ sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(200000,
 with Context(0) as ctx:
     for ns, nt in sizes:
         src, tgt, _ = synth.make_scan_vs_submap(ns, nt, seed=3) if nt > 300000 else synth.make_pair(ns, nt, seed=4)
+        order = os.environ.get("SRC_ORDER", "")
+        if order:  # experiment: spatially coherent source order (cells of `order` metres, z-major like a voxel filter's output)
+            c = np.floor(src[:, :3] / float(order)).astype(np.int64)
+            c -= c.min(0)
+            d = c.max(0) + 1
+            src = src[np.argsort((c[:, 2] * d[1] + c[:, 1]) * d[0] + c[:, 0], kind="stable")]
         ctx.set_params(ctx.default_params(), max_iterations=40, nn_mode=NN_GRID)
         ctx.set_source(src); ctx.set_target(tgt)
         Tc = ctx.align()["T"]
