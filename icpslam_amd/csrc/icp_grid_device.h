@@ -25,22 +25,22 @@ __device__ __forceinline__ void cell_of(const GridDesc& g, float x, float y, flo
 
 // ---- wave-level primitives ------------------------------------------------------------------------------------------
 // DPP (data-parallel primitive) lane moves stay inside the VALU: no LDS round trip like ds_bpermute, which is what
-// __shfl_xor compiles to.  Controls (GFX9 encoding): quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140,
-// row_bcast15 0x142 (lane 15 of every row -> the next row), row_bcast31 0x143 (lane 31 -> rows 2, 3).
-template <int CTRL, int ROW_MASK>
+// __shfl_xor compiles to, and the compiler folds them into the consuming v_min (one instruction per step).
+// Controls (GFX9 encoding): quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140.
+template <int CTRL>
 __device__ __forceinline__ unsigned int dpp_move(unsigned int v) {
-  return (unsigned int)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 
 // minimum of v over the 64 lanes, returned wave-uniform (an SGPR)
 __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
-  v = min(v, dpp_move<0xB1, 0xF>(v));   // quad_perm [1,0,3,2]: lane ^ 1
-  v = min(v, dpp_move<0x4E, 0xF>(v));   // quad_perm [2,3,0,1]: lane ^ 2
-  v = min(v, dpp_move<0x141, 0xF>(v));  // row_half_mirror: the other quad of each 8
-  v = min(v, dpp_move<0x140, 0xF>(v));  // row_mirror: the other half of each 16 -> every lane holds its row's minimum
-  v = min(v, dpp_move<0x142, 0xA>(v));  // row_bcast15 into rows 1 and 3
-  v = min(v, dpp_move<0x143, 0xC>(v));  // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave minimum
-  return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+  v = min(v, dpp_move<0xB1>(v));   // quad_perm [1,0,3,2]: lane ^ 1
+  v = min(v, dpp_move<0x4E>(v));   // quad_perm [2,3,0,1]: lane ^ 2
+  v = min(v, dpp_move<0x141>(v));  // row_half_mirror: the other quad of each 8
+  v = min(v, dpp_move<0x140>(v));  // row_mirror: the other half of each 16 -> every lane holds its row's minimum
+  const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16),
+                     r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));  // scalar unit
 }
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {  // lane must be wave-uniform
@@ -54,10 +54,10 @@ struct LaneBest {
 
 // Both points are finite here (non-finite targets are never binned, non-finite queries never search), so d2 is a finite
 // float or +inf, never NaN: its bit pattern orders like its value and no NaN guard is needed.
-__device__ __forceinline__ void consider(const float4& q, float px, float py, float pz, bool valid, LaneBest& b) {
+__device__ __forceinline__ void consider(const float4& q, float px, float py, float pz, LaneBest& b) {
   const float d = dist2(q.x, q.y, q.z, px, py, pz);
   const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
-  if (valid && key < b.key) {
+  if (key < b.key) {
     b.key = key;
     b.qx = q.x;
     b.qy = q.y;
@@ -89,34 +89,32 @@ __device__ __forceinline__ bool merge_lanes(LaneBest& b) {
 }
 
 // Walk the cell rows whose (lo, len) sit in the lanes named by `mask` (a row = fixed y,z and a contiguous x run = ONE
-// range of `sorted`), two rows per step.  Row bounds are read with v_readlane (the lane index is wave-uniform), both
-// loads are issued unconditionally at clamped positions so that they are in flight together, and lanes past the end of
-// a row are masked out in the comparison instead.
+// range of `sorted`), two rows per step.  Row bounds are read with v_readlane (the lane index is wave-uniform), so a
+// row's base address is scalar.  Lanes past the end of a row re-read its last entry (same cache line, no extra traffic)
+// instead of being masked: evaluating a target point twice cannot change an exact minimum, so there is no per-lane
+// bounds test, and both loads of a step are in flight together.
 __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, int lo, int len, unsigned long long mask,
-                                           int lane, float px, float py, float pz, LaneBest& b) {
+                                           unsigned int lane, float px, float py, float pz, LaneBest& b) {
   while (mask) {
     const int ra = __ffsll((long long)mask) - 1;
     mask &= mask - 1;
     const int alo = __builtin_amdgcn_readlane(lo, ra), alen = __builtin_amdgcn_readlane(len, ra);
-    int blo = alo, blen = 0;
+    int blo = alo, blen = 1;  // no second row: row a's first entry again
     if (mask) {
       const int rb = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       blo = __builtin_amdgcn_readlane(lo, rb);
       blen = __builtin_amdgcn_readlane(len, rb);
     }
-    const float4 qa = sorted[alo + min(lane, alen - 1)];
-    const float4 qb = sorted[blo + min(lane, max(blen - 1, 0))];
-    consider(qa, px, py, pz, lane < alen, b);
-    consider(qb, px, py, pz, lane < blen, b);
-    for (int k = 64; k < alen; k += 64) {  // long rows (dense cells close to the sensor)
-      const float4 q = sorted[alo + min(k + lane, alen - 1)];
-      consider(q, px, py, pz, k + lane < alen, b);
-    }
-    for (int k = 64; k < blen; k += 64) {
-      const float4 q = sorted[blo + min(k + lane, blen - 1)];
-      consider(q, px, py, pz, k + lane < blen, b);
-    }
+    const float4* __restrict__ pa = sorted + alo;
+    const float4* __restrict__ pb = sorted + blo;
+    const float4 qa = pa[min(lane, (unsigned int)(alen - 1))];
+    const float4 qb = pb[min(lane, (unsigned int)(blen - 1))];
+    consider(qa, px, py, pz, b);
+    consider(qb, px, py, pz, b);
+    for (int k = 64; k < alen; k += 64)  // long rows (dense cells near the sensor)
+      consider((pa + k)[min(lane, (unsigned int)(alen - 1 - k))], px, py, pz, b);
+    for (int k = 64; k < blen; k += 64) consider((pb + k)[min(lane, (unsigned int)(blen - 1 - k))], px, py, pz, b);
   }
 }
 
@@ -141,13 +139,13 @@ __device__ __forceinline__ void octant_row(const int* __restrict__ cell_start, c
 // inside the cube; px..cz are wave-uniform.  On return b holds the wave-uniform winner.
 __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                            const GridDesc& g, float px, float py, float pz, int cx, int cy, int cz,
-                                           int lane, LaneBest& b) {
+                                           unsigned int lane, LaneBest& b) {
   for (int rho = 1;; rho = min(2 * rho, g.r_max)) {
     const int side = 2 * rho + 1, nrows = side * side;
     const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
     const float inv_side = 1.0f / (float)side;
     for (int rb = 0; rb < nrows; rb += 64) {
-      const int r = rb + lane;  // lane -> one cell row of the cube; (y, z) by an exact float reciprocal
+      const int r = rb + (int)lane;  // lane -> one cell row of the cube; (y, z) by an exact float reciprocal
       const int zr = (int)(((float)r + 0.5f) * inv_side), yr = r - zr * side;
       const int yy = cy + yr - rho, zz = cz + zr - rho;
       int lo = 0, len = 0;
