@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
         const int yy = cy + yr - rho, zz = cz + zr - rho;
         int lo = 0, len = 0;
         if (r < nrows && x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-          const int row = (zz * g.ny + yy) * g.nx;
+          const int row = zz * g.sz + yy * g.sy;
           lo = cell_start[row + x0];
           len = cell_start[row + x1 + 1] - lo;
         }

@@ -13,6 +13,7 @@
 // contiguous range (9 range lookups for a 3x3x3 block); `cell_start` = int32 per cell (+1).
 #include <math.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "icp_device.h"
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restric
   if (finite3(p.x, p.y, p.z)) {
     int cx, cy, cz;
     cell_of(g, p.x, p.y, p.z, cx, cy, cz);
-    if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) c = (cz * g.ny + cy) * g.nx + cx;
+    if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) c = cz * g.sz + cy * g.sy + cx;
   }
   cell_of_point[i] = c;
   rank[i] = c >= 0 ? atomicAdd(&counts[c], 1) : 0;
@@ -218,12 +219,13 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restr
 //    distance is <= 63/64 * h/2 it is final (~91 % of the points of a converging scan pair); otherwise cubes of Chebyshev
 //    radius 1, 2, 4, ... r_max are searched until the best distance is provably inside the cube.
 //  * The fused 17-term accumulation keeps one term per lane; keys are written once per wave, coalesced.
-constexpr int WQ_BLOCK = 256;  // 4 waves
-constexpr int WQ_WAVES = WQ_BLOCK / 64;
 constexpr int WQ_MAX_QPW = 16;  // points per wave (fewer for small clouds so that the chip still fills)
 
+constexpr int WQ_WAVES = 4;
+constexpr int WQ_BLOCK = WQ_WAVES * 64;
+
 template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
-__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpw, Xform T,
+__global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
                                                            const float4* __restrict__ sorted,
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
@@ -233,7 +235,10 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
   // Point j of this wave is k0 + j * stride: consecutive points go to DIFFERENT waves.  Clouds usually arrive in firing
   // or voxel order, where neighbours in memory are neighbours in space; waves that owned 16 consecutive points of a dense
   // patch (hundreds of candidates each) would run 3x longer than the rest (measured), striding spreads them evenly.
-  const int k0 = blockIdx.x * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
+  // Workgroups go round-robin to the 8 XCDs (each with a private L2).  When the source is in cell order, XCD x gets the
+  // x-th eighth of it (gridDim.x is a multiple of 8): its L2 then only ever sees that part of the target.
+  const int lb = xcd_map ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int k0 = lb * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
 
   // fused reduction: lane t < 17 owns term t = qsel * psel (term order of accumulate_pair)
   double acc = 0.0;
@@ -366,18 +371,19 @@ static int queries_per_wave(int n_s) {
 
 int grid_search_blocks(int n_s) {
   const int per_block = WQ_WAVES * queries_per_wave(n_s);
-  return (n_s + per_block - 1) / per_block;
+  const int nb = (n_s + per_block - 1) / per_block;
+  return (nb + 7) & ~7;  // a multiple of the 8 XCDs
 }
 
-hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, const float4* sorted, const int* cell_start,
-                                 const GridDesc& g, float accept_thr, unsigned long long* keys, double* partials,
-                                 int* unmatched, int* unmatched_count, hipStream_t stream) {
+hipError_t launch_nn_grid_search(const float4* src, int n_s, bool src_in_cell_order, const Xform& T, const float4* sorted,
+                                 const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
+                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream) {
+  if (n_s <= 0) return hipSuccess;
   const int blocks = grid_search_blocks(n_s);
-  if (blocks == 0) return hipSuccess;
-  const int qpw = queries_per_wave(n_s);
+  const int qpw = queries_per_wave(n_s), xm = src_in_cell_order ? 1 : 0;
   dim3 grid(blocks), block(WQ_BLOCK);
-#define ICP_LAUNCH_WQ(K, F, U)                                                                                      \
-  hipLaunchKernelGGL((nn_wave_kernel<K, F, U>), grid, block, 0, stream, src, n_s, qpw, T, sorted, cell_start, g, \
+#define ICP_LAUNCH_WQ(K, F, U)                                                                                        \
+  hipLaunchKernelGGL((nn_wave_kernel<K, F, U>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, g, \
                      accept_thr, keys, partials, unmatched, unmatched_count)
   const bool k = keys != nullptr, f = partials != nullptr, u = unmatched != nullptr;
   if (k && !f && u) ICP_LAUNCH_WQ(true, false, true);

@@ -129,7 +129,7 @@ __device__ __forceinline__ void octant_row(const int* __restrict__ cell_start, c
   lo = 0;
   len = 0;
   if (x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-    const int row = (zz * g.ny + yy) * g.nx;
+    const int row = zz * g.sz + yy * g.sy;
     lo = cell_start[row + x0];
     len = cell_start[row + x1 + 1] - lo;
   }
@@ -150,7 +150,7 @@ __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, co
       const int yy = cy + yr - rho, zz = cz + zr - rho;
       int lo = 0, len = 0;
       if (r < nrows && x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-        const int row = (zz * g.ny + yy) * g.nx;
+        const int row = zz * g.sz + yy * g.sy;
         lo = cell_start[row + x0];
         len = cell_start[row + x1 + 1] - lo;
       }

@@ -62,6 +62,8 @@ struct GridDesc {
   float ox, oy, oz;  // origin (min corner)
   float h, inv_h;    // cell size
   int nx, ny, nz;
+  int sy, sz;        // cell index = cz * sz + cy * sy + cx: x is always the fastest axis (a cell row = one x run); the
+                     // thinner of y / z comes next, so that the layers of a flat scene stay close together in memory
   int r_max;         // last cube radius searched: r_max * h * kGridSafety >= cutoff distance
 };
 static constexpr float kGridSafety = 0.984375f;  // 63/64: covers the rounding of the float binning
@@ -87,9 +89,9 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 //   keys      : optional (nullptr to skip) 8-byte keys with ORIGINAL target indices
 //   partials  : optional fused a3+a4 reduction: grid_search_blocks(n_s) partials of 17 doubles
 //   unmatched : optional compaction of unmatched source indices (count at unmatched_count[0], pre-zeroed)
-hipError_t launch_nn_grid_search(const float4* src, int n_s, const Xform& T, const float4* sorted, const int* cell_start,
-                                 const GridDesc& g, float accept_thr, unsigned long long* keys, double* partials,
-                                 int* unmatched, int* unmatched_count, hipStream_t stream);
+hipError_t launch_nn_grid_search(const float4* src, int n_s, bool src_in_cell_order, const Xform& T, const float4* sorted,
+                                 const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
+                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream);
 int grid_search_blocks(int n_s);
 
 // brute force for a list of source indices (fallback for points the grid could not match); keys pre-filled empty.

@@ -10,7 +10,11 @@ with Context(0) as ctx:
         src, tgt, _ = synth.make_scan_vs_submap(ns, nt, seed=3) if nt > 300000 else synth.make_pair(ns, nt, seed=4)
         order = os.environ.get("SRC_ORDER", "")
         if order:  # experiment: spatially coherent source order (cells of `order` metres, z-major like a voxel filter's output)
-            c = np.floor(src[:, :3] / float(order)).astype(np.int64)
+            off = src[:, :3].min(0) - float(order) if os.environ.get("SRC_PHASE") else 0.0
+            c = np.floor((src[:, :3] - off) / float(order)).astype(np.int64)
+            if os.environ.get("SRC_INNER") == "x":  # within a cell: ascending x instead of the (shuffled) input order
+                src = src[np.argsort(src[:, 0], kind="stable")]
+                c = np.floor((src[:, :3] - off) / float(order)).astype(np.int64)
             c -= c.min(0)
             d = c.max(0) + 1
             src = src[np.argsort((c[:, 2] * d[1] + c[:, 1]) * d[0] + c[:, 0], kind="stable")]

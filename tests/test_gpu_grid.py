@@ -124,3 +124,34 @@ def test_promote_source_to_target_sequence(ctx):
         assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"]
         assert np.abs(got["T"] - ref["T"]).max() <= 1e-4
         ctx.promote_source_to_target()
+
+
+def test_cell_ordered_source_same_answer_and_grid_follows_promote(ctx):
+    """>= 100k-point sources are iterated in cell order (icpgpu_api.cpp ensure_source_order): the transform must not
+    depend on it, non-finite source points must stay harmless, and after promote_source_to_target the source's grid
+    serves as the target's (each cloud is binned once)."""
+    src, tgt, _ = synth.make_pair(120000, 120000, seed=21)
+    src = src.copy()
+    src[7, :3] = np.nan
+    src[8, :3] = np.inf
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=12))
+    ctx.set_params(ctx.default_params(), max_iterations=12, nn_mode=NN_GRID)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    ctx.profile_reset()
+    r = ctx.align(want_fitness=True)
+    p = ctx.profile()
+    assert p.grid_builds == 2                                  # target + source
+    assert r["iterations"] == ref["iterations"] and r["n_corr"] == ref["n_corr"]
+    assert np.abs(r["T"][:3, :3] - ref["T"][:3, :3]).max() <= 1e-4      # BASELINE tolerance (R)
+    assert np.linalg.norm(r["T"][:3, 3] - ref["T"][:3, 3]) <= 1e-3      # BASELINE tolerance (t), metres
+    ctx.promote_source_to_target()
+    src2, _, _ = synth.make_pair(120000, 16, seed=22)
+    ctx.set_source(src2)
+    ctx.profile_reset()
+    r2 = ctx.align()
+    assert ctx.profile().grid_builds == 1                      # only the new source; the target's grid came along
+    ref2 = oracle.icp_align(src2, src, oracle.default_params(max_iterations=12))
+    assert r2["iterations"] == ref2["iterations"] and r2["n_corr"] == ref2["n_corr"]
+    assert np.abs(r2["T"][:3, :3] - ref2["T"][:3, :3]).max() <= 1e-4
+    assert np.linalg.norm(r2["T"][:3, 3] - ref2["T"][:3, 3]) <= 1e-3
