@@ -333,7 +333,7 @@ hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials);
-  return launch_reduce_final(partials, blocks, sums_out, stream);
+  return launch_reduce_final(partials, blocks, sums_out, nullptr, 0, stream);
 }
 
 }  // namespace icpgpu

@@ -43,9 +43,13 @@ hipError_t launch_nn_brute(const float4* src, int n_s, const float4* tgt, int n_
 
 // partials: [blocks][17] doubles, sums_out: 17 doubles (device). Deterministic (fixed order) two-stage reduction.
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
-                         float d2_threshold, double* partials, double* sums_out, hipStream_t stream);
+                         float d2_threshold, double* partials, double* sums_out, unsigned long long* flags,
+                         unsigned long long seq, hipStream_t stream);
 
-hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, hipStream_t stream);
+// sums_out may be host-mapped pinned memory.  flags (nullable, 17 entries, host-mapped): every term's workgroup stores
+// `seq` there after its sum (system-scope release), so the host can poll instead of synchronising the stream.
+hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, unsigned long long* flags,
+                               unsigned long long seq, hipStream_t stream);
 
 hipError_t launch_transform(const float4* src, int n_s, const Xform& T, float4* out, hipStream_t stream);
 

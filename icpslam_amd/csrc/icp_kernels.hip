@@ -212,8 +212,11 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
 
 // stage 2: one 256-thread workgroup per term; thread t adds partials t, t+256, ... in that order (independent loads),
 // then a fixed shuffle + LDS tree -> bitwise reproducible run to run.
+// `flags` (optional) lets a host that polls pinned memory see the result without a stream synchronisation: each
+// workgroup publishes `seq` after its sum, with system-scope release ordering.
 __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks,
-                                                           double* __restrict__ sums) {
+                                                           double* __restrict__ sums, unsigned long long* flags,
+                                                           unsigned long long seq) {
   const int k = blockIdx.x;
   double v = 0.0;
   for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[(size_t)b * kReduceTerms + k];
@@ -221,7 +224,10 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
   __shared__ double w[4];
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) sums[k] = (w[0] + w[1]) + (w[2] + w[3]);
+  if (threadIdx.x == 0) {
+    sums[k] = (w[0] + w[1]) + (w[2] + w[3]);
+    if (flags) __hip_atomic_store(&flags[k], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // a6: output cloud. 32 B/point of HBM traffic, float4 in / float4 out.
@@ -292,16 +298,19 @@ hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, 
 }
 
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
-                         float thr, double* partials, double* sums_out, hipStream_t stream) {
+                         float thr, double* partials, double* sums_out, unsigned long long* flags, unsigned long long seq,
+                         hipStream_t stream) {
   int blocks = (n_s + RED_BLOCK - 1) / RED_BLOCK;
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
-  return launch_reduce_final(partials, blocks, sums_out, stream);
+  return launch_reduce_final(partials, blocks, sums_out, flags, seq, stream);
 }
 
-hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(256), 0, stream, partials, n_blocks, sums_out);
+hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, unsigned long long* flags,
+                               unsigned long long seq, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(256), 0, stream, partials, n_blocks, sums_out, flags,
+                     seq);
   return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial c
 constexpr double kDenseCellPopulation = 64.0;   // shrink the cells beyond this point-weighted population ...
 constexpr double kTargetCellPopulation = 18.0;  // ... down to about this one
 constexpr size_t kOrderSourceMin = 100000;      // AUTO: order the source by cell from this size on (see ensure_source_order)
+constexpr int kEventRing = 64;                   // sweeps whose kernel timing may be outstanding
 constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-force kernel is launch-latency bound anyway
 
 }  // namespace
@@ -81,8 +82,19 @@ struct icpgpu_ctx {
   GridIndex cov_grid_src, cov_grid_tgt;
   DeviceBuf cov_src, cov_tgt, maha;
   uint64_t cov_src_version = 0, cov_tgt_version = 0;
-  double* h_sums = nullptr;  // pinned, mapped (17 doubles)
-  double* h_sums_dev = nullptr;  // the device alias of h_sums: reductions store their result straight into host memory
+  // Per-iteration result mailbox in pinned, mapped host memory: 17 sums + 17 sequence flags.  The final reduction
+  // stores straight into it and the host polls the flags -- no copy engine and no stream synchronisation (whose wake-up
+  // costs 20-70 us depending on how the process set up the runtime) on the iteration path.
+  double* h_sums = nullptr;
+  double* h_sums_dev = nullptr;              // device alias of h_sums
+  volatile unsigned long long* h_flags = nullptr;
+  unsigned long long* h_flags_dev = nullptr;  // device alias of h_flags
+  unsigned long long sums_seq = 0;
+  // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
+  std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
+  struct PendingSweep { int slot; bool grid; };
+  std::vector<PendingSweep> pending;
+  double dev_ms_accum = 0.0;
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
   bool have_final = false;
   Mat4d final_T = mat4_identity();
@@ -202,10 +214,6 @@ static double grid_divisor() {
   }();
   return d;
 }
-
-struct SweepTimes {
-  float nn_ms = 0.f, reduce_ms = 0.f;
-};
 
 // (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
 // cannot help (no finite point, one cell holding > kMaxCellPopulation points).
@@ -372,19 +380,64 @@ bool source_ordered(const icpgpu_ctx* c) {
   return c->src_grid.built && c->src_grid.usable && c->src_grid.version == c->src_version && c->src_grid.n_binned > 0;
 }
 
-// One NN sweep + reduction with transform T; leaves the 17 sums in c->h_sums. Synchronises the stream.
-//   open_range = false : ICP iteration; correspondences beyond thr are rejected, so the grid search (cut at the
-//                        correspondence distance) is complete by itself and the reduction is fused into it
-//   open_range = true  : fitness; every point needs its true NN -> grid + brute-force completion + reduce kernel
-int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, SweepTimes* times) {
+// Read back the kernel timings of the sweeps issued since the last call (one stream synchronisation for all of them).
+int resolve_sweep_timings(icpgpu_ctx* c) {
+  if (c->pending.empty()) return ICPGPU_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (const auto& p : c->pending) {
+    float nn_ms = 0.f, red_ms = 0.f;
+    hipEvent_t* e = &c->ev_ring[(size_t)p.slot * 3];
+    HIP_TRY(c, hipEventElapsedTime(&nn_ms, e[0], e[1]));
+    HIP_TRY(c, hipEventElapsedTime(&red_ms, e[1], e[2]));
+    if (p.grid) c->prof.grid_ms += nn_ms;
+    else c->prof.nn_ms += nn_ms;
+    c->prof.reduce_ms += red_ms;
+    c->dev_ms_accum += (double)nn_ms + (double)red_ms;
+  }
+  c->pending.clear();
+  return ICPGPU_OK;
+}
+
+// Spin on the mailbox flags until every term of sweep `seq` has landed.  The stream is queried now and then so that a
+// faulted kernel turns into an error instead of an endless wait.
+int wait_sums(icpgpu_ctx* c, unsigned long long seq) {
+  for (unsigned spins = 1;; ++spins) {
+    bool all = true;
+    for (int k = 0; k < kReduceTerms; ++k) all = all && (c->h_flags[k] == seq);
+    if (all) break;
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {  // everything retired: the flags must be there on the next look
+        bool ok = true;
+        for (int k = 0; k < kReduceTerms; ++k) ok = ok && (c->h_flags[k] == seq);
+        if (ok) break;
+        return fail(c, ICPGPU_ERR_HIP, "reduction finished without publishing its result");
+      }
+      if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ICPGPU_OK;
+}
+
+// One NN sweep + reduction with transform T; leaves the 17 sums in c->h_sums.  Waits for the result (by polling the
+// mailbox), not for the stream.
+int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   int rc = ensure(c, c->keys, (size_t)(n_s ? n_s : 1) * sizeof(unsigned long long));
   if (rc) return rc;
   auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
   auto* partials = static_cast<double*>(c->partials.ptr);
-  double* d_sums = c->h_sums_dev;  // final sums land in pinned host memory: no copy engine on the per-iteration path
+  double* d_sums = c->h_sums_dev;
   const bool use_grid = grid_ready(c) && n_s > 0 && (open_range || thr <= c->grid.cutoff * c->grid.cutoff);
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if ((int)c->pending.size() >= kEventRing && (rc = resolve_sweep_timings(c))) return rc;
+  const int slot = (int)c->pending.size();
+  hipEvent_t* ev = &c->ev_ring[(size_t)slot * 3];
+  const unsigned long long seq = ++c->sums_seq;
+  HIP_TRY(c, hipEventRecord(ev[0], c->stream));
   if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
     const bool ordered = source_ordered(c);
@@ -396,42 +449,35 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Swe
     HIP_TRY(c, launch_nn_grid_search(src_pts, n_q, ordered, T, static_cast<const float4*>(c->grid.sorted.ptr),
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
                                      nullptr, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    HIP_TRY(c, launch_reduce_final(partials, blocks, d_sums, c->stream));
+    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    HIP_TRY(c, launch_reduce_final(partials, blocks, d_sums, c->h_flags_dev, seq, c->stream));
   } else {
     if (use_grid) {
       if ((rc = nn_keys_grid(c, T, keys))) return rc;
     } else {
       const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
       if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-      HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+      HIP_TRY(c, hipEventRecord(ev[0], c->stream));
       HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, T, plan, keys, c->stream));
     }
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, partials, d_sums, c->stream));
+    HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
   }
-  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  SweepTimes t;
-  HIP_TRY(c, hipEventElapsedTime(&t.nn_ms, c->ev[0], c->ev[1]));
-  HIP_TRY(c, hipEventElapsedTime(&t.reduce_ms, c->ev[1], c->ev[2]));
+  HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+  c->pending.push_back({slot, use_grid});
   if (use_grid) {
     c->prof.grid_launches += 1;
-    c->prof.grid_ms += t.nn_ms;
     c->prof.grid_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + (open_range ? 8ull * (uint64_t)n_s : 136ull * (uint64_t)grid_search_blocks(n_s));
   } else {
     c->prof.nn_launches += (n_s > 0);
-    c->prof.nn_ms += t.nn_ms;
     c->prof.nn_pairs += (uint64_t)n_s * (uint64_t)n_t;
     c->prof.nn_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + 8ull * (uint64_t)n_s;
   }
   c->prof.reduce_launches += 1;
-  c->prof.reduce_ms += t.reduce_ms;
   c->prof.reduce_bytes += (use_grid && !open_range) ? 136ull * (uint64_t)grid_search_blocks(n_s) : 40ull * (uint64_t)n_s + 136;
-  if (times) *times = t;
-  return ICPGPU_OK;
+  return wait_sums(c, seq);
 }
 
 int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {
@@ -516,7 +562,11 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   const auto t_start = std::chrono::steady_clock::now();
   init_result(res);
   c->prof.aligns += 1;
-  double dev_ms = 0.0;
+  {
+    int rc = resolve_sweep_timings(c);
+    if (rc) return rc;
+    c->dev_ms_accum = 0.0;
+  }
 
   Mat4d final_T = mat4_identity();
   if (guess)
@@ -548,10 +598,8 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   unsigned n_corr = 0;
   double mse = 0.0;
   for (;;) {
-    SweepTimes st;
-    int rc = nn_and_reduce(c, to_xform(final_T), thr, false, &st);
+    int rc = nn_and_reduce(c, to_xform(final_T), thr, false);
     if (rc) return rc;
-    dev_ms += st.nn_ms + st.reduce_ms;
     const double* sums = c->h_sums;
     n_corr = (unsigned)sums[0];
     Mat4d Tk;
@@ -582,15 +630,14 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
 
   const Xform Tf = to_xform(final_T);
   if (want_fitness) {
-    SweepTimes st;
-    int rc = nn_and_reduce(c, Tf, FLT_MAX, true, &st);
+    int rc = nn_and_reduce(c, Tf, FLT_MAX, true);
     if (rc) return rc;
-    dev_ms += st.nn_ms + st.reduce_ms;
     res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   }
   int rc = write_output_cloud(c, Tf, out_xyzw);
   if (rc) return rc;
-  res->t_device_ms = dev_ms;
+  if ((rc = resolve_sweep_timings(c))) return rc;
+  res->t_device_ms = c->dev_ms_accum;
   res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   return ICPGPU_OK;
 }
@@ -797,9 +844,11 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   res->mse_last = mse;
   const Xform Tf = xform_from_f16(fin);
   if (want_fitness) {
-    SweepTimes st;
-    if ((rc = nn_and_reduce(c, Tf, FLT_MAX, true, &st))) return rc;
-    dev_ms += st.nn_ms + st.reduce_ms;
+    if ((rc = resolve_sweep_timings(c))) return rc;
+    c->dev_ms_accum = 0.0;
+    if ((rc = nn_and_reduce(c, Tf, FLT_MAX, true))) return rc;
+    if ((rc = resolve_sweep_timings(c))) return rc;
+    dev_ms += c->dev_ms_accum;
     res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   }
   if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
@@ -863,11 +912,19 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), kReduceTerms * sizeof(double), hipHostMallocMapped)) !=
+  // mailbox: 17 sums then 17 flags (kept apart by 64 B so that the flags sit in their own cache lines)
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + kReduceTerms) * sizeof(double), hipHostMallocMapped)) !=
       hipSuccess)
     return bail("hipHostMalloc", e);
+  std::memset(c->h_sums, 0, (24 + kReduceTerms) * sizeof(double));
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_sums_dev), c->h_sums, 0)) != hipSuccess)
     return bail("hipHostGetDevicePointer", e);
+  c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
+  c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
+  c->ev_ring.assign((size_t)kEventRing * 3, nullptr);
+  for (auto& ev : c->ev_ring)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  c->pending.reserve(kEventRing);
   if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ints), 16 * sizeof(int), hipHostMallocDefault)) != hipSuccess)
     return bail("hipHostMalloc", e);
   if ((e = hipMalloc(&c->partials.ptr, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double))) != hipSuccess)
@@ -927,6 +984,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_ring)
     if (ev) (void)hipEventDestroy(ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1013,7 +1072,7 @@ int icpgpu_fitness(icpgpu_ctx* c, double max_range, double* out) {
   const Mat4d T = c->have_final ? c->final_T : mat4_identity();
   int rc = ensure_grid(c, threshold_from(c->params.max_correspondence_distance * c->params.max_correspondence_distance));
   if (rc) return rc;
-  rc = nn_and_reduce(c, to_xform(T), threshold_from(max_range), true, nullptr);
+  rc = nn_and_reduce(c, to_xform(T), threshold_from(max_range), true);
   if (rc) return rc;
   *out = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   return ICPGPU_OK;
@@ -1136,7 +1195,7 @@ int icpgpu_reduce(icpgpu_ctx* c, const float* T, double max_dist, double sums[17
   }
   HIP_TRY(c, launch_reduce(c->src.data(), (int)c->src.n, c->tgt.data(), static_cast<unsigned long long*>(c->keys.ptr),
                            to_xform(T), threshold_from(max_dist * max_dist), static_cast<double*>(c->partials.ptr),
-                           static_cast<double*>(c->sums.ptr), c->stream));
+                           static_cast<double*>(c->sums.ptr), nullptr, 0, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.ptr, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   std::memcpy(sums, c->h_sums, kReduceTerms * sizeof(double));
@@ -1212,12 +1271,15 @@ int icpgpu_gicp_covariances(icpgpu_ctx* c, int of_target, double* out6) {
 
 int icpgpu_profile_reset(icpgpu_ctx* c) {
   if (!c) return ICPGPU_ERR_INVALID_ARG;
+  (void)resolve_sweep_timings(c);
   std::memset(&c->prof, 0, sizeof(c->prof));
   return ICPGPU_OK;
 }
 
 int icpgpu_profile_get(icpgpu_ctx* c, icpgpu_profile* out) {
   if (!c || !out) return ICPGPU_ERR_INVALID_ARG;
+  int rc = resolve_sweep_timings(c);
+  if (rc) return rc;
   *out = c->prof;
   return ICPGPU_OK;
 }
