@@ -36,7 +36,9 @@ class Profile(C.Structure):
                 ("grid_launches", C.c_uint64), ("grid_ms", C.c_double), ("grid_bytes", C.c_uint64),
                 ("grid_builds", C.c_uint64), ("grid_build_ms", C.c_double), ("grid_fallback_points", C.c_uint64),
                 ("voxel_launches", C.c_uint64), ("voxel_ms", C.c_double), ("voxel_bytes", C.c_uint64),
-                ("gicp_cov_launches", C.c_uint64), ("gicp_cov_ms", C.c_double), ("gicp_cost_launches", C.c_uint64)]
+                ("gicp_cov_launches", C.c_uint64), ("gicp_cov_ms", C.c_double), ("gicp_cost_launches", C.c_uint64),
+                ("map_inserts", C.c_uint64), ("map_insert_ms", C.c_double), ("map_points_in", C.c_uint64),
+                ("map_nn_launches", C.c_uint64), ("map_nn_ms", C.c_double)]
 
 
 class Pose(C.Structure):
@@ -51,10 +53,12 @@ EXPORTS = [
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_get_stream", "icpgpu_synchronize",
     "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
-    "icpgpu_pose_from_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
+    "icpgpu_pose_from_matrix", "icpgpu_pose_to_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
     "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
     "icpgpu_posegraph_get_keyframe", "icpgpu_posegraph_get_edge", "icpgpu_posegraph_write_g2o",
+    "icpgpu_map_reset", "icpgpu_map_add_points", "icpgpu_map_add_source", "icpgpu_map_size", "icpgpu_map_get_points",
+    "icpgpu_map_nn_target",
 ]
 
 _lib = None
@@ -108,6 +112,7 @@ def load():
     L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]
     pp, lp = C.POINTER(Pose), C.POINTER(C.c_long)
     L.icpgpu_pose_from_matrix.argtypes = [fp, pp]
+    L.icpgpu_pose_to_matrix.argtypes = [pp, fp]
     L.icpgpu_pose_compose.argtypes = [pp, pp, pp]
     L.icpgpu_pose_inverse.argtypes = [pp, pp]
     L.icpgpu_posegraph_create.argtypes = [C.POINTER(vp), C.c_double, dp]
@@ -120,6 +125,13 @@ def load():
     L.icpgpu_posegraph_get_keyframe.argtypes = [vp, C.c_long, pp, lp]
     L.icpgpu_posegraph_get_edge.argtypes = [vp, C.c_long, pp]
     L.icpgpu_posegraph_write_g2o.argtypes = [vp, C.c_char_p]
+    sp = C.POINTER(C.c_size_t)
+    L.icpgpu_map_reset.argtypes = [vp, C.c_double]
+    L.icpgpu_map_add_points.argtypes = [vp, fp, C.c_size_t, fp, sp]
+    L.icpgpu_map_add_source.argtypes = [vp, fp, sp]
+    L.icpgpu_map_size.argtypes = [vp, sp]
+    L.icpgpu_map_get_points.argtypes = [vp, fp, C.c_size_t, sp]
+    L.icpgpu_map_nn_target.argtypes = [vp, fp, fp, fp, sp]
     L.icpgpu_profile_reset.argtypes = [vp]
     L.icpgpu_profile_get.argtypes = [vp, C.POINTER(Profile)]
     L.icpgpu_get_stream.argtypes = [vp, C.POINTER(vp)]

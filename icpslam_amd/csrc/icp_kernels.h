@@ -119,6 +119,25 @@ hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const
                             const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
                             hipStream_t stream);
 
+// ---- the mapper's one-point-per-voxel map (icp_map.hip), SURVEY.md 8(f4) --------------------------------------------
+struct MapDesc {
+  double ox, oy, oz;  // lattice origin = first inserted point - resolution / 2 (PCL OctreePointCloud bounding-box rule)
+  double res;         // voxel size (octree_resolution_, 0.5 m)
+};
+size_t map_scan_temp_bytes(int n);
+// hash set: keys (packed voxel coordinates, all-ones = empty), vals (map index, -1 = claimed this call), first (bids)
+hipError_t launch_map_fill(unsigned long long* keys, int* vals, int* first, unsigned int cap, hipStream_t stream);
+hipError_t launch_map_rehash(const float4* map_pts, int n_map, const MapDesc& m, unsigned long long* keys, int* vals,
+                             unsigned int cap, hipStream_t stream);
+// addPointsToMap(): p = T * in[i]; the first point (lowest i) of every unoccupied voxel is appended to map_pts at
+// base + (its rank among the appended), input order preserved; *d_n_added = number appended.  cap is a power of two.
+hipError_t launch_map_insert(const float4* in, int n, const Xform& T, const MapDesc& m, unsigned long long* keys, int* vals,
+                             int* first, unsigned int cap, float4* moved, int* slot_of, int* flags, int* rank, void* temp,
+                             size_t temp_bytes, int base, float4* map_pts, int* d_n_added, hipStream_t stream);
+// nn cloud: out = T_out * map[index(keys[i])] for every non-empty key, order preserved; *d_n_out = points written
+hipError_t launch_map_nn_gather(const unsigned long long* keys, int n, const float4* map_pts, const Xform& T_out, int* flags,
+                                int* rank, void* temp, size_t temp_bytes, float4* out, int* d_n_out, hipStream_t stream);
+
 // ---- voxel-grid down-sampling (icp_voxel.hip), SURVEY.md 8(f2) -------------------------------------------------
 size_t voxel_temp_bytes(int n);
 // keys/vals: 2*n ints each, flags/slots: n ints each, d_n_out: 2 ints whose sum is the number of cells written to `out`.

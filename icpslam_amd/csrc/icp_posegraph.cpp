@@ -146,6 +146,25 @@ int icpgpu_pose_from_matrix(const float* T, icpgpu_pose* out) {
   return ICPGPU_OK;
 }
 
+int icpgpu_pose_to_matrix(const icpgpu_pose* p, float* T) {
+  if (!p || !T) return ICPGPU_ERR_INVALID_ARG;
+  // tf::Matrix3x3::setRotation (what Pose6DOF::toTFTransform feeds pcl_ros::transformPointCloud), then the cast to float
+  const double x = p->quat[0], y = p->quat[1], z = p->quat[2], w = p->quat[3];
+  const double d = x * x + y * y + z * z + w * w;
+  if (!(d > 0.0)) return ICPGPU_ERR_INVALID_ARG;
+  const double s = 2.0 / d;
+  const double xs = x * s, ys = y * s, zs = z * s;
+  const double wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+  const double r[3][3] = {{1.0 - (yy + zz), xy - wz, xz + wy}, {xy + wz, 1.0 - (xx + zz), yz - wx}, {xz - wy, yz + wx, 1.0 - (xx + yy)}};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[j * 4 + i] = (float)r[i][j];
+    T[12 + i] = (float)p->pos[i];
+    T[i * 4 + 3] = 0.0f;
+  }
+  T[15] = 1.0f;
+  return ICPGPU_OK;
+}
+
 int icpgpu_pose_compose(const icpgpu_pose* a, const icpgpu_pose* b, icpgpu_pose* out) {
   if (!a || !b || !out) return ICPGPU_ERR_INVALID_ARG;
   *out = compose(*a, *b);

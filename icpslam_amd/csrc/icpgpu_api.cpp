@@ -56,6 +56,19 @@ struct GridIndex {
   DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
 };
 
+// The mapper's one-point-per-voxel map (icp_map.hip; octree_mapper.cpp:55-90).
+struct VoxelMap {
+  bool defined = false;   // resolution set by icpgpu_map_reset
+  bool anchored = false;  // lattice origin fixed by the first point ever added
+  MapDesc desc{};
+  int n = 0;              // points in the map
+  uint64_t version = 1;   // bumped whenever points are appended
+  unsigned int cap = 0;   // hash-set capacity (power of two, load <= 1/2)
+  Cloud pts;              // the map cloud (owned)
+  DeviceBuf keys, vals, first, staged, moved, slot_of, flags, rank, temp, counter, nn_keys;
+  GridIndex grid;         // for the nn-cloud search
+};
+
 constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
 constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
 constexpr double kDenseCellPopulation = 64.0;   // shrink the cells beyond this point-weighted population ...
@@ -76,6 +89,7 @@ struct icpgpu_ctx {
   DeviceBuf keys, partials, sums, out, idx, d2;
   GridIndex grid;            // acceleration structure over the current target
   GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
+  VoxelMap map;              // the mapper's map
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
   uint64_t src_version = 1;  // bumped whenever the source cloud changes
   // GICP mode: grids used for the 20-NN covariances, per-point covariances (6 doubles), Mahalanobis matrices
@@ -333,15 +347,14 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
 
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
 // the brute-force kernel. Does not synchronise except for the 4-byte unmatched count.
-int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys) {
-  GridIndex& G = c->grid;
-  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t, const Xform& T,
+                 unsigned long long* keys) {
   int rc = ensure(c, G.unmatched, (size_t)(n_s + 1) * sizeof(int));
   if (rc) return rc;
   int* d_list = static_cast<int*>(G.unmatched.ptr);
   int* d_count = d_list + n_s;
   HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
-  HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, false, T, static_cast<const float4*>(G.sorted.ptr),
+  HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, false, T, static_cast<const float4*>(G.sorted.ptr),
                                    static_cast<const int*>(G.cell_start.ptr), G.g, 0.f, keys, nullptr, d_list, d_count,
                                    c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -349,8 +362,12 @@ int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys) {
   const int n_un = c->h_ints[0];
   c->prof.grid_fallback_points += (uint64_t)n_un;
   if (n_un > 0)
-    HIP_TRY(c, launch_nn_brute_list(c->src.data(), d_list, n_un, c->tgt.data(), n_t, T, c->num_cus, keys, c->stream));
+    HIP_TRY(c, launch_nn_brute_list(src_pts, d_list, n_un, tgt_pts, n_t, T, c->num_cus, keys, c->stream));
   return ICPGPU_OK;
+}
+
+int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys) {
+  return nn_keys_grid(c, c->grid, c->src.data(), (int)c->src.n, c->tgt.data(), (int)c->tgt.n, T, keys);
 }
 
 bool grid_ready(const icpgpu_ctx* c) { return c->grid.usable && c->grid.version == c->tgt_version; }
@@ -971,7 +988,10 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->vox_ints);
   release(c->idx);
   release(c->d2);
-  for (GridIndex* G : {&c->grid, &c->src_grid}) {
+  for (DeviceBuf* b : {&c->map.pts.buf, &c->map.keys, &c->map.vals, &c->map.first, &c->map.staged, &c->map.moved, &c->map.slot_of,
+                       &c->map.flags, &c->map.rank, &c->map.temp, &c->map.counter, &c->map.nn_keys})
+    release(*b);
+  for (GridIndex* G : {&c->grid, &c->src_grid, &c->map.grid}) {
     release(G->sorted);
     release(G->cell_start);
     release(G->cell_of_point);
@@ -1266,6 +1286,229 @@ int icpgpu_gicp_covariances(icpgpu_ctx* c, int of_target, double* out6) {
   const DeviceBuf& cov = of_target ? c->cov_tgt : c->cov_src;
   HIP_TRY(c, hipMemcpyAsync(out6, cov.ptr, cl.n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ICPGPU_OK;
+}
+
+// ---- the mapper's map (octree_mapper.cpp:55-90,133-172) ------------------------------------------
+namespace {
+
+int grow_preserving(icpgpu_ctx* c, DeviceBuf& b, size_t keep_bytes, size_t want_bytes) {
+  if (want_bytes <= b.cap) return ICPGPU_OK;
+  size_t cap = std::max<size_t>(2 * want_bytes, 1u << 20);
+  void* np = nullptr;
+  HIP_TRY(c, hipMalloc(&np, cap));
+  if (keep_bytes && b.ptr) {
+    const hipError_t e = hipMemcpyAsync(np, b.ptr, keep_bytes, hipMemcpyDeviceToDevice, c->stream);
+    const hipError_t e2 = e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+    if (e2 != hipSuccess) {
+      (void)hipFree(np);
+      return fail(c, ICPGPU_ERR_HIP, "map growth: %s", hipGetErrorString(e2));
+    }
+  }
+  if (b.ptr && !b.external) HIP_TRY(c, hipFree(b.ptr));
+  b.ptr = np;
+  b.cap = cap;
+  b.external = false;
+  return ICPGPU_OK;
+}
+
+// host copy of the device transform (same expression, same fused multiply-adds: icp_device.h xform_point)
+void xform_point_host(const Xform& T, const float* s, float p[3]) {
+  p[0] = std::fmaf(T.m[2], s[2], std::fmaf(T.m[1], s[1], std::fmaf(T.m[0], s[0], T.m[3])));
+  p[1] = std::fmaf(T.m[6], s[2], std::fmaf(T.m[5], s[1], std::fmaf(T.m[4], s[0], T.m[7])));
+  p[2] = std::fmaf(T.m[10], s[2], std::fmaf(T.m[9], s[1], std::fmaf(T.m[8], s[0], T.m[11])));
+}
+
+// The lattice is anchored by the first point that is ever added: origin = p - resolution / 2 (PCL
+// OctreePointCloud::adoptBoundingBoxToPoint for an empty octree).  d_in: the batch in HBM.
+int map_anchor(icpgpu_ctx* c, const float4* d_in, int n, const Xform& T) {
+  VoxelMap& M = c->map;
+  std::vector<float> chunk;
+  for (int off = 0; off < n && !M.anchored; off += 4096) {
+    const int m = std::min(4096, n - off);
+    chunk.resize((size_t)m * 4);
+    HIP_TRY(c, hipMemcpyAsync(chunk.data(), d_in + off, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < m; ++i) {
+      float p[3];
+      xform_point_host(T, &chunk[(size_t)i * 4], p);
+      if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) {
+        M.desc.ox = (double)p[0] - M.desc.res / 2.0;
+        M.desc.oy = (double)p[1] - M.desc.res / 2.0;
+        M.desc.oz = (double)p[2] - M.desc.res / 2.0;
+        M.anchored = true;
+        break;
+      }
+    }
+  }
+  return ICPGPU_OK;
+}
+
+// addPointsToMap() for a batch already in HBM
+int map_insert_device(icpgpu_ctx* c, const float4* d_in, int n, const float* pose, size_t* n_added) {
+  VoxelMap& M = c->map;
+  if (n_added) *n_added = 0;
+  if (!M.defined) return fail(c, ICPGPU_ERR_NO_INPUT, "map: call icpgpu_map_reset first");
+  if (n <= 0) return ICPGPU_OK;
+  if ((size_t)M.n + (size_t)n > (size_t)INT32_MAX / 4) return fail(c, ICPGPU_ERR_INVALID_ARG, "map too large");
+  const Xform T = to_xform(pose);
+  int rc;
+  if (!M.anchored && (rc = map_anchor(c, d_in, n, T))) return rc;
+  if (!M.anchored) return ICPGPU_OK;  // nothing finite in the batch: the map stays empty
+
+  // hash set with load <= 1/2 even if every point of the batch opens a new voxel
+  const size_t need = 2 * ((size_t)M.n + (size_t)n);
+  if (need > M.cap) {
+    unsigned int cap = 1u << 16;
+    while (cap < need) cap <<= 1;
+    if ((rc = ensure(c, M.keys, (size_t)cap * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, M.vals, (size_t)cap * sizeof(int)))) return rc;
+    if ((rc = ensure(c, M.first, (size_t)cap * sizeof(int)))) return rc;
+    M.cap = cap;
+    HIP_TRY(c, launch_map_fill(static_cast<unsigned long long*>(M.keys.ptr), static_cast<int*>(M.vals.ptr),
+                               static_cast<int*>(M.first.ptr), cap, c->stream));
+    HIP_TRY(c, launch_map_rehash(M.pts.data(), M.n, M.desc, static_cast<unsigned long long*>(M.keys.ptr),
+                                 static_cast<int*>(M.vals.ptr), cap, c->stream));
+  }
+  if ((rc = grow_preserving(c, M.pts.buf, (size_t)M.n * sizeof(float4), ((size_t)M.n + (size_t)n) * sizeof(float4)))) return rc;
+  if ((rc = ensure(c, M.moved, (size_t)n * sizeof(float4)))) return rc;
+  if ((rc = ensure(c, M.slot_of, (size_t)n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, M.flags, (size_t)n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, M.rank, (size_t)n * sizeof(int)))) return rc;
+  const size_t temp_bytes = map_scan_temp_bytes(n);
+  if ((rc = ensure(c, M.temp, temp_bytes))) return rc;
+  if ((rc = ensure(c, M.counter, 4 * sizeof(int)))) return rc;
+  int* d_added = static_cast<int*>(M.counter.ptr);
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_map_insert(d_in, n, T, M.desc, static_cast<unsigned long long*>(M.keys.ptr), static_cast<int*>(M.vals.ptr),
+                               static_cast<int*>(M.first.ptr), M.cap, static_cast<float4*>(M.moved.ptr),
+                               static_cast<int*>(M.slot_of.ptr), static_cast<int*>(M.flags.ptr), static_cast<int*>(M.rank.ptr),
+                               M.temp.ptr, temp_bytes, M.n, static_cast<float4*>(M.pts.buf.ptr), d_added, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_added, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  const int added = c->h_ints[0];
+  M.n += added;
+  M.pts.n = (size_t)M.n;
+  M.pts.set = true;
+  if (added > 0) M.version++;
+  c->prof.map_inserts += 1;
+  c->prof.map_insert_ms += ms;
+  c->prof.map_points_in += (uint64_t)n;
+  if (n_added) *n_added = (size_t)added;
+  return ICPGPU_OK;
+}
+
+}  // namespace
+
+int icpgpu_map_reset(icpgpu_ctx* c, double resolution) {
+  ENTER(c);
+  if (!(resolution > 0.0) || !std::isfinite(resolution)) return fail(c, ICPGPU_ERR_INVALID_ARG, "map: resolution must be positive");
+  VoxelMap& M = c->map;
+  M.defined = true;
+  M.anchored = false;
+  M.desc = MapDesc{0.0, 0.0, 0.0, resolution};
+  M.n = 0;
+  M.pts.n = 0;
+  M.pts.set = true;
+  M.version++;
+  M.cap = 0;  // the hash set is rebuilt by the next insertion
+  M.grid.built = M.grid.usable = false;
+  return ICPGPU_OK;
+}
+
+int icpgpu_map_add_points(icpgpu_ctx* c, const float* xyzw, size_t n, const float* pose, size_t* n_added) {
+  ENTER(c);
+  if (n_added) *n_added = 0;
+  if (n && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  if (!c->map.defined) return fail(c, ICPGPU_ERR_NO_INPUT, "map: call icpgpu_map_reset first");
+  if (n == 0) return ICPGPU_OK;
+  int rc = ensure(c, c->map.staged, n * sizeof(float4));
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(c->map.staged.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free xyzw as soon as we return
+  return map_insert_device(c, static_cast<const float4*>(c->map.staged.ptr), (int)n, pose, n_added);
+}
+
+int icpgpu_map_add_source(icpgpu_ctx* c, const float* pose, size_t* n_added) {
+  ENTER(c);
+  if (n_added) *n_added = 0;
+  if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "map_add_source: no source set");
+  return map_insert_device(c, c->src.data(), (int)c->src.n, pose, n_added);
+}
+
+int icpgpu_map_size(icpgpu_ctx* c, size_t* n) {
+  if (!c || !n) return ICPGPU_ERR_INVALID_ARG;
+  *n = (size_t)c->map.n;
+  return ICPGPU_OK;
+}
+
+int icpgpu_map_get_points(icpgpu_ctx* c, float* out_xyzw, size_t capacity, size_t* n) {
+  ENTER(c);
+  if (n) *n = (size_t)c->map.n;
+  if ((size_t)c->map.n > capacity) return fail(c, ICPGPU_ERR_INVALID_ARG, "map_get_points: %d points, room for %zu", c->map.n, capacity);
+  if (c->map.n > 0) {
+    if (!out_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null output");
+    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->map.pts.buf.ptr, (size_t)c->map.n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return ICPGPU_OK;
+}
+
+int icpgpu_map_nn_target(icpgpu_ctx* c, const float* pose, const float* pose_inv, float* nn_out_xyzw, size_t* n_nn) {
+  ENTER(c);
+  if (n_nn) *n_nn = 0;
+  VoxelMap& M = c->map;
+  if (!M.defined) return fail(c, ICPGPU_ERR_NO_INPUT, "map: call icpgpu_map_reset first");
+  if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "map_nn_target: no source set");
+  const int n_s = (int)c->src.n;
+  if (c->tgt.buf.external) c->tgt.buf = DeviceBuf{};
+  c->tgt_version++;
+  c->tgt.set = true;
+  c->tgt.n = 0;
+  c->have_final = false;
+  if (M.n == 0 || n_s == 0) return ICPGPU_OK;  // approxNearestNeighbors() on an empty map: empty nn cloud
+
+  // exact NN of pose * s in the map: grid where the neighbour is within 2 voxel sizes, brute force for the rest
+  int rc = build_grid(c, M.pts, M.version, 2.0 * M.desc.res, /*adapt=*/true, M.grid);
+  if (rc) return rc;
+  if ((rc = ensure(c, M.nn_keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+  auto* keys = static_cast<unsigned long long*>(M.nn_keys.ptr);
+  const Xform T = to_xform(pose), Tinv = to_xform(pose_inv);
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (M.grid.usable) {
+    if ((rc = nn_keys_grid(c, M.grid, c->src.data(), n_s, M.pts.data(), M.n, T, keys))) return rc;
+  } else {
+    const NnPlan plan = plan_nn_brute(n_s, M.n, c->nn_variant, c->num_cus);
+    if (plan.splits > 1) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+    HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, M.pts.data(), M.n, T, plan, keys, c->stream));
+  }
+  if ((rc = ensure(c, c->tgt.buf, (size_t)n_s * sizeof(float4)))) return rc;
+  if ((rc = ensure(c, M.flags, (size_t)n_s * sizeof(int)))) return rc;
+  if ((rc = ensure(c, M.rank, (size_t)n_s * sizeof(int)))) return rc;
+  const size_t temp_bytes = map_scan_temp_bytes(n_s);
+  if ((rc = ensure(c, M.temp, temp_bytes))) return rc;
+  if ((rc = ensure(c, M.counter, 4 * sizeof(int)))) return rc;
+  int* d_count = static_cast<int*>(M.counter.ptr);
+  HIP_TRY(c, launch_map_nn_gather(keys, n_s, M.pts.data(), Tinv, static_cast<int*>(M.flags.ptr), static_cast<int*>(M.rank.ptr),
+                                  M.temp.ptr, temp_bytes, static_cast<float4*>(c->tgt.buf.ptr), d_count, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.map_nn_launches += 1;
+  c->prof.map_nn_ms += ms;
+  const int m = c->h_ints[0];
+  c->tgt.n = (size_t)m;
+  if (nn_out_xyzw && m > 0) {
+    HIP_TRY(c, hipMemcpyAsync(nn_out_xyzw, c->tgt.buf.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  if (n_nn) *n_nn = (size_t)m;
   return ICPGPU_OK;
 }
 

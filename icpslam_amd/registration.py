@@ -114,6 +114,46 @@ class Context:
         self._check(self._L.icpgpu_promote_source_to_target(self._h))
         self.n_target, self.n_source = self.n_source, 0
 
+    # the mapper's map (octree_mapper.cpp:55-90) -----------------------------------------------
+    def map_reset(self, resolution: float = 0.5):
+        """resetMap(): empty one-point-per-voxel map (octree_resolution_, octree_mapper.cpp:41)."""
+        self._check(self._L.icpgpu_map_reset(self._h, float(resolution)))
+
+    def map_add_points(self, cloud, pose=None) -> int:
+        """addPointsToMap(transformCloudToPoseFrame(cloud, pose)); returns the number of points appended."""
+        cloud = _as_cloud(cloud)
+        n = C.c_size_t()
+        g = _fp(_colmajor16(pose)) if pose is not None else None
+        self._check(self._L.icpgpu_map_add_points(self._h, _fp(cloud), cloud.shape[0], g, C.byref(n)))
+        return int(n.value)
+
+    def map_add_source(self, pose=None) -> int:
+        n = C.c_size_t()
+        g = _fp(_colmajor16(pose)) if pose is not None else None
+        self._check(self._L.icpgpu_map_add_source(self._h, g, C.byref(n)))
+        return int(n.value)
+
+    def map_size(self) -> int:
+        n = C.c_size_t()
+        self._check(self._L.icpgpu_map_size(self._h, C.byref(n)))
+        return int(n.value)
+
+    def map_points(self) -> np.ndarray:
+        n = self.map_size()
+        out = np.empty((n, 4), np.float32)
+        m = C.c_size_t()
+        self._check(self._L.icpgpu_map_get_points(self._h, _fp(out) if n else None, n, C.byref(m)))
+        return out
+
+    def map_nn_target(self, pose, pose_inv, want_cloud: bool = True):
+        """approxNearestNeighbors(cloud_in_map) moved by pose_inv becomes the target (exact NN); returns the nn cloud."""
+        out = np.empty((self.n_source, 4), np.float32) if want_cloud else None
+        n = C.c_size_t()
+        self._check(self._L.icpgpu_map_nn_target(self._h, _fp(_colmajor16(pose)), _fp(_colmajor16(pose_inv)),
+                                                 _fp(out) if out is not None and self.n_source else None, C.byref(n)))
+        self.n_target = int(n.value)
+        return out[: n.value] if out is not None else None
+
     # hot path ---------------------------------------------------------------------------------------------
     def align(self, guess=None, want_cloud: bool = False, want_fitness: bool = False):
         res = Result()

@@ -27,6 +27,15 @@ def pose_from_matrix(T) -> Pose:
     return p
 
 
+def pose_to_matrix(p: Pose) -> np.ndarray:
+    """Pose6DOF::toTFTransform as the float 4x4 that pcl_ros::transformPointCloud applies (row-major numpy)."""
+    buf = np.zeros(16, np.float32)
+    rc = _lib.load().icpgpu_pose_to_matrix(C.byref(p), buf.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise IcpGpuError(rc, "pose_to_matrix: zero quaternion")
+    return buf.reshape(4, 4).T.copy()
+
+
 def pose_compose(a: Pose, b: Pose) -> Pose:
     out = Pose()
     _lib.load().icpgpu_pose_compose(C.byref(a), C.byref(b), C.byref(out))

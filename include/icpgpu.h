@@ -124,6 +124,11 @@ typedef struct {
   uint64_t gicp_cov_launches; /* GICP: per-cloud 20-NN covariance passes */
   double gicp_cov_ms;
   uint64_t gicp_cost_launches; /* GICP: BFGS function/gradient evaluations (one device reduction each) */
+  uint64_t map_inserts;       /* f4: addPointsToMap batches */
+  double map_insert_ms;
+  uint64_t map_points_in;     /* points offered to the map */
+  uint64_t map_nn_launches;   /* f4: nn-cloud builds */
+  double map_nn_ms;
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -200,6 +205,31 @@ int icpgpu_voxel_grid(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, 
  * filtered cloud the source without a round trip to the host (icp_odometer.cpp:177 then :193). */
 int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, size_t* n_out);
 
+/* ---- the mapper's target: a one-point-per-voxel map and its "nn cloud"  -------- */
+/* replaces OctreeMapper's pcl::octree::OctreePointCloudSearch map
+ * (/root/reference/src/icpslam/octree_mapper.cpp:55-59 resetMap, :62-69 addPointsToMap,
+ *  :72-90 approxNearestNeighbors, :133-172 refineTransformAndGrowMap; octree_resolution_ 0.5 m, :41).
+ * The map belongs to the context and lives in HBM.
+ *   reset        resetMap(): empty map with voxel size `resolution` (> 0).
+ *   add_points   addPointsToMap(transformCloudToPoseFrame(cloud, pose)): p = pose * x (float, the a6
+ *                contract); going through the points IN ORDER, p is appended to the map iff its voxel
+ *                holds no point yet.  Voxels are the cells floor((p - origin) / resolution) (double) of
+ *                the lattice whose origin is (first point ever added) - resolution / 2 -- PCL's octree
+ *                bounding-box rule.  Non-finite points are skipped.  pose NULL = identity.
+ *   add_source   the same for the context's current source cloud (already in HBM).
+ *   nn_target    approxNearestNeighbors + transformCloudToPoseFrame(.., raw_pose.inverse()) + setInputTarget:
+ *                for every source point s (in order) the map point nearest to pose * s -- EXACT, lowest map
+ *                index among equals, where PCL's approxNearestSearch is a heuristic -- moved by pose_inv,
+ *                becomes the context's TARGET cloud (device to device).  Source points whose image is not
+ *                finite are dropped, like the reference's "result_index < 0".  nn_out_xyzw (nullable) must
+ *                hold n_source points; *n_nn = points in the nn cloud.  An empty map gives an empty target. */
+int icpgpu_map_reset(icpgpu_ctx* ctx, double resolution);
+int icpgpu_map_add_points(icpgpu_ctx* ctx, const float* xyzw, size_t n, const float* pose, size_t* n_added);
+int icpgpu_map_add_source(icpgpu_ctx* ctx, const float* pose, size_t* n_added);
+int icpgpu_map_size(icpgpu_ctx* ctx, size_t* n);
+int icpgpu_map_get_points(icpgpu_ctx* ctx, float* out_xyzw, size_t capacity, size_t* n);
+int icpgpu_map_nn_target(icpgpu_ctx* ctx, const float* pose, const float* pose_inv, float* nn_out_xyzw, size_t* n_nn);
+
 /* ---- the data contract after the path: pose chain, keyframes, pose graph ---- */
 /* SE(3) pose as the reference's Pose6DOF keeps it (/root/reference/include/utils/pose6DOF.h):
  * position + unit quaternion (x, y, z, w). Host-only arithmetic in double; no GPU involved. */
@@ -212,6 +242,8 @@ typedef struct icpgpu_posegraph icpgpu_posegraph; /* opaque */
 /* Pose6DOF(T): pose6DOF.cpp:185-190 (T = float[16] column-major as returned in icpgpu_result.T). */
 int icpgpu_pose_from_matrix(const float* T, icpgpu_pose* out);
 /* Pose6DOF::compose (operator+): pose6DOF.cpp:98-105.  Pose6DOF::inverse: pose6DOF.cpp:117-122. */
+/* Pose6DOF::toTFTransform -> the Matrix4f pcl_ros::transformPointCloud applies (pose6DOF.cpp:254-259): column-major float */
+int icpgpu_pose_to_matrix(const icpgpu_pose* p, float* T);
 int icpgpu_pose_compose(const icpgpu_pose* a, const icpgpu_pose* b, icpgpu_pose* out);
 int icpgpu_pose_inverse(const icpgpu_pose* a, icpgpu_pose* out);
 

@@ -45,7 +45,7 @@ class IterTrace(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile oracle/liboracle.so with the committed Makefile (gcc only)."""
-    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "gicp_oracle.c", "icp_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("icp_oracle.c", "gicp_oracle.c", "map_oracle.c", "icp_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
@@ -78,6 +78,18 @@ def lib():
         L.orc_gicp_covariances.argtypes = [fp, C.c_size_t, C.c_int, dp]
         L.orc_svd3.argtypes = [dp, dp, dp, dp]
         L.orc_svd3.restype = None
+        L.orc_map_create.argtypes = [C.c_double]
+        L.orc_map_create.restype = C.c_void_p
+        L.orc_map_destroy.argtypes = [C.c_void_p]
+        L.orc_map_destroy.restype = None
+        L.orc_map_size.argtypes = [C.c_void_p]
+        L.orc_map_size.restype = C.c_size_t
+        L.orc_map_points.argtypes = [C.c_void_p]
+        L.orc_map_points.restype = fp
+        L.orc_map_add_points.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
+        L.orc_map_add_points.restype = C.c_long
+        L.orc_map_nn_cloud.argtypes = [C.c_void_p, fp, C.c_size_t, fp, fp, fp]
+        L.orc_map_nn_cloud.restype = C.c_long
         _lib = L
     return _lib
 
@@ -198,3 +210,53 @@ def svd3(A):
     dp = C.POINTER(C.c_double)
     lib().orc_svd3(A.ctypes.data_as(dp), U.ctypes.data_as(dp), s.ctypes.data_as(dp), V.ctypes.data_as(dp))
     return U.reshape(3, 3), s, V.reshape(3, 3)
+
+
+class VoxelMap:
+    """The mapper's one-point-per-voxel map (oracle/map_oracle.c; octree_mapper.cpp:55-90), sequential restatement."""
+
+    def __init__(self, resolution: float = 0.5):
+        self._L = lib()
+        self._h = self._L.orc_map_create(float(resolution))
+        if not self._h:
+            raise MemoryError("orc_map_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.orc_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._L.orc_map_size(self._h))
+
+    def add_points(self, cloud, pose=None) -> int:
+        cloud, pc = _f32(cloud)
+        g = None
+        if pose is not None:
+            gc, g = _f32(_colmajor(pose))
+        n = self._L.orc_map_add_points(self._h, pc, cloud.shape[0], g)
+        if n < 0:
+            raise MemoryError("orc_map_add_points")
+        return int(n)
+
+    def points(self) -> np.ndarray:
+        n = len(self)
+        if n == 0:
+            return np.zeros((0, 4), np.float32)
+        return np.ctypeslib.as_array(self._L.orc_map_points(self._h), shape=(n, 4)).copy()
+
+    def nn_cloud(self, cloud, pose, pose_inv) -> np.ndarray:
+        cloud, pc = _f32(cloud)
+        a, pa = _f32(_colmajor(pose))
+        b, pb = _f32(_colmajor(pose_inv))
+        out = np.empty_like(cloud)
+        n = self._L.orc_map_nn_cloud(self._h, pc, cloud.shape[0], pa, pb, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if n < 0:
+            raise MemoryError("orc_map_nn_cloud")
+        return out[:n].copy()

@@ -397,7 +397,7 @@ static void kd_nearest(const kd_tree* t, const float* q, int32_t* idx, float* d2
     mind += offs[a] * offs[a];
   }
   kd_search_rec(&Q, 0, mind, offs);
-  *idx = Q.best_idx;
+  *idx = Q.best_idx == INT32_MAX ? -1 : Q.best_idx; /* non-finite query: no neighbour (like the brute-force scan) */
   *d2 = Q.best;
 }
 

@@ -1,0 +1,136 @@
+/*
+ * map_oracle.c -- CPU ORACLE for the mapper's map.  TEST INFRASTRUCTURE ONLY (see icp_oracle.h:
+ * PARITY UNPINNED -- the octree is PCL's, which is not under /root/reference).
+ *
+ * Restates what the reference relies on at
+ *   /root/reference/src/icpslam/octree_mapper.cpp:55-59   resetMap (OctreePointCloudSearch, resolution 0.5 m)
+ *   /root/reference/src/icpslam/octree_mapper.cpp:62-69   addPointsToMap: "if (!isVoxelOccupiedAtPoint(p)) addPointToCloud(p)"
+ *   /root/reference/src/icpslam/octree_mapper.cpp:72-90   approxNearestNeighbors -> nn cloud
+ * as a plain sequential loop: points are visited in order; a point is appended iff its voxel is empty; a voxel is
+ * floor((p - origin) / resolution) per axis in double, origin = first point ever added - resolution / 2 (PCL
+ * OctreePointCloud::adoptBoundingBoxToPoint + genOctreeKeyforPoint: the box only grows by whole octree side lengths, so
+ * the lattice never moves).  The nearest-neighbour query is EXACT (orc_nn), where PCL's approxNearestSearch is a
+ * heuristic descent -- SURVEY.md 8(f4) asks for the exact one.
+ *
+ * The voxel set is a sorted array + binary search rebuilt per batch: deliberately nothing like the GPU's hash set.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "icp_oracle.h"
+
+struct orc_map {
+  double res, ox, oy, oz;
+  int anchored;
+  size_t n, cap;
+  float* pts;     /* n x 4 */
+  int64_t* keys;  /* sorted voxel keys of the n points */
+};
+
+static int64_t pack_key(int64_t kx, int64_t ky, int64_t kz) { return ((kz + (1 << 20)) << 42) | ((ky + (1 << 20)) << 21) | (kx + (1 << 20)); }
+
+static int point_key(const orc_map* m, const float* p, int64_t* key) {
+  const double fx = floor(((double)p[0] - m->ox) / m->res), fy = floor(((double)p[1] - m->oy) / m->res),
+               fz = floor(((double)p[2] - m->oz) / m->res);
+  const double lim = (double)((1 << 20) - 1);
+  if (!(fabs(fx) <= lim && fabs(fy) <= lim && fabs(fz) <= lim)) return 0;
+  *key = pack_key((int64_t)fx, (int64_t)fy, (int64_t)fz);
+  return 1;
+}
+
+orc_map* orc_map_create(double resolution) {
+  orc_map* m = (orc_map*)calloc(1, sizeof(orc_map));
+  if (m) m->res = resolution;
+  return m;
+}
+
+void orc_map_destroy(orc_map* m) {
+  if (!m) return;
+  free(m->pts);
+  free(m->keys);
+  free(m);
+}
+
+size_t orc_map_size(const orc_map* m) { return m->n; }
+const float* orc_map_points(const orc_map* m) { return m->pts; }
+
+static long find_key(const int64_t* keys, size_t n, int64_t k) { /* position of k in the sorted array or -(insert)-1 */
+  size_t lo = 0, hi = n;
+  while (lo < hi) {
+    const size_t mid = (lo + hi) / 2;
+    if (keys[mid] < k) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < n && keys[lo] == k) ? (long)lo : -(long)lo - 1;
+}
+
+/* addPointsToMap(transformCloudToPoseFrame(cloud, pose)); returns the number of points appended, -1 on allocation failure */
+long orc_map_add_points(orc_map* m, const float* in_xyzw, size_t n, const float pose[16]) {
+  float* moved = (float*)malloc((n ? n : 1) * 4 * sizeof(float));
+  if (!moved) return -1;
+  if (pose) orc_transform_cloud(in_xyzw, n, pose, moved);
+  else {
+    memcpy(moved, in_xyzw, n * 4 * sizeof(float));
+    for (size_t i = 0; i < n; ++i) moved[4 * i + 3] = 1.0f;
+  }
+  long added = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = moved + 4 * i;
+    if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+    if (!m->anchored) {
+      m->ox = (double)p[0] - m->res / 2.0;
+      m->oy = (double)p[1] - m->res / 2.0;
+      m->oz = (double)p[2] - m->res / 2.0;
+      m->anchored = 1;
+    }
+    int64_t key;
+    if (!point_key(m, p, &key)) continue;
+    const long pos = find_key(m->keys, m->n, key);
+    if (pos >= 0) continue; /* isVoxelOccupiedAtPoint */
+    if (m->n == m->cap) {
+      const size_t cap = m->cap ? 2 * m->cap : 4096;
+      float* np_ = (float*)realloc(m->pts, cap * 4 * sizeof(float));
+      int64_t* nk = (int64_t*)realloc(m->keys, cap * sizeof(int64_t));
+      if (np_) m->pts = np_;
+      if (nk) m->keys = nk;
+      if (!np_ || !nk) {
+        free(moved);
+        return -1;
+      }
+      m->cap = cap;
+    }
+    const size_t ins = (size_t)(-pos - 1);
+    memmove(m->keys + ins + 1, m->keys + ins, (m->n - ins) * sizeof(int64_t));
+    m->keys[ins] = key;
+    memcpy(m->pts + 4 * m->n, p, 4 * sizeof(float)); /* map_cloud_ keeps insertion order */
+    m->n++;
+    added++;
+  }
+  free(moved);
+  return added;
+}
+
+/* nn cloud of `cloud` seen from `pose`, moved back by pose_inv: out must hold n points; returns the number written */
+long orc_map_nn_cloud(const orc_map* m, const float* cloud_xyzw, size_t n, const float pose[16], const float pose_inv[16],
+                      float* out_xyzw) {
+  if (m->n == 0 || n == 0) return 0;
+  int32_t* idx = (int32_t*)malloc(n * sizeof(int32_t));
+  float* d2 = (float*)malloc(n * sizeof(float));
+  float* sel = (float*)malloc(n * 4 * sizeof(float));
+  if (!idx || !d2 || !sel) {
+    free(idx);
+    free(d2);
+    free(sel);
+    return -1;
+  }
+  orc_nn(cloud_xyzw, n, m->pts, m->n, pose, ORC_NN_KDTREE, ORC_ARITH_FMA, idx, d2);
+  long k = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (idx[i] >= 0) memcpy(sel + 4 * (k++), m->pts + 4 * (size_t)idx[i], 4 * sizeof(float));
+  orc_transform_cloud(sel, (size_t)k, pose_inv, out_xyzw);
+  free(idx);
+  free(d2);
+  free(sel);
+  return k;
+}

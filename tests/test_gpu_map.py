@@ -1,0 +1,124 @@
+"""GPU parity of the mapper's map (octree_mapper.cpp:55-90,133-172) against oracle/map_oracle.c:
+map contents and order bit for bit, nn cloud bit for bit, and the refine-and-grow loop end to end."""
+import numpy as np
+import pytest
+
+import oracle
+from icpslam_amd import NN_BRUTE, NN_GRID, synth
+from icpslam_amd.mapper import OctreeMapper, identity_pose
+from icpslam_amd.sequence import pose_compose, pose_from_matrix, pose_inverse, pose_to_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_map_insert_bit_exact_over_several_batches(ctx):
+    ref = oracle.VoxelMap(0.5)
+    ctx.map_reset(0.5)
+    rng = np.random.default_rng(0)
+    for k in range(4):
+        a, _, _ = synth.make_pair(30000 + 5000 * k, 10, seed=10 + k)
+        T = synth.pose_matrix(0.8 * k, 0.1 * k, 0.0, 0.0, 0.0, 0.05 * k) if k else None
+        a = a.copy()
+        a[rng.integers(0, a.shape[0], 5), :3] = np.nan           # never inserted
+        got = ctx.map_add_points(a, T)
+        want = ref.add_points(a, T)
+        assert got == want and ctx.map_size() == len(ref)
+    assert np.array_equal(_bits(ctx.map_points()), _bits(ref.points()))
+    # every voxel of the last batch is taken now
+    assert ctx.map_add_points(a, T) == 0
+
+
+def test_map_anchor_is_first_finite_point_and_other_resolutions(ctx):
+    a, _, _ = synth.make_pair(20000, 10, seed=20)
+    a = a.copy()
+    a[:3, :3] = np.nan
+    for res in (0.05, 0.2, 3.0):
+        ref = oracle.VoxelMap(res)
+        ctx.map_reset(res)
+        assert ctx.map_add_points(a) == ref.add_points(a)
+        assert np.array_equal(_bits(ctx.map_points()), _bits(ref.points()))
+
+
+def test_map_duplicates_and_single_voxel(ctx):
+    pts = np.ones((5000, 4), np.float32)
+    pts[:, :3] = (1.0, 2.0, 3.0)
+    ctx.map_reset(0.5)
+    assert ctx.map_add_points(pts) == 1
+    assert np.array_equal(ctx.map_points(), pts[:1])
+    assert ctx.map_add_points(np.zeros((0, 4), np.float32)) == 0
+
+
+@pytest.mark.parametrize("mode", [NN_GRID, NN_BRUTE])
+def test_nn_target_bit_exact(ctx, mode):
+    scan0, scan1, Tgt = synth.make_pair(40000, 40000, seed=30)
+    pose = synth.pose_matrix(2.0, -1.0, 0.1, 0.01, 0.02, 0.3)
+    pose_inv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+    ref = oracle.VoxelMap(0.5)
+    ref.add_points(scan1, pose)
+    ctx.set_params(ctx.default_params(), nn_mode=mode)
+    ctx.map_reset(0.5)
+    ctx.map_add_points(scan1, pose)
+    src = scan0.copy()
+    src[11, :3] = np.nan                                           # dropped
+    src[12, :3] = (500.0, 500.0, 50.0)                             # far from the map: brute-force completion
+    ctx.set_source(src)
+    nn = ctx.map_nn_target(pose, pose_inv)
+    want = ref.nn_cloud(src, pose, pose_inv)
+    assert nn.shape == want.shape == (src.shape[0] - 1, 4)
+    assert np.array_equal(_bits(nn), _bits(want))
+    # the nn cloud IS the target now: aligning against it equals aligning against the oracle's nn cloud
+    r = ctx.align()
+    o = oracle.icp_align(src, want, oracle.default_params())
+    assert r["iterations"] == o["iterations"] and r["n_corr"] == o["n_corr"]
+    assert np.abs(r["T"][:3, :3] - o["T"][:3, :3]).max() <= 1e-4   # BASELINE tolerance (R)
+    assert np.linalg.norm(r["T"][:3, 3] - o["T"][:3, 3]) <= 1e-3   # BASELINE tolerance (t), metres
+
+
+def test_nn_target_on_empty_map(ctx):
+    a, _, _ = synth.make_pair(1000, 10, seed=31)
+    ctx.map_reset(0.5)
+    ctx.set_source(a)
+    nn = ctx.map_nn_target(np.eye(4), np.eye(4))
+    assert nn.shape == (0, 4)
+    r = ctx.align()                                                 # PCL: empty target -> not converged, identity
+    assert not r["converged"] and np.array_equal(r["T"], np.eye(4, dtype=np.float32))
+
+
+def test_refine_and_grow_matches_the_oracle_flow(ctx):
+    """octree_mapper.cpp:133-172 over five scans of a short drive, odometry = ground truth + a known error."""
+    scene = synth.make_scene(seed=40)
+    poses = [synth.pose_matrix(0.6 * k, 0.05 * k, 0.0, 0.0, 0.0, 0.02 * k) for k in range(5)]
+    scans = [synth.scan(scene, P, 30000, seed=400 + k) for k, P in enumerate(poses)]
+    err = synth.pose_matrix(0.15, -0.1, 0.02, 0.0, 0.0, 0.01)
+
+    mapper = OctreeMapper(ctx, octree_resolution=0.5)
+    ref = oracle.VoxelMap(0.5)
+    p_icp = oracle.default_params(max_iterations=30)
+    for k, (scan, P) in enumerate(zip(scans, poses)):
+        raw = pose_from_matrix((P.astype(np.float64) @ err.astype(np.float64)).astype(np.float32) if k else P)
+        raw_M = pose_to_matrix(raw)
+        raw_Minv = pose_to_matrix(pose_inverse(raw))
+        ok, transform, refined, info = mapper.refineTransformAndGrowMap(scan, raw)
+        # the same sequence on the CPU
+        if len(ref) == 0:
+            ref.add_points(scan, raw_M)
+            assert not ok and info["seeded"]
+        else:
+            nn = ref.nn_cloud(scan, raw_M, raw_Minv)
+            o = oracle.icp_align(scan, nn, p_icp)
+            assert ok == o["converged"]
+            assert info["n_nn"] == nn.shape[0]
+            T_gpu = pose_to_matrix(transform)
+            assert np.abs(T_gpu[:3, :3] - o["T"][:3, :3]).max() <= 1e-4
+            assert np.linalg.norm(T_gpu[:3, 3] - o["T"][:3, 3]) <= 1e-3
+            # the CPU map grows with the GPU's refined pose so that both maps stay comparable bit for bit
+            ref.add_points(scan, pose_to_matrix(refined))
+            # the refinement must undo most of the injected odometry error
+            resid = np.linalg.inv(P.astype(np.float64)) @ pose_to_matrix(refined).astype(np.float64)
+            assert np.linalg.norm(resid[:3, 3]) < 0.08
+        assert mapper.map_size == len(ref)
+    assert np.array_equal(_bits(mapper.map_cloud()), _bits(ref.points()))
