@@ -103,7 +103,12 @@ class IterativeClosestPoint {
   template <class CloudPtr>
   void setInputSource(const CloudPtr& cloud) { source_ = &*cloud; }
   template <class CloudPtr>
-  void setInputTarget(const CloudPtr& cloud) { target_ = &*cloud; }
+  void setInputTarget(const CloudPtr& cloud) {
+    target_ = &*cloud;
+    target_from_map_ = false;
+  }
+  // the target is the nn cloud OctreeMap::approxNearestNeighbors just left in HBM: skips one host round trip
+  void setInputTargetFromMap() { target_from_map_ = true; }
 
   int getMaximumIterations() const { return params_.max_iterations; }
   double getTransformationEpsilon() const { return params_.transformation_epsilon; }
@@ -130,11 +135,14 @@ class IterativeClosestPoint {
   void align_impl(CloudT& output, const float* guess) {
     aligned_ = false;
     result_.converged = 0;
-    if (!source_ || !target_) return;  // PCL: initCompute() fails, align returns, converged_ stays false
+    if (!source_ || (!target_ && !target_from_map_)) return;  // PCL: initCompute() fails, align returns, converged_ stays false
     if (icpgpu_set_params(ctx_, &params_) != ICPGPU_OK) return;
-    const std::size_t ns = source_->points.size(), nt = target_->points.size();
+    const std::size_t ns = source_->points.size();
     if (icpgpu_set_source(ctx_, ns ? reinterpret_cast<const float*>(&source_->points[0]) : nullptr, ns) != ICPGPU_OK) return;
-    if (icpgpu_set_target(ctx_, nt ? reinterpret_cast<const float*>(&target_->points[0]) : nullptr, nt) != ICPGPU_OK) return;
+    if (!target_from_map_) {
+      const std::size_t nt = target_->points.size();
+      if (icpgpu_set_target(ctx_, nt ? reinterpret_cast<const float*>(&target_->points[0]) : nullptr, nt) != ICPGPU_OK) return;
+    }
     output.points.resize(ns);
     float* out = ns ? reinterpret_cast<float*>(&output.points[0]) : nullptr;
     if (icpgpu_align(ctx_, guess, out, 0, &result_) != ICPGPU_OK) {
@@ -151,6 +159,7 @@ class IterativeClosestPoint {
   const CloudT* target_ = nullptr;
   int ransac_iterations_ = 0;
   bool aligned_ = false;
+  bool target_from_map_ = false;
 };
 
 // pcl::VoxelGrid<PointT>-shaped front end for the odometer's pre-step
@@ -181,6 +190,50 @@ class VoxelGrid {
   icpgpu_ctx* ctx_;
   const CloudT* input_ = nullptr;
   float leaf_ = 0.1f;
+};
+
+// The mapper's map (/root/reference/src/icpslam/octree_mapper.cpp:55-90): replaces the pair
+//   pcl::octree::OctreePointCloudSearch<pcl::PointXYZ>::Ptr map_octree_;  pcl::PointCloud<pcl::PointXYZ>::Ptr map_cloud_;
+// Poses are the float 4x4 that pcl_ros::transformPointCloud applies (icpgpu_pose_to_matrix gives it for a Pose6DOF);
+// the transform of transformCloudToPoseFrame is fused into both calls, so the mapper passes the scan in the robot frame.
+template <class CloudT>
+class OctreeMap {
+ public:
+  explicit OctreeMap(double resolution, int device = 0) : ctx_(detail::thread_context(device)), resolution_(resolution) { resetMap(); }
+  void resetMap() { icpgpu_map_reset(ctx_, resolution_); }                                     // :55-59
+  std::size_t addPointsToMap(const CloudT& cloud, const Matrix4& pose) {                         // :62-69 (+ :135, :152)
+    std::size_t added = 0;
+    const std::size_t n = cloud.points.size();
+    icpgpu_map_add_points(ctx_, n ? reinterpret_cast<const float*>(&cloud.points[0]) : nullptr, n, pose.data(), &added);
+    return added;
+  }
+  // :72-90 followed by the transform back at :146.  nearest_neighbors receives the nn cloud; it also stays in HBM as
+  // the registration target (IterativeClosestPoint::setInputTargetFromMap).  Exact nearest neighbours.
+  bool approxNearestNeighbors(const CloudT& cloud, const Matrix4& pose, const Matrix4& pose_inv, CloudT& nearest_neighbors) {
+    const std::size_t n = cloud.points.size();
+    nearest_neighbors.points.resize(n);
+    std::size_t m = 0;
+    if (icpgpu_set_source(ctx_, n ? reinterpret_cast<const float*>(&cloud.points[0]) : nullptr, n) != ICPGPU_OK ||
+        icpgpu_map_nn_target(ctx_, pose.data(), pose_inv.data(), n ? reinterpret_cast<float*>(&nearest_neighbors.points[0]) : nullptr,
+                             &m) != ICPGPU_OK)
+      m = 0;
+    nearest_neighbors.points.resize(m);
+    return m > 0;
+  }
+  std::size_t size() const {
+    std::size_t n = 0;
+    icpgpu_map_size(ctx_, &n);
+    return n;
+  }
+  void getMapCloud(CloudT& out) const {  // map_cloud_ for the publisher at :155
+    std::size_t n = size(), m = 0;
+    out.points.resize(n);
+    if (icpgpu_map_get_points(ctx_, n ? reinterpret_cast<float*>(&out.points[0]) : nullptr, n, &m) != ICPGPU_OK) out.points.resize(0);
+  }
+
+ private:
+  icpgpu_ctx* ctx_;
+  double resolution_;
 };
 
 }  // namespace icpgpu

@@ -11,11 +11,11 @@ from icpslam_amd import _lib, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build_demo(tmp_path):
-    exe = tmp_path / "shim_demo"
+def _build_demo(tmp_path, name="shim_demo"):
+    exe = tmp_path / name
     libdir = os.path.dirname(_lib.LIB_PATH)
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"), "-o", str(exe), "-L", libdir, "-licpgpu",
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", str(exe), "-L", libdir, "-licpgpu",
                            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
@@ -53,3 +53,49 @@ def test_shim_matches_oracle(built, tmp_path):
     assert abs(fit - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
     c = ref["cloud"].astype(np.float64)
     assert abs(float(vals[19]) - (c[:, 0] + 2 * c[:, 1] + 3 * c[:, 2] + c[:, 3]).sum()) <= 1e-2
+
+
+def _run_map(exe, tmp_path, scan0, scan1, pose, pose_inv):
+    a, b = tmp_path / "s0.bin", tmp_path / "s1.bin"
+    scan0.tofile(a)
+    scan1.tofile(b)
+    cm = lambda M: [repr(float(v)) for v in np.asarray(M, np.float32).T.reshape(-1)]  # column-major
+    return subprocess.run([str(exe), str(a), str(scan0.shape[0]), str(b), str(scan1.shape[0])] + cm(pose) + cm(pose_inv),
+                          capture_output=True, text=True)
+
+
+def test_map_shim_compiles_and_fails_loudly_without_gpu(built, tmp_path):
+    import torch
+    exe = _build_demo(tmp_path, "map_demo")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    s0, s1, T = synth.make_pair(100, 100, seed=1)
+    r = _run_map(exe, tmp_path, s0, s1, T, np.linalg.inv(T))
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_map_shim_matches_oracle(built, tmp_path):
+    """octree_mapper.cpp:133-172 through the C++ shim (OctreeMap + IterativeClosestPoint::setInputTargetFromMap)."""
+    exe = _build_demo(tmp_path, "map_demo")
+    scan1, scan0, Tgt = synth.make_pair(20000, 20000, seed=7)      # scan1 (source) sits at Tgt in scan0's frame
+    pose = Tgt.astype(np.float64).copy()
+    pose[:3, 3] += (0.1, -0.05, 0.0)                                # raw odometry with an error
+    pose = pose.astype(np.float32)
+    pose_inv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+    r = _run_map(exe, tmp_path, scan0, scan1, pose, pose_inv)
+    assert r.returncode == 0, r.stderr
+    v = r.stdout.split()
+    ref = oracle.VoxelMap(0.5)
+    ref.add_points(scan0, np.eye(4))
+    assert int(v[0]) == len(ref)
+    nn = ref.nn_cloud(scan1, pose, pose_inv)
+    assert int(v[1]) == nn.shape[0]
+    o = oracle.icp_align(scan1, nn, oracle.default_params(max_iterations=30))
+    assert int(v[2]) == int(o["converged"]) and int(v[3]) == o["iterations"]
+    T = np.array([float(x) for x in v[4:20]]).reshape(4, 4).T
+    assert np.abs(T[:3, :3] - o["T"][:3, :3]).max() <= 1e-4 and np.linalg.norm(T[:3, 3] - o["T"][:3, 3]) <= 1e-3
+    ref.add_points(scan1, pose)
+    assert int(v[20]) == len(ref)
+    c = nn.astype(np.float64)
+    assert abs(float(v[21]) - (c[:, 0] + 2 * c[:, 1] + 3 * c[:, 2] + c[:, 3]).sum()) <= 1e-2
