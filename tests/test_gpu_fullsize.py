@@ -1,0 +1,121 @@
+"""Parity at BASELINE.json's full sizes (200k x 200k headline, config 3: 200k scan vs 1M-point submap, config 2: 50k x 50k
+with 30 iterations): directly against the oracle (it finishes these in seconds) and through size-independent properties
+(known answer, grid == brute force bit for bit, permutation invariance, rigid equivariance)."""
+import numpy as np
+import pytest
+
+import oracle
+from icpslam_amd import NN_BRUTE, NN_GRID, synth
+
+pytestmark = pytest.mark.gpu
+
+R_TOL, T_TOL = 1e-4, 1e-3    # BASELINE.json: transforms within 1e-4 (R) / 1e-3 m (t)
+
+
+def _close(Ta, Tb):
+    return np.abs(Ta[:3, :3] - Tb[:3, :3]).max() <= R_TOL and np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]) <= T_TOL
+
+
+@pytest.fixture(scope="module")
+def pair200k():
+    return synth.make_pair(200000, 200000, seed=4)
+
+
+@pytest.fixture(scope="module")
+def scan_vs_submap():
+    return synth.make_scan_vs_submap(200000, 1000000, seed=3)
+
+
+def test_headline_pair_matches_oracle(ctx, pair200k):
+    src, tgt, _ = pair200k
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=10), want_fitness=True)
+    ctx.set_params(ctx.default_params(), max_iterations=10)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    r = ctx.align(want_fitness=True)
+    assert r["iterations"] == ref["iterations"] and r["n_corr"] == ref["n_corr"] and r["converged"] == ref["converged"]
+    assert _close(r["T"], ref["T"])
+    assert abs(r["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+
+
+def test_headline_pair_grid_keys_equal_brute_force_and_oracle(ctx, pair200k):
+    src, tgt, Tgt = pair200k
+    out = {}
+    for mode in (NN_GRID, NN_BRUTE):
+        ctx.set_params(ctx.default_params(), nn_mode=mode)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        out[mode] = ctx.nn(Tgt)
+    assert np.array_equal(out[NN_GRID][0], out[NN_BRUTE][0])
+    assert np.array_equal(out[NN_GRID][1].view(np.uint32), out[NN_BRUTE][1].view(np.uint32))
+    io, do = oracle.nn(src, tgt, Tgt)
+    assert np.array_equal(out[NN_GRID][0], io) and np.array_equal(out[NN_GRID][1].view(np.uint32), do.view(np.uint32))
+
+
+def test_known_answer_200k(ctx):
+    src, tgt, Tgt = synth.make_known_answer_pair(200000, seed=9)
+    # the reference's epsilon (1e-6 on cos(angle)) stops a dense cloud ~1e-3 rad short of the fixed point; a known-answer
+    # check wants the fixed point itself, where every correspondence is the point's own image
+    ctx.set_params(ctx.default_params(), max_iterations=300, transformation_epsilon=1e-14)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    r = ctx.align(want_fitness=True)
+    assert r["converged"] and _close(r["T"], Tgt)
+    assert np.abs(r["T"][:3, :3] - Tgt[:3, :3]).max() <= 1e-5 and np.linalg.norm(r["T"][:3, 3] - Tgt[:3, 3]) <= 1e-4
+    assert r["fitness"] < 1e-6 and r["n_corr"] == 200000
+
+
+def test_permutation_invariance_and_rigid_equivariance_200k(ctx, pair200k):
+    src, tgt, _ = pair200k
+    ctx.set_params(ctx.default_params(), max_iterations=10)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    base = ctx.align()
+    rng = np.random.default_rng(0)
+    ctx.set_source(src[rng.permutation(src.shape[0])])
+    ctx.set_target(tgt[rng.permutation(tgt.shape[0])])
+    perm = ctx.align()
+    assert perm["iterations"] == base["iterations"] and perm["n_corr"] == base["n_corr"]
+    assert np.abs(perm["T"] - base["T"]).max() <= 1e-6
+    # a common rigid motion M of both clouds conjugates the answer: T' = M T M^-1 (up to the float rounding of M * cloud)
+    M = synth.pose_matrix(3.0, -2.0, 0.5, 0.02, -0.01, 0.7).astype(np.float64)
+    mv = lambda c: np.hstack([(c[:, :3].astype(np.float64) @ M[:3, :3].T + M[:3, 3]).astype(np.float32), c[:, 3:]])
+    ctx.set_source(mv(src))
+    ctx.set_target(mv(tgt))
+    moved = ctx.align()
+    want = M @ base["T"].astype(np.float64) @ np.linalg.inv(M)
+    assert np.abs(moved["T"][:3, :3] - want[:3, :3]).max() <= R_TOL
+    assert np.linalg.norm(moved["T"][:3, 3] - want[:3, 3]) <= T_TOL
+    assert abs(moved["n_corr"] - base["n_corr"]) <= 1e-3 * base["n_corr"]
+
+
+def test_config3_scan_vs_1m_submap(ctx, scan_vs_submap):
+    src, tgt, _ = scan_vs_submap
+    assert src.shape[0] == 200000 and tgt.shape[0] == 1000000
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=30), want_fitness=True)
+    ctx.set_params(ctx.default_params(), max_iterations=30)     # octree_mapper.h:56
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    r = ctx.align(want_fitness=True)
+    assert r["iterations"] == ref["iterations"] and r["n_corr"] == ref["n_corr"] and r["converged"] == ref["converged"]
+    assert _close(r["T"], ref["T"])
+    assert abs(r["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+    # the (density-adapted) grid returns the brute-force kernel's keys bit for bit
+    keys = {}
+    for mode in (NN_GRID, NN_BRUTE):
+        ctx.set_params(nn_mode=mode)
+        keys[mode] = ctx.nn(r["T"])
+    assert np.array_equal(keys[NN_GRID][0], keys[NN_BRUTE][0])
+    assert np.array_equal(keys[NN_GRID][1].view(np.uint32), keys[NN_BRUTE][1].view(np.uint32))
+
+
+def test_config2_50k_30_iterations(ctx):
+    src, tgt, _ = synth.make_pair(50000, 50000, seed=2)
+    p = oracle.default_params(max_iterations=30, force_iterations=1, transformation_epsilon=0.0)
+    ref = oracle.icp_align(src, tgt, p, want_trace=True)
+    ctx.set_params(ctx.default_params(), max_iterations=30, force_iterations=1, transformation_epsilon=0.0)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    r = ctx.align()
+    assert r["iterations"] == ref["iterations"] == 30 and r["n_corr"] == ref["n_corr"]
+    assert _close(r["T"], ref["T"])
