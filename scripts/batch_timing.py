@@ -7,7 +7,8 @@ n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 base = [synth.make_pair(n, n, seed=1000 + k)[:2] for k in range(8)]
 pairs = [base[k % 8] for k in range(n_pairs)]
-for workers in (1, 2, 4, 8):
+wlist = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (1, 2, 4, 8)
+for workers in wlist:
     os.environ["ICPGPU_BATCH_WORKERS"] = str(workers)
     with Context(0) as ctx:
         ctx.set_params(ctx.default_params(), max_iterations=10)
