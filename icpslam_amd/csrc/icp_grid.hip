@@ -199,13 +199,16 @@ __global__ __launch_bounds__(256) void grid_scatter_kernel(const float4* __restr
                                                            const int* __restrict__ cell_of_point,
                                                            const int* __restrict__ rank,
                                                            const int* __restrict__ cell_start,
+                                                           const int* __restrict__ orig_index,
                                                            float4* __restrict__ sorted) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int c = cell_of_point[i];
   if (c < 0) return;
   const float4 p = pts[i];
-  sorted[cell_start[c] + rank[i]] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+  // the index a search reports: the point's own, or (a grid over the DISTINCT points of a cloud with repeats) the index
+  // of its first occurrence in the full cloud
+  sorted[cell_start[c] + rank[i]] = make_float4(p.x, p.y, p.z, __int_as_float(orig_index ? orig_index[i] : i));
 }
 
 // ---- correspondence search over the grid --------------------------------------------------------------------------
@@ -349,15 +352,15 @@ hipError_t launch_grid_count(const float4* pts, int n, const GridDesc& g, int* c
 }
 
 hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const int* cell_of_point,
-                              const int* rank_in_cell, int* counts, int* block_sums, int* d_stats, float4* sorted,
-                              hipStream_t stream) {
+                              const int* rank_in_cell, int* counts, int* block_sums, int* d_stats, const int* orig_index,
+                              float4* sorted, hipStream_t stream) {
   const int ncells = g.nx * g.ny * g.nz;
   const int nb = (ncells + kScanItems - 1) / kScanItems;
   hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, block_sums, nb, d_stats);
   hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, counts, ncells, block_sums, d_stats);
   if (n > 0)
     hipLaunchKernelGGL(grid_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, cell_of_point,
-                       rank_in_cell, counts, sorted);
+                       rank_in_cell, counts, orig_index, sorted);
   return hipGetLastError();
 }
 

@@ -84,9 +84,10 @@ void decode_bbox(const int enc[6], float lo[3], float hi[3]);  // host
 // population, [2..3] u64 sum of squared populations, [4] binned points (valid after count).
 hipError_t launch_grid_count(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
                              int* counts_then_start, int* block_sums, int* d_stats, hipStream_t stream);
+// orig_index (nullable): sorted[].w carries orig_index[i] instead of i (see icpgpu_map_nn_target)
 hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const int* cell_of_point,
                               const int* rank_in_cell, int* counts_then_start, int* block_sums, int* d_stats,
-                              float4* sorted, hipStream_t stream);
+                              const int* orig_index, float4* sorted, hipStream_t stream);
 
 // Exact NN of T*src[i] among the grid's points, guaranteed whenever the NN lies within the cutoff the grid was built
 // for; otherwise the point is reported unmatched (empty key).  One wave per query (see icp_grid.hip).
@@ -137,6 +138,12 @@ hipError_t launch_map_insert(const float4* in, int n, const Xform& T, const MapD
 // nn cloud: out = T_out * map[index(keys[i])] for every non-empty key, order preserved; *d_n_out = points written
 hipError_t launch_map_nn_gather(const unsigned long long* keys, int n, const float4* map_pts, const Xform& T_out, int* flags,
                                 int* rank, void* temp, size_t temp_bytes, float4* out, int* d_n_out, hipStream_t stream);
+// The nn cloud repeats every map point once per scan point that chose it.  uniq / uniq_index receive its DISTINCT points
+// (first occurrences, in nn-cloud order) and their positions in the nn cloud; first_user is n_map ints of scratch,
+// uflags / urank n ints each.  flags / rank are the arrays launch_map_nn_gather left behind.
+hipError_t launch_map_nn_unique(const unsigned long long* keys, const int* flags, const int* rank, int n, const float4* nn_cloud,
+                                int n_map, int* first_user, int* uflags, int* urank, void* temp, size_t temp_bytes,
+                                float4* uniq, int* uniq_index, int* d_n_uniq, hipStream_t stream);
 
 // ---- voxel-grid down-sampling (icp_voxel.hip), SURVEY.md 8(f2) -------------------------------------------------
 size_t voxel_temp_bytes(int n);

@@ -160,6 +160,37 @@ __global__ __launch_bounds__(256) void map_nn_gather_kernel(const unsigned long 
   if (i == n - 1) *n_out = rank[i] + flags[i];
 }
 
+// distinct points of the nn cloud: a map point's first user (lowest scan index) represents it
+__global__ __launch_bounds__(256) void map_first_user_kernel(const unsigned long long* __restrict__ keys,
+                                                             const int* __restrict__ flags, int n,
+                                                             int* __restrict__ first_user) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && flags[i]) atomicMin(&first_user[(unsigned int)keys[i]], i);
+}
+
+__global__ __launch_bounds__(256) void map_unique_flag_kernel(const unsigned long long* __restrict__ keys,
+                                                              const int* __restrict__ flags, int n,
+                                                              const int* __restrict__ first_user,
+                                                              int* __restrict__ uflags) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) uflags[i] = (flags[i] && first_user[(unsigned int)keys[i]] == i) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void map_unique_gather_kernel(const int* __restrict__ uflags, const int* __restrict__ urank,
+                                                                const int* __restrict__ rank, int n,
+                                                                const float4* __restrict__ nn_cloud,
+                                                                float4* __restrict__ uniq, int* __restrict__ uniq_index,
+                                                                int* __restrict__ n_uniq) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (uflags[i]) {
+    const int pos = rank[i];  // position of scan point i's neighbour in the nn cloud
+    uniq[urank[i]] = nn_cloud[pos];
+    uniq_index[urank[i]] = pos;
+  }
+  if (i == n - 1) *n_uniq = urank[i] + uflags[i];
+}
+
 }  // namespace
 
 size_t map_scan_temp_bytes(int n) {
@@ -203,6 +234,22 @@ hipError_t launch_map_nn_gather(const unsigned long long* keys, int n, const flo
   hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, flags, rank, 0, (size_t)n, rocprim::plus<int>(), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(map_nn_gather_kernel, grid, block, 0, stream, keys, flags, rank, n, map_pts, T_out, out, d_n_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_map_nn_unique(const unsigned long long* keys, const int* flags, const int* rank, int n, const float4* nn_cloud,
+                                int n_map, int* first_user, int* uflags, int* urank, void* temp, size_t temp_bytes,
+                                float4* uniq, int* uniq_index, int* d_n_uniq, hipStream_t stream) {
+  if (n <= 0 || n_map <= 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(first_user, 0x7F, (size_t)n_map * sizeof(int), stream);  // 0x7F7F7F7F: larger than any index
+  if (e != hipSuccess) return e;
+  const dim3 grid((n + 255) / 256), block(256);
+  hipLaunchKernelGGL(map_first_user_kernel, grid, block, 0, stream, keys, flags, n, first_user);
+  hipLaunchKernelGGL(map_unique_flag_kernel, grid, block, 0, stream, keys, flags, n, first_user, uflags);
+  e = rocprim::exclusive_scan(temp, temp_bytes, uflags, urank, 0, (size_t)n, rocprim::plus<int>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(map_unique_gather_kernel, grid, block, 0, stream, uflags, urank, rank, n, nn_cloud, uniq, uniq_index,
+                     d_n_uniq);
   return hipGetLastError();
 }
 

@@ -66,6 +66,8 @@ struct VoxelMap {
   unsigned int cap = 0;   // hash-set capacity (power of two, load <= 1/2)
   Cloud pts;              // the map cloud (owned)
   DeviceBuf keys, vals, first, staged, moved, slot_of, flags, rank, temp, counter, nn_keys;
+  DeviceBuf first_user, uflags, urank, uniq_index;
+  Cloud uniq;             // the distinct points of the last nn cloud (what the ICP target's grid is built from)
   GridIndex grid;         // for the nn-cloud search
 };
 
@@ -219,6 +221,11 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
   return ICPGPU_OK;
 }
 
+static double sparse_population() {  // ICPGPU_SPARSE_POP overrides (tuning experiments only)
+  static const double v = [] { const char* e = std::getenv("ICPGPU_SPARSE_POP"); return e ? std::atof(e) : 2.5; }();
+  return v;
+}
+
 // cells per cutoff; 4 unless ICPGPU_GRID_DIV overrides it (tuning experiments only)
 static double grid_divisor() {
   static const double d = [] {
@@ -231,7 +238,8 @@ static double grid_divisor() {
 
 // (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
 // cannot help (no finite point, one cell holding > kMaxCellPopulation points).
-int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G) {
+int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
+               const int* orig_index = nullptr) {
   const int n_t = (int)cloud.n;
   const float cutoff = (float)cut;
   if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;
@@ -259,6 +267,7 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
   double h = cut / grid_divisor();
   GridDesc g;
   long long ncells = 0;
+  bool shrunk = false;
   for (int attempt = 0;; ++attempt) {
     long long nx, ny, nz;
     for (;;) {
@@ -307,8 +316,15 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
       const double h_new = std::max(h * std::sqrt(kTargetCellPopulation / pop), cut / 16.0);
       if (h_new < 0.9 * h) {
         h = h_new;
+        shrunk = true;
         continue;
       }
+    }
+    // ... and a sparse target (one point per 0.5 m voxel: the mapper's nn cloud, a voxel-filtered scan) gets cells of
+    // twice the size: neighbours are then typically farther than h/2 and would fall through the octant stage
+    if (attempt <= 1 && !shrunk && adapt && binned > 0 && pop < sparse_population() && 2.0 * h <= cut) {
+      h *= 2.0;
+      continue;
     }
     G.n_binned = binned;
     G.max_pop = c->h_ints[7];
@@ -319,7 +335,7 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
   if ((rc = ensure(c, G.sorted, (size_t)n_t * sizeof(float4)))) return rc;
   HIP_TRY(c, launch_grid_finish(cloud.data(), n_t, g, static_cast<const int*>(G.cell_of_point.ptr),
                                 static_cast<const int*>(G.rank.ptr), static_cast<int*>(G.cell_start.ptr),
-                                static_cast<int*>(G.block_sums.ptr), d_ints + 6, static_cast<float4*>(G.sorted.ptr), c->stream));
+                                static_cast<int*>(G.block_sums.ptr), d_ints + 6, orig_index, static_cast<float4*>(G.sorted.ptr), c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;
@@ -989,7 +1005,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->idx);
   release(c->d2);
   for (DeviceBuf* b : {&c->map.pts.buf, &c->map.keys, &c->map.vals, &c->map.first, &c->map.staged, &c->map.moved, &c->map.slot_of,
-                       &c->map.flags, &c->map.rank, &c->map.temp, &c->map.counter, &c->map.nn_keys})
+                       &c->map.flags, &c->map.rank, &c->map.temp, &c->map.counter, &c->map.nn_keys, &c->map.first_user,
+                       &c->map.uflags, &c->map.urank, &c->map.uniq_index, &c->map.uniq.buf})
     release(*b);
   for (GridIndex* G : {&c->grid, &c->src_grid, &c->map.grid}) {
     release(G->sorted);
@@ -1504,6 +1521,32 @@ int icpgpu_map_nn_target(icpgpu_ctx* c, const float* pose, const float* pose_inv
   c->prof.map_nn_ms += ms;
   const int m = c->h_ints[0];
   c->tgt.n = (size_t)m;
+  // The nn cloud repeats every chosen map point ~30x (0.5 m voxels, 200k-point scans).  Repeats add nothing to a nearest-
+  // neighbour search but make every cell of the target's grid 30x denser, so the grid for the coming align is built here
+  // from the DISTINCT points, each carrying the index of its first occurrence in the nn cloud -- exactly the index the
+  // lowest-index tie-break would report on the full cloud.  (A later change of the correspondence gate simply rebuilds
+  // the grid from the full cloud.)
+  const int mode = c->params.nn_mode;
+  const float thr = threshold_from(c->params.max_correspondence_distance * c->params.max_correspondence_distance);
+  const double cut = std::sqrt((double)thr) * (1.0 + 1e-6);
+  if (m > 0 && (mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && (size_t)m >= kGridMinTarget)) && thr > 0.f && std::isfinite(cut) &&
+      cut <= 1e6) {
+    if ((rc = ensure(c, M.first_user, (size_t)M.n * sizeof(int)))) return rc;
+    if ((rc = ensure(c, M.uflags, (size_t)n_s * sizeof(int)))) return rc;
+    if ((rc = ensure(c, M.urank, (size_t)n_s * sizeof(int)))) return rc;
+    if ((rc = ensure(c, M.uniq_index, (size_t)n_s * sizeof(int)))) return rc;
+    if ((rc = ensure(c, M.uniq.buf, (size_t)n_s * sizeof(float4)))) return rc;
+    HIP_TRY(c, launch_map_nn_unique(keys, static_cast<const int*>(M.flags.ptr), static_cast<const int*>(M.rank.ptr), n_s,
+                                    static_cast<const float4*>(c->tgt.buf.ptr), M.n, static_cast<int*>(M.first_user.ptr),
+                                    static_cast<int*>(M.uflags.ptr), static_cast<int*>(M.urank.ptr), M.temp.ptr, temp_bytes,
+                                    static_cast<float4*>(M.uniq.buf.ptr), static_cast<int*>(M.uniq_index.ptr), d_count + 1, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    M.uniq.n = (size_t)c->h_ints[0];
+    M.uniq.set = true;
+    c->grid.built = false;
+    if ((rc = build_grid(c, M.uniq, c->tgt_version, cut, /*adapt=*/true, c->grid, static_cast<const int*>(M.uniq_index.ptr)))) return rc;
+  }
   if (nn_out_xyzw && m > 0) {
     HIP_TRY(c, hipMemcpyAsync(nn_out_xyzw, c->tgt.buf.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

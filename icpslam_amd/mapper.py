@@ -61,6 +61,7 @@ class OctreeMapper:
 
     # octree_mapper.cpp:72-90 + the transform back into the robot frame at :146; the result is the ICP target
     def approxNearestNeighbors(self, cloud, raw_pose: Pose, want_cloud: bool = True):
+        self.ctx.set_params(self.ctx.default_params(), **self._icp)   # the target's search index is built for this gate
         self.ctx.set_source(cloud)
         return self.ctx.map_nn_target(pose_to_matrix(raw_pose), pose_to_matrix(pose_inverse(raw_pose)), want_cloud=want_cloud)
 
