@@ -150,12 +150,14 @@ def main():
     # the brute-force kernel (north_star's design) measured in the same process for its own roofline line
     brute = None
     if rank == 0:
+        ctx.profile_sampling(1)                    # 4 launches only: time every one of them
         ctx.set_params(nn_mode=NN_BRUTE, max_iterations=2)
         ctx.align()
         ctx.profile_reset()
         ctx.align()
         pb = ctx.profile()
-        brute = {"avg_launch_ms": pb.nn_ms / max(1, pb.nn_launches), "launches": int(pb.nn_launches)}
+        brute = {"avg_launch_ms": pb.nn_ms / max(1, pb.nn_timed), "launches": int(pb.nn_launches)}
+        ctx.profile_sampling(7)
         ctx.set_params(nn_mode=nn_mode, max_iterations=a.iters)
 
     if rank == 0:
@@ -183,19 +185,20 @@ def main():
             "note": "brute-force NN is FP32-compute-bound (8*Ns*Nt flop per launch); peak = f32 dense MFMA peak = f32 "
                     "vector peak (157.3 TFLOP/s)"}
         if used_grid:
-            g_ms = prof.grid_ms / max(1, prof.grid_launches)
+            g_ms = prof.grid_ms / max(1, prof.grid_timed)
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
             roofline = {
                 "kernel": "nn_wave_kernel<fused> (uniform-grid exact NN + rejection + 17-term reduction)",
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic.get("nn_grid_hbm_bytes_per_launch"), "avg_launch_ms": g_ms,
-                "launches": int(prof.grid_launches), "algorithmic_bytes_per_launch": alg_bytes_fused,
+                "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
+                "algorithmic_bytes_per_launch": alg_bytes_fused,
                 "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
                         "(SURVEY.md 8(d) fused lower bound); an exact NN search is bound by L2 transactions and instruction issue "
                         "(PMC: TCC ~74 % busy), not by HBM streaming -- DESIGN.md section 5",
                 "brute_force_kernel": brute_roofline}
         else:
-            nn_ms = prof.nn_ms / max(1, prof.nn_launches)
+            nn_ms = prof.nn_ms / max(1, prof.nn_timed)
             tf = flops / (nn_ms * 1e-3) / 1e12
             roofline = dict(brute_roofline, achieved=tf, frac=tf / FP32_PEAK_TFLOPS, avg_launch_ms=nn_ms,
                             launches=int(prof.nn_launches))
@@ -222,7 +225,7 @@ def main():
                              "(target index reused; set_target + index build are outside)",
             "iterations_timed": iters_done,
             "roofline": roofline,
-            "reduce_kernel": {"avg_ms": prof.reduce_ms / max(1, prof.reduce_launches)},
+            "reduce_kernel": {"avg_ms": prof.reduce_ms / max(1, prof.reduce_timed)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(src, tgt, a.iters, a.cpu_seconds)

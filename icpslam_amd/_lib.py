@@ -38,7 +38,8 @@ class Profile(C.Structure):
                 ("voxel_launches", C.c_uint64), ("voxel_ms", C.c_double), ("voxel_bytes", C.c_uint64),
                 ("gicp_cov_launches", C.c_uint64), ("gicp_cov_ms", C.c_double), ("gicp_cost_launches", C.c_uint64),
                 ("map_inserts", C.c_uint64), ("map_insert_ms", C.c_double), ("map_points_in", C.c_uint64),
-                ("map_nn_launches", C.c_uint64), ("map_nn_ms", C.c_double)]
+                ("map_nn_launches", C.c_uint64), ("map_nn_ms", C.c_double),
+                ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64)]
 
 
 class Pose(C.Structure):
@@ -51,7 +52,7 @@ EXPORTS = [
     "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
     "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
-    "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_get_stream", "icpgpu_synchronize",
+    "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_profile_set_sampling", "icpgpu_get_stream", "icpgpu_synchronize",
     "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
     "icpgpu_pose_from_matrix", "icpgpu_pose_to_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
@@ -134,6 +135,7 @@ def load():
     L.icpgpu_map_nn_target.argtypes = [vp, fp, fp, fp, sp]
     L.icpgpu_profile_reset.argtypes = [vp]
     L.icpgpu_profile_get.argtypes = [vp, C.POINTER(Profile)]
+    L.icpgpu_profile_set_sampling.argtypes = [vp, C.c_int]
     L.icpgpu_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.icpgpu_synchronize.argtypes = [vp]
     for name in EXPORTS:

@@ -111,6 +111,9 @@ struct icpgpu_ctx {
   struct PendingSweep { int slot; bool grid; };
   std::vector<PendingSweep> pending;
   double dev_ms_accum = 0.0;
+  unsigned call_sweeps = 0, call_timed = 0;  // sweeps of the current align call: all / timed
+  int timing_every = 7;       // time one sweep in 7 (coprime with the 10 / 30 iterations of the reference's aligns)
+  unsigned sweep_counter = 0;
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
   bool have_final = false;
   Mat4d final_T = mat4_identity();
@@ -422,9 +425,15 @@ int resolve_sweep_timings(icpgpu_ctx* c) {
     hipEvent_t* e = &c->ev_ring[(size_t)p.slot * 3];
     HIP_TRY(c, hipEventElapsedTime(&nn_ms, e[0], e[1]));
     HIP_TRY(c, hipEventElapsedTime(&red_ms, e[1], e[2]));
-    if (p.grid) c->prof.grid_ms += nn_ms;
-    else c->prof.nn_ms += nn_ms;
+    if (p.grid) {
+      c->prof.grid_ms += nn_ms;
+      c->prof.grid_timed += 1;
+    } else {
+      c->prof.nn_ms += nn_ms;
+      c->prof.nn_timed += 1;
+    }
     c->prof.reduce_ms += red_ms;
+    c->prof.reduce_timed += 1;
     c->dev_ms_accum += (double)nn_ms + (double)red_ms;
   }
   c->pending.clear();
@@ -470,7 +479,10 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
   const int slot = (int)c->pending.size();
   hipEvent_t* ev = &c->ev_ring[(size_t)slot * 3];
   const unsigned long long seq = ++c->sums_seq;
-  HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+  // kernel timing is sampled: an event record is a barrier packet on the queue, three of them per sweep cost 6-7 us
+  const bool timed = c->timing_every <= 1 || (c->sweep_counter++ % (unsigned)c->timing_every) == 0;
+#define EVREC(e) do { if (timed) HIP_TRY(c, hipEventRecord((e), c->stream)); } while (0)
+  EVREC(ev[0]);
   if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
     const bool ordered = source_ordered(c);
@@ -482,7 +494,7 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
     HIP_TRY(c, launch_nn_grid_search(src_pts, n_q, ordered, T, static_cast<const float4*>(c->grid.sorted.ptr),
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
                                      nullptr, c->stream));
-    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    EVREC(ev[1]);
     HIP_TRY(c, launch_reduce_final(partials, blocks, d_sums, c->h_flags_dev, seq, c->stream));
   } else {
     if (use_grid) {
@@ -490,16 +502,19 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
     } else {
       const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
       if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-      HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+      EVREC(ev[0]);
       HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, T, plan, keys, c->stream));
     }
-    HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    EVREC(ev[1]);
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
     HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
   }
-  HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-  c->pending.push_back({slot, use_grid});
+  EVREC(ev[2]);
+  if (timed) c->pending.push_back({slot, use_grid});
+  c->call_sweeps += 1;
+  c->call_timed += timed ? 1 : 0;
+#undef EVREC
   if (use_grid) {
     c->prof.grid_launches += 1;
     c->prof.grid_bytes += 16ull * ((uint64_t)n_s + (uint64_t)n_t) + (open_range ? 8ull * (uint64_t)n_s : 136ull * (uint64_t)grid_search_blocks(n_s));
@@ -599,6 +614,7 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
     int rc = resolve_sweep_timings(c);
     if (rc) return rc;
     c->dev_ms_accum = 0.0;
+    c->call_sweeps = c->call_timed = 0;
   }
 
   Mat4d final_T = mat4_identity();
@@ -670,7 +686,7 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   int rc = write_output_cloud(c, Tf, out_xyzw);
   if (rc) return rc;
   if ((rc = resolve_sweep_timings(c))) return rc;
-  res->t_device_ms = c->dev_ms_accum;
+  res->t_device_ms = c->call_timed ? c->dev_ms_accum * (double)c->call_sweeps / (double)c->call_timed : 0.0;
   res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   return ICPGPU_OK;
 }
@@ -881,7 +897,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     c->dev_ms_accum = 0.0;
     if ((rc = nn_and_reduce(c, Tf, FLT_MAX, true))) return rc;
     if ((rc = resolve_sweep_timings(c))) return rc;
-    dev_ms += c->dev_ms_accum;
+    dev_ms += c->dev_ms_accum;  // 0 when this sweep was not a timed one
     res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   }
   if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
@@ -1168,6 +1184,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.transform_launches += p.transform_launches; c->prof.transform_ms += p.transform_ms; c->prof.transform_bytes += p.transform_bytes;
     c->prof.iterations += p.iterations; c->prof.aligns += p.aligns;
     c->prof.grid_launches += p.grid_launches; c->prof.grid_ms += p.grid_ms; c->prof.grid_bytes += p.grid_bytes;
+    c->prof.nn_timed += p.nn_timed; c->prof.grid_timed += p.grid_timed; c->prof.reduce_timed += p.reduce_timed;
     c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
     c->prof.voxel_launches += p.voxel_launches; c->prof.voxel_ms += p.voxel_ms; c->prof.voxel_bytes += p.voxel_bytes;
     c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;
@@ -1559,6 +1576,17 @@ int icpgpu_profile_reset(icpgpu_ctx* c) {
   if (!c) return ICPGPU_ERR_INVALID_ARG;
   (void)resolve_sweep_timings(c);
   std::memset(&c->prof, 0, sizeof(c->prof));
+  return ICPGPU_OK;
+}
+
+int icpgpu_profile_set_sampling(icpgpu_ctx* c, int every) {
+  if (!c || every < 1) return ICPGPU_ERR_INVALID_ARG;
+  c->timing_every = every;
+  c->sweep_counter = 0;
+  for (icpgpu_ctx* w : c->workers) {
+    w->timing_every = every;
+    w->sweep_counter = 0;
+  }
   return ICPGPU_OK;
 }
 

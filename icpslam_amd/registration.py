@@ -243,6 +243,10 @@ class Context:
     def profile_reset(self):
         self._check(self._L.icpgpu_profile_reset(self._h))
 
+    def profile_sampling(self, every: int):
+        """Time one correspondence sweep in `every` (library default 7; 1 = all of them, at 6-7 us per iteration)."""
+        self._check(self._L.icpgpu_profile_set_sampling(self._h, int(every)))
+
     def profile(self) -> Profile:
         p = Profile()
         self._check(self._L.icpgpu_profile_get(self._h, C.byref(p)))

@@ -94,14 +94,15 @@ typedef struct {
   double mse_last;            /* mean squared correspondence distance of the last iteration (m^2) */
   double fitness;             /* getFitnessScore(): icp_odometer.cpp:201; NaN unless requested */
   double t_total_ms;          /* host wall time of the align call */
-  double t_device_ms;         /* HIP-event time of all kernels of the call on the context's stream */
+  double t_device_ms;         /* kernel time of the call on the context's stream: HIP-event time of the TIMED sweeps
+                               * (icpgpu_profile_set_sampling), scaled to all sweeps of the call */
 } icpgpu_result;
 
 /* Kernel-level accounting since the last icpgpu_profile_reset(); times are HIP-event times on the
  * context's own stream (this is what bench.py's roofline object is computed from). */
 typedef struct {
   uint64_t nn_launches;       /* brute-force correspondence-search launches (a2) */
-  double nn_ms;               /* their summed duration */
+  double nn_ms;               /* summed duration of the TIMED ones (nn_timed of them, see icpgpu_profile_set_sampling) */
   uint64_t nn_pairs;          /* point pairs evaluated by those launches */
   uint64_t nn_bytes;          /* algorithmic bytes: 16*(N_s+N_t) + 8*N_s per launch */
   uint64_t reduce_launches;   /* rejection + covariance reduction launches (a3+a4) */
@@ -129,6 +130,9 @@ typedef struct {
   uint64_t map_points_in;     /* points offered to the map */
   uint64_t map_nn_launches;   /* f4: nn-cloud builds */
   double map_nn_ms;
+  uint64_t nn_timed;          /* launches behind nn_ms / grid_ms / reduce_ms: kernel timing is sampled, because the three */
+  uint64_t grid_timed;        /*   event records around a sweep are barrier packets that cost 6-7 us per iteration */
+  uint64_t reduce_timed;
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -268,6 +272,9 @@ int icpgpu_posegraph_get_edge(const icpgpu_posegraph* g, long new_kf, icpgpu_pos
 int icpgpu_posegraph_write_g2o(const icpgpu_posegraph* g, const char* path);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
+/* time one correspondence sweep in `every` (default 7, coprime with the reference's 10 / 30 iterations; 1 = every sweep).
+ * Average kernel durations are *_ms / *_timed. */
+int icpgpu_profile_set_sampling(icpgpu_ctx* ctx, int every);
 int icpgpu_profile_reset(icpgpu_ctx* ctx);
 int icpgpu_profile_get(icpgpu_ctx* ctx, icpgpu_profile* out);
 /* stream handle (hipStream_t as void*) so a host can order its own work against the context. */

@@ -16,4 +16,4 @@ with Context(0) as ctx:
             ctx.align(); ctx.profile_reset()
             for _ in range(5): ctx.align()
             p = ctx.profile()
-            print(f"{name} leaf={leaf}: n_s={len(s2)} n_t={len(t2)} NN kernel {p.grid_ms/max(1,p.grid_launches)*1e3:.1f} us/iter ({p.grid_launches} grid launches, {p.nn_launches} brute)")
+            print(f"{name} leaf={leaf}: n_s={len(s2)} n_t={len(t2)} NN kernel {p.grid_ms/max(1,p.grid_timed)*1e3:.1f} us/iter ({p.grid_launches} grid launches, {p.nn_launches} brute)")

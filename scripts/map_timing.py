@@ -13,6 +13,7 @@ scene = synth.make_scene(seed=3)
 poses = [synth.pose_matrix(1.0 * k, 0.05 * k, 0.0, 0.0, 0.0, 0.01 * k) for k in range(n_scans)]
 scans = [synth.scan(scene, P, 200000, seed=300 + k) for k, P in enumerate(poses)]
 with Context(0) as ctx:
+    ctx.profile_sampling(1)   # dev tool: time every sweep
     m = OctreeMapper(ctx, octree_resolution=res)
     for k, (s, P) in enumerate(zip(scans, poses)):
         ctx.profile_reset()

@@ -25,7 +25,7 @@ with Context(0) as ctx:
                 r = ctx.align()
             wall = (time.perf_counter() - t0) / n
             p = ctx.profile()
-            k_ms = (p.grid_ms / max(1, p.grid_launches)) if mode == NN_GRID else (p.nn_ms / max(1, p.nn_launches))
+            k_ms = (p.grid_ms / max(1, p.grid_timed)) if mode == NN_GRID else (p.nn_ms / max(1, p.nn_timed))
             print(f"{name:5s} {ns}x{nt}: align(10 it) {wall*1e3:8.3f} ms -> {10/wall:9.1f} it/s | NN kernel {k_ms*1e3:8.1f} us "
                   f"reduce {p.reduce_ms/max(1,p.reduce_launches)*1e3:6.1f} us n_corr {r['n_corr']}", flush=True)
         ctx.set_params(ctx.default_params(), nn_mode=NN_GRID)

@@ -30,7 +30,7 @@ for variant in os.environ.get("VARIANTS", "0,1,2,10,12").split(","):
             for _ in range(n):
                 ctx.nn(np.eye(4))
             p = ctx.profile()
-            ms = p.nn_ms / p.nn_launches
+            ms = p.nn_ms / max(1, p.nn_timed)
             pairs = ns * nt
             print(f"variant {variant:>2} {ns}x{nt}: nn {ms:8.3f} ms  {pairs/ms/1e9:6.2f} Gpair/ms  "
                   f"{8*pairs/ms/1e9:6.1f} TFLOP/s  bitexact_vs_first={same}", flush=True)

@@ -19,4 +19,4 @@ with Context(0) as ctx:
     for _ in range(20): ctx.align()
     wall = (time.perf_counter() - t0) / 20
     p = ctx.profile()
-    print(f"{mode:8s}: align(10) {wall*1e3:.3f} ms, NN kernel {p.grid_ms/p.grid_launches*1e3:.1f} us, reduce {p.reduce_ms/p.reduce_launches*1e3:.1f} us")
+    print(f"{mode:8s}: align(10) {wall*1e3:.3f} ms, NN kernel {p.grid_ms/max(1,p.grid_timed)*1e3:.1f} us, reduce {p.reduce_ms/max(1,p.reduce_timed)*1e3:.1f} us")

@@ -28,4 +28,4 @@ with Context(0) as ctx:
             for _ in range(5): ctx.align(guess=guess)
             wall = (time.perf_counter() - t0) / 5
             p = ctx.profile()
-            print(f"{ns}x{nt} {name:15s}: NN kernel {p.grid_ms/p.grid_launches*1e3:7.1f} us/iter, align(10) {wall*1e3:7.3f} ms", flush=True)
+            print(f"{ns}x{nt} {name:15s}: NN kernel {p.grid_ms/max(1,p.grid_timed)*1e3:7.1f} us/iter, align(10) {wall*1e3:7.3f} ms", flush=True)
