@@ -328,12 +328,12 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
 
 hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                             const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
-                            hipStream_t stream) {
+                            unsigned long long* flags, unsigned long long seq, hipStream_t stream) {
   int blocks = (n_s + 255) / 256;
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials);
-  return launch_reduce_final(partials, blocks, sums_out, nullptr, 0, stream);
+  return launch_reduce_final(partials, blocks, sums_out, flags, seq, stream);
 }
 
 }  // namespace icpgpu

@@ -118,7 +118,7 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
 // sums_out[0..14] = {m, sum r^T M r, sum M r (3), sum (base p)(M r)^T (9), sum d2}; partials: kMaxReduceBlocks x 17
 hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                             const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
-                            hipStream_t stream);
+                            unsigned long long* flags, unsigned long long seq, hipStream_t stream);
 
 // ---- the mapper's one-point-per-voxel map (icp_map.hip), SURVEY.md 8(f4) --------------------------------------------
 struct MapDesc {

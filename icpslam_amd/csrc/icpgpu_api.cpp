@@ -810,12 +810,12 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       float T[16];
       std::memcpy(T, guess, sizeof(T));
       gicp_apply_state(T, x);
+      // ~300 evaluations per align, each a dependent launch: the result comes back through the polled mailbox
+      const unsigned long long seq = ++c->sums_seq;
       if (launch_gicp_cost(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
-                           static_cast<double*>(c->partials.ptr), static_cast<double*>(c->sums.ptr), c->stream) != hipSuccess)
+                           static_cast<double*>(c->partials.ptr), c->h_sums_dev, c->h_flags_dev, seq, c->stream) != hipSuccess)
         return false;
-      if (hipMemcpyAsync(c->h_sums, c->sums.ptr, kReduceTerms * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-        return false;
-      if (hipStreamSynchronize(c->stream) != hipSuccess) return false;
+      if (wait_sums(c, seq) != ICPGPU_OK) return false;
       c->prof.gicp_cost_launches += 1;
       const double* s = c->h_sums;
       m_count = s[0];
