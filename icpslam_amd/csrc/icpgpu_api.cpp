@@ -242,7 +242,7 @@ static double grid_divisor() {
 // (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
 // cannot help (no finite point, one cell holding > kMaxCellPopulation points).
 int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
-               const int* orig_index = nullptr) {
+               const int* orig_index = nullptr, double knn_population = 0.0) {
   const int n_t = (int)cloud.n;
   const float cutoff = (float)cut;
   if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;
@@ -317,6 +317,15 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
     const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
     if (attempt == 0 && adapt && pop > kDenseCellPopulation) {
       const double h_new = std::max(h * std::sqrt(kTargetCellPopulation / pop), cut / 16.0);
+      if (h_new < 0.9 * h) {
+        h = h_new;
+        shrunk = true;
+        continue;
+      }
+    }
+    // k-nearest-neighbour searches (GICP covariances) read whole 3x3x3 cubes: they want only a few points per cell
+    if (attempt == 0 && knn_population > 0.0 && pop > 2.0 * knn_population) {
+      const double h_new = std::max(h * std::sqrt(knn_population / pop), cut / 64.0);
       if (h_new < 0.9 * h) {
         h = h_new;
         shrunk = true;
@@ -717,7 +726,8 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   if (cov_version == version && cov.ptr) return ICPGPU_OK;
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
-  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G);
+  static const double knn_pop = [] { const char* e = std::getenv("ICPGPU_KNN_POP"); return e ? std::atof(e) : 6.0; }();
+  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G, nullptr, knn_pop);
   if (rc) return rc;
   if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
   if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
