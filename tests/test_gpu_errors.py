@@ -1,0 +1,126 @@
+"""The C-ABI's error convention on a real device (include/icpgpu.h): status codes instead of exceptions or aborts,
+non-convergence is not an error (PCL: hasConverged() == false), a context stays usable after a failed call."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from icpslam_amd import GICP, NN_AUTO, NN_GRID, IcpGpuError, _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+ERR_INVALID_ARG, ERR_NO_INPUT = -1, -5
+NO_CORRESPONDENCES = 5          # ICPGPU_CONV_NO_CORRESPONDENCES
+
+
+def _code(exc):
+    return exc.value.code
+
+
+def test_calls_before_inputs_report_no_input_and_context_survives():
+    from icpslam_amd import Context
+    with Context(0) as ctx:
+        for call in (ctx.align, ctx.fitness, lambda: ctx.nn(np.eye(4)), ctx.promote_source_to_target,
+                     lambda: ctx.map_add_points(np.ones((4, 4), np.float32)), lambda: ctx.map_add_source(),
+                     lambda: ctx.map_nn_target(np.eye(4), np.eye(4))):
+            with pytest.raises(IcpGpuError) as e:
+                call()
+            assert _code(e) == ERR_NO_INPUT and str(e.value)
+        src, tgt, _ = synth.make_pair(3000, 3000, seed=1)
+        ctx.set_source(src)
+        with pytest.raises(IcpGpuError) as e:       # target still missing
+            ctx.align()
+        assert _code(e) == ERR_NO_INPUT
+        ctx.set_target(tgt)
+        assert ctx.align()["converged"]              # the same context works after all those failures
+
+
+def test_invalid_arguments(ctx):
+    L = _lib.load()
+    with pytest.raises(IcpGpuError) as e:
+        ctx.set_params(ctx.default_params(), method=7)
+    assert _code(e) == ERR_INVALID_ARG
+    with pytest.raises(IcpGpuError) as e:
+        ctx.set_params(ctx.default_params(), nn_mode=9)
+    assert _code(e) == ERR_INVALID_ARG
+    with pytest.raises(IcpGpuError) as e:
+        ctx.map_reset(0.0)
+    assert _code(e) == ERR_INVALID_ARG
+    with pytest.raises(IcpGpuError) as e:
+        ctx.voxel_grid(np.ones((10, 4), np.float32), -1.0)
+    assert _code(e) == ERR_INVALID_ARG
+    assert L.icpgpu_align(None, None, None, 0, None) == ERR_INVALID_ARG        # null context: code, no crash
+    assert L.icpgpu_set_source(ctx._h, None, C.c_size_t(5)) == ERR_INVALID_ARG  # null cloud with n > 0
+    assert b"null" in L.icpgpu_last_error(ctx._h)
+    with pytest.raises(IcpGpuError) as e:
+        ctx.profile_sampling(0)
+    assert _code(e) == ERR_INVALID_ARG
+
+
+def test_non_convergence_is_not_an_error(ctx):
+    src, tgt, _ = synth.make_pair(3000, 3000, seed=2)
+    ctx.set_params(ctx.default_params())
+    ctx.set_source(src)
+    # empty target: PCL's setInputTarget refuses it, align() returns with converged_ = false and the identity
+    ctx.set_target(np.zeros((0, 4), np.float32))
+    r = ctx.align()
+    assert not r["converged"] and np.array_equal(r["T"], np.eye(4, dtype=np.float32))
+    # empty source: no correspondences
+    ctx.set_source(np.zeros((0, 4), np.float32))
+    ctx.set_target(tgt)
+    r = ctx.align()
+    assert not r["converged"] and r["state"] == NO_CORRESPONDENCES and r["n_corr"] == 0
+    # everything outside the gate: no correspondences either
+    far = src.copy()
+    far[:, :3] += 1000.0
+    ctx.set_source(far)
+    r = ctx.align(want_fitness=True)
+    assert not r["converged"] and r["state"] == NO_CORRESPONDENCES and r["iterations"] == 0
+    assert r["fitness"] > 1e5                       # getFitnessScore has no gate: ~1000 m away, squared
+    # fewer correspondences than PCL's minimum (3)
+    ctx.set_source(src[:2])
+    r = ctx.align()
+    assert not r["converged"] and r["state"] == NO_CORRESPONDENCES
+    # all-NaN source
+    ctx.set_source(np.full((100, 4), np.nan, np.float32))
+    r = ctx.align()
+    assert not r["converged"] and r["n_corr"] == 0
+
+
+def test_gicp_needs_twenty_points(ctx):
+    src, tgt, _ = synth.make_pair(3000, 3000, seed=3)
+    ctx.set_params(ctx.default_params(), method=GICP)
+    ctx.set_source(src[:10])
+    ctx.set_target(tgt)
+    r = ctx.align()       # PCL: computeCovariances gives up below k_correspondences_ points, converged_ stays false
+    assert not r["converged"] and np.array_equal(r["T"], np.eye(4, dtype=np.float32))
+    with pytest.raises(IcpGpuError) as e:           # asked for explicitly, it is an argument error
+        ctx.gicp_covariances(of_target=False)
+    assert _code(e) == ERR_INVALID_ARG and "20" in str(e.value)
+    ctx.set_source(src)
+    assert ctx.align()["iterations"] >= 1
+
+
+@pytest.mark.parametrize("mode", [NN_AUTO, NN_GRID])
+def test_huge_and_degenerate_gates_still_give_the_brute_force_answer(ctx, mode):
+    import oracle
+    src, tgt, _ = synth.make_pair(5000, 5000, seed=4)
+    for gate in (1e9, 1e-4):
+        ctx.set_params(ctx.default_params(), nn_mode=mode, max_correspondence_distance=gate)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        r = ctx.align()
+        o = oracle.icp_align(src, tgt, oracle.default_params(max_correspondence_distance=gate))
+        assert r["iterations"] == o["iterations"] and r["n_corr"] == o["n_corr"] and r["converged"] == o["converged"]
+        if o["n_corr"] >= 3:
+            assert np.abs(r["T"] - o["T"]).max() <= 1e-4
+
+
+def test_map_get_points_capacity_is_checked(ctx):
+    L = _lib.load()
+    ctx.map_reset(0.5)
+    ctx.map_add_points(synth.make_pair(2000, 10, seed=5)[0])
+    n = C.c_size_t()
+    buf = np.zeros((4, 4), np.float32)
+    rc = L.icpgpu_map_get_points(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(4), C.byref(n))
+    assert rc == ERR_INVALID_ARG and n.value == ctx.map_size() > 4
