@@ -972,7 +972,8 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
   // mailbox: 17 sums then 17 flags (kept apart by 64 B so that the flags sit in their own cache lines)
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + kReduceTerms) * sizeof(double), hipHostMallocMapped)) !=
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + kReduceTerms) * sizeof(double),
+                         hipHostMallocMapped | hipHostMallocCoherent)) !=  // fine-grained: the polled flags must become visible without a sync
       hipSuccess)
     return bail("hipHostMalloc", e);
   std::memset(c->h_sums, 0, (24 + kReduceTerms) * sizeof(double));
