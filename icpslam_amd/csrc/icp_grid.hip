@@ -227,7 +227,7 @@ constexpr int WQ_MAX_QPW = 16;  // points per wave (fewer for small clouds so th
 constexpr int WQ_WAVES = 4;
 constexpr int WQ_BLOCK = WQ_WAVES * 64;
 
-template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED>
+template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool PACK_SHORT_ROWS>
 __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
                                                            const float4* __restrict__ sorted,
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
       if (!found) {
         const int cx = __builtin_amdgcn_readlane(lcx, l0), cy = __builtin_amdgcn_readlane(lcy, l0),
                   cz = __builtin_amdgcn_readlane(lcz, l0);
-        found = grow_cubes(sorted, cell_start, g, px, py, pz, cx, cy, cz, lane, b);
+        found = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, px, py, pz, cx, cy, cz, lane, b);
       }
     }
     if constexpr (WRITE_KEYS) {
@@ -378,22 +378,29 @@ int grid_search_blocks(int n_s) {
   return (nb + 7) & ~7;  // a multiple of the 8 XCDs
 }
 
-hipError_t launch_nn_grid_search(const float4* src, int n_s, bool src_in_cell_order, const Xform& T, const float4* sorted,
+hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream) {
   if (n_s <= 0) return hipSuccess;
   const int blocks = grid_search_blocks(n_s);
-  const int qpw = queries_per_wave(n_s), xm = src_in_cell_order ? 1 : 0;
+  const int qpw = queries_per_wave(n_s), xm = flags & kGridSrcInCellOrder;
+  const bool pack = (flags & kGridPackShortRows) != 0;
   dim3 grid(blocks), block(WQ_BLOCK);
-#define ICP_LAUNCH_WQ(K, F, U)                                                                                        \
-  hipLaunchKernelGGL((nn_wave_kernel<K, F, U>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, g, \
+#define ICP_LAUNCH_WQP(K, F, U, P)                                                                                      \
+  hipLaunchKernelGGL((nn_wave_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, g, \
                      accept_thr, keys, partials, unmatched, unmatched_count)
+#define ICP_LAUNCH_WQ(K, F, U)              \
+  do {                                      \
+    if (pack) ICP_LAUNCH_WQP(K, F, U, true); \
+    else ICP_LAUNCH_WQP(K, F, U, false);     \
+  } while (0)
   const bool k = keys != nullptr, f = partials != nullptr, u = unmatched != nullptr;
   if (k && !f && u) ICP_LAUNCH_WQ(true, false, true);
   else if (k && !f) ICP_LAUNCH_WQ(true, false, false);
   else if (!k && f && !u) ICP_LAUNCH_WQ(false, true, false);
   else if (k && f && !u) ICP_LAUNCH_WQ(true, true, false);
   else return hipErrorInvalidValue;
+#undef ICP_LAUNCH_WQP
 #undef ICP_LAUNCH_WQ
   return hipGetLastError();
 }

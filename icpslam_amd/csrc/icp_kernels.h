@@ -94,7 +94,9 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 //   keys      : optional (nullptr to skip) 8-byte keys with ORIGINAL target indices
 //   partials  : optional fused a3+a4 reduction: grid_search_blocks(n_s) partials of 17 doubles
 //   unmatched : optional compaction of unmatched source indices (count at unmatched_count[0], pre-zeroed)
-hipError_t launch_nn_grid_search(const float4* src, int n_s, bool src_in_cell_order, const Xform& T, const float4* sorted,
+// flags: kGridSrcInCellOrder (XCD-contiguous workgroup mapping), kGridPackShortRows (sparse targets: four short rows per step)
+static constexpr int kGridSrcInCellOrder = 1, kGridPackShortRows = 2;
+hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream);
 int grid_search_blocks(int n_s);

@@ -373,6 +373,12 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
   return build_grid(c, c->tgt, c->tgt_version, cut, /*adapt=*/true, G);
 }
 
+constexpr double kPackRowsBelowPopulation = 30.0;  // see sweep_rows_packed
+
+int grid_flags(const GridIndex& G, bool src_in_cell_order) {
+  return (src_in_cell_order ? kGridSrcInCellOrder : 0) | (G.point_population < kPackRowsBelowPopulation ? kGridPackShortRows : 0);
+}
+
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
 // the brute-force kernel. Does not synchronise except for the 4-byte unmatched count.
 int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t, const Xform& T,
@@ -382,7 +388,7 @@ int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, co
   int* d_list = static_cast<int*>(G.unmatched.ptr);
   int* d_count = d_list + n_s;
   HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
-  HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, false, T, static_cast<const float4*>(G.sorted.ptr),
+  HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, grid_flags(G, false), T, static_cast<const float4*>(G.sorted.ptr),
                                    static_cast<const int*>(G.cell_start.ptr), G.g, 0.f, keys, nullptr, d_list, d_count,
                                    c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -500,7 +506,7 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
     const int blocks = grid_search_blocks(n_q);
     if ((rc = ensure(c, c->partials, (size_t)blocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    HIP_TRY(c, launch_nn_grid_search(src_pts, n_q, ordered, T, static_cast<const float4*>(c->grid.sorted.ptr),
+    HIP_TRY(c, launch_nn_grid_search(src_pts, n_q, grid_flags(c->grid, ordered), T, static_cast<const float4*>(c->grid.sorted.ptr),
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
                                      nullptr, c->stream));
     EVREC(ev[1]);
@@ -802,7 +808,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     // correspondences: exact NN keys (only those with d2 < r^2 are used, so the grid's cutoff search is complete)
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (grid_ready(c)) {
-      HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, false, Tq, static_cast<const float4*>(c->grid.sorted.ptr),
+      HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, grid_flags(c->grid, false), Tq, static_cast<const float4*>(c->grid.sorted.ptr),
                                        static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, keys, nullptr, nullptr,
                                        nullptr, c->stream));
     } else {
