@@ -304,14 +304,20 @@ static kd_tree* kd_build(const float* pts, size_t n, int arith) {
   t->n = n;
   t->arith = arith;
   t->perm = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
-  for (size_t i = 0; i < n; ++i) t->perm[i] = (int32_t)i;
+  /* non-finite points never enter the tree but keep their indices: pcl::KdTreeFLANN::convertCloudToArray skips points
+   * for which the point representation is not valid and maps tree indices back to cloud indices */
+  size_t m = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (isfinite(pts[4 * i]) && isfinite(pts[4 * i + 1]) && isfinite(pts[4 * i + 2])) t->perm[m++] = (int32_t)i;
+  n = m;
+  t->n = n;
   for (int a = 0; a < 3; ++a) {
     t->bbox_lo[a] = FLT_MAX;
     t->bbox_hi[a] = -FLT_MAX;
   }
-  for (size_t i = 0; i < n; ++i)
+  for (size_t k = 0; k < n; ++k)
     for (int a = 0; a < 3; ++a) {
-      float v = pts[4 * i + a];
+      float v = pts[4 * (size_t)t->perm[k] + a];
       if (v < t->bbox_lo[a]) t->bbox_lo[a] = v;
       if (v > t->bbox_hi[a]) t->bbox_hi[a] = v;
     }

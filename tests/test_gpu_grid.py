@@ -155,3 +155,64 @@ def test_cell_ordered_source_same_answer_and_grid_follows_promote(ctx):
     assert r2["iterations"] == ref2["iterations"] and r2["n_corr"] == ref2["n_corr"]
     assert np.abs(r2["T"][:3, :3] - ref2["T"][:3, :3]).max() <= 1e-4
     assert np.linalg.norm(r2["T"][:3, 3] - ref2["T"][:3, 3]) <= 1e-3
+
+
+def _fuzz_cloud(rng, n, kind):
+    if kind == "uniform":
+        p = rng.uniform(-20, 20, (n, 3))
+    elif kind == "planes":        # a few thin slabs: long dense rows, empty space between
+        p = rng.uniform(-30, 30, (n, 3))
+        p[:, rng.integers(0, 3)] = rng.choice([-3.0, 0.0, 2.5], n) + rng.normal(0, 0.01, n)
+    elif kind == "clusters":      # tight clumps (hundreds of points per cell) plus a sparse background
+        c = rng.uniform(-15, 15, (12, 3))
+        p = c[rng.integers(0, 12, n)] + rng.normal(0, 0.05, (n, 3))
+        p[: n // 10] = rng.uniform(-40, 40, (n // 10, 3))
+    elif kind == "line":          # degenerate: everything on one cell row
+        p = np.zeros((n, 3))
+        p[:, 0] = rng.uniform(-50, 50, n)
+    else:                         # lattice: exact ties between equidistant neighbours
+        g = rng.integers(-12, 12, (n, 3)).astype(np.float64) * 0.5
+        p = g
+    out = np.ones((n, 4), np.float32)
+    out[:, :3] = p.astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_grid_keys_equal_brute_force(ctx, seed):
+    """Random shapes, sizes, gates and poses: the grid search (all its stages, the sparse / dense cell-size rules, the
+    packed short rows) must return the brute-force kernel's keys bit for bit, ties included."""
+    rng = np.random.default_rng(1000 + seed)
+    kinds = ["uniform", "planes", "clusters", "line", "lattice"]
+    ks, kt = kinds[seed % 5], kinds[(seed // 2) % 5]
+    n_s, n_t = int(rng.integers(4500, 30000)), int(rng.integers(4500, 60000))
+    src, tgt = _fuzz_cloud(rng, n_s, ks), _fuzz_cloud(rng, n_t, kt)
+    if seed % 3 == 0:
+        tgt[rng.integers(0, n_t, 20), :3] = np.nan
+        src[rng.integers(0, n_s, 20), :3] = np.inf
+    T = synth.pose_matrix(*rng.uniform(-1, 1, 3), *rng.uniform(-0.2, 0.2, 3))
+    gate = float(rng.choice([0.07, 0.4, 1.0, 3.0, 12.0]))
+    ig, dg, pg = _nn(ctx, src, tgt, T, NN_GRID, gate)
+    ib, db, _ = _nn(ctx, src, tgt, T, NN_BRUTE, gate)
+    assert np.array_equal(ig, ib) and np.array_equal(dg.view(np.uint32), db.view(np.uint32))
+    # and the fused iteration path feeds the solver the same sums as the brute-force path: same count, same mean squared
+    # distance; the same transform wherever the problem determines one (a lattice against a few clumps can leave a
+    # rank-1 cross-covariance, where the rotation is noise in any implementation)
+    res = {}
+    for mode in (NN_GRID, NN_BRUTE):
+        ctx.set_params(ctx.default_params(), nn_mode=mode, max_correspondence_distance=gate, max_iterations=1,
+                       force_iterations=1)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        res[mode] = ctx.align(guess=T)
+    assert res[NN_GRID]["n_corr"] == res[NN_BRUTE]["n_corr"]
+    assert abs(res[NN_GRID]["mse"] - res[NN_BRUTE]["mse"]) <= 1e-12 * max(1.0, res[NN_BRUTE]["mse"])
+    if res[NN_BRUTE]["n_corr"] >= 3:
+        tr = oracle.icp_align(src, tgt, oracle.default_params(max_correspondence_distance=gate, max_iterations=1,
+                                                              force_iterations=1), guess=T, want_trace=True)["trace"][0]
+        sm = tr["sums"]
+        S = sm[7:16].reshape(3, 3) / sm[0] - np.outer(sm[4:7] / sm[0], sm[1:4] / sm[0])
+        sv = np.linalg.svd(S, compute_uv=False)
+        if sv[1] > 1e-6 * sv[0]:          # a plane of correspondences at least: the rotation is determined
+            assert np.allclose(res[NN_GRID]["T"], res[NN_BRUTE]["T"], atol=1e-5)
+            assert np.allclose(res[NN_GRID]["T"], tr["final"], atol=1e-4)
