@@ -472,8 +472,9 @@ int wait_sums(icpgpu_ctx* c, unsigned long long seq) {
       }
       if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
     }
+    if (spins > 8192u) std::this_thread::yield();  // a long (brute-force) sweep: stop monopolising the core
 #if defined(__x86_64__)
-    __builtin_ia32_pause();
+    else __builtin_ia32_pause();
 #endif
   }
   std::atomic_thread_fence(std::memory_order_acquire);
