@@ -30,13 +30,10 @@ __device__ __forceinline__ void cell_of_g(const GridDesc& g, float x, float y, f
   cz = (int)fminf(fmaxf(fz, -lim), lim);
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {  // lane: wave-uniform
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -128,8 +125,10 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
                                                        const float4* __restrict__ sorted,
                                                        const int* __restrict__ cell_start, GridDesc g,
                                                        double* __restrict__ cov6) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per point
+  __shared__ unsigned long long s_key[4][GK];  // per-wave staging of the top-20 while it is re-ranked
+  __shared__ int s_pos[4][GK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;  // one wave per point
   if (i >= n) return;
   const float4 s = cloud[i];
   double C[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
@@ -169,20 +168,39 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
               const float d = dist2(q.x, q.y, q.z, s.x, s.y, s.z);
               ckey = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
             }
-            unsigned long long better = __ballot(ckey < kth);
-            while (better) {  // wave-uniform: insert one candidate at a time
-              const int cl = __ffsll((long long)better) - 1;
-              better &= better - 1;
-              const unsigned long long c = __shfl(ckey, cl, 64);
-              if (c >= kth) continue;  // kth shrank since the ballot
-              const int cp = __shfl(cpos, cl, 64);
-              const unsigned long long holders = __ballot(lane < GK && mykey == kth);
-              const int hl = __ffsll((long long)holders) - 1;  // a slot holding the current maximum (or an empty one)
-              if (lane == hl) {
-                mykey = c;
-                mypos = cp;
+            const unsigned long long better = __ballot(ckey < kth);
+            if (better) {  // wave-uniform
+              // Merge the chunk's improving candidates into the sorted top-20 (lanes 0..19) by RANK: keys are distinct
+              // (the index is part of the key), so "how many keys of the union are smaller than mine" is my slot.
+              // ~80 + 6 * popcount(better) instructions per chunk, against ~40 per candidate for one-at-a-time insertion
+              // (measured: covariances of a 200k-point cloud 4.75 -> 4.25 ms; most of the kernel's time is the row walk).
+              int rank_top = (int)lane;  // slots below me among the current top keys (they are sorted); lanes < GK only
+              int rank_cand = 0;
+              for (unsigned long long m = better; m; m &= m - 1) {
+                const int j = __ffsll((long long)m) - 1;
+                const unsigned long long bk = readlane_u64(ckey, j);
+                rank_top += bk < mykey ? 1 : 0;
+                rank_cand += bk < ckey ? 1 : 0;
               }
-              kth = wave_max_u64(lane < GK ? mykey : 0ull);
+#pragma unroll
+              for (int j = 0; j < GK; ++j) rank_cand += readlane_u64(mykey, j) < ckey ? 1 : 0;  // empty slots hold the maximum key
+              if (lane < GK) {
+                s_key[wv][lane] = kEmptyKey;
+                s_pos[wv][lane] = -1;
+              }
+              if (lane < GK && mykey != kEmptyKey && rank_top < GK) {
+                s_key[wv][rank_top] = mykey;
+                s_pos[wv][rank_top] = mypos;
+              }
+              if (((better >> lane) & 1ull) && rank_cand < GK) {
+                s_key[wv][rank_cand] = ckey;
+                s_pos[wv][rank_cand] = cpos;
+              }
+              if (lane < GK) {
+                mykey = s_key[wv][lane];
+                mypos = s_pos[wv][lane];
+              }
+              kth = readlane_u64(mykey, GK - 1);
             }
           }
         }
