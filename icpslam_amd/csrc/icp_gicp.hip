@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
                                                         const float4* __restrict__ tgt,
                                                         const unsigned long long* __restrict__ keys, float thr, Xform T,
                                                         Xform base, const double* __restrict__ maha6,
-                                                        double* __restrict__ partials) {
+                                                        double* __restrict__ partials, unsigned long long* flags,
+                                                        unsigned long long seq) {
   double acc[kReduceTerms];
 #pragma unroll
   for (int k = 0; k < kReduceTerms; ++k) acc[k] = 0.0;
@@ -326,6 +327,10 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
     acc[14] += (double)d2;
   }
   block_reduce_store<4>(acc, partials);
+  // "direct" mode (flags != nullptr): partials IS the host mailbox and there is no second kernel -- the host adds the few
+  // workgroups' partials itself.  The 17 stores above come from wave 0, like this flag, so the release orders them.
+  if (flags != nullptr && threadIdx.x == 0)
+    __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -350,8 +355,24 @@ hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const
   int blocks = (n_s + 255) / 256;
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials);
+  hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials,
+                     static_cast<unsigned long long*>(nullptr), 0ull);
   return launch_reduce_final(partials, blocks, sums_out, flags, seq, stream);
+}
+
+int gicp_direct_blocks(int n_s) {
+  int blocks = (n_s + 1023) / 1024;  // >= 4 points per thread: the grid-stride loop keeps the few workgroups busy
+  if (blocks > kGicpDirectBlocks) blocks = kGicpDirectBlocks;
+  if (blocks < 1) blocks = 1;
+  return blocks;
+}
+
+hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                                   const Xform& T, const Xform& base, const double* maha6, double* host_partials,
+                                   unsigned long long* host_flags, unsigned long long seq, hipStream_t stream) {
+  hipLaunchKernelGGL(gicp_cost_kernel, dim3(gicp_direct_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base,
+                     maha6, host_partials, host_flags, seq);
+  return hipGetLastError();
 }
 
 }  // namespace icpgpu

@@ -122,6 +122,15 @@ hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const
                             const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
                             unsigned long long* flags, unsigned long long seq, hipStream_t stream);
 
+// One-kernel variant for the ~300 dependent evaluations of an align: at most kGicpDirectBlocks workgroups, each stores
+// its 17 partial sums straight into host-mapped memory (host_partials[block * 17 + term]) followed by host_flags[block] =
+// seq; the host adds the partials in block order.  gicp_direct_blocks(n_s) = workgroups launched.
+static constexpr int kGicpDirectBlocks = 64;
+int gicp_direct_blocks(int n_s);
+hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                                   const Xform& T, const Xform& base, const double* maha6, double* host_partials,
+                                   unsigned long long* host_flags, unsigned long long seq, hipStream_t stream);
+
 // ---- the mapper's one-point-per-voxel map (icp_map.hip), SURVEY.md 8(f4) --------------------------------------------
 struct MapDesc {
   double ox, oy, oz;  // lattice origin = first inserted point - resolution / 2 (PCL OctreePointCloud bounding-box rule)

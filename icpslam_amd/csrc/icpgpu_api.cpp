@@ -106,6 +106,11 @@ struct icpgpu_ctx {
   volatile unsigned long long* h_flags = nullptr;
   unsigned long long* h_flags_dev = nullptr;  // device alias of h_flags
   unsigned long long sums_seq = 0;
+  // GICP cost evaluations: per-workgroup partials (kGicpDirectBlocks x 17) + one flag per workgroup, same kind of memory
+  double* h_gicp = nullptr;
+  double* h_gicp_dev = nullptr;
+  volatile unsigned long long* h_gicp_flags = nullptr;
+  unsigned long long* h_gicp_flags_dev = nullptr;
   // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
   std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
   struct PendingSweep { int slot; bool grid; };
@@ -457,16 +462,16 @@ int resolve_sweep_timings(icpgpu_ctx* c) {
 
 // Spin on the mailbox flags until every term of sweep `seq` has landed.  The stream is queried now and then so that a
 // faulted kernel turns into an error instead of an endless wait.
-int wait_sums(icpgpu_ctx* c, unsigned long long seq) {
+int wait_flags(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_flags, unsigned long long seq) {
   for (unsigned spins = 1;; ++spins) {
     bool all = true;
-    for (int k = 0; k < kReduceTerms; ++k) all = all && (c->h_flags[k] == seq);
+    for (int k = 0; k < n_flags; ++k) all = all && (flags[k] == seq);
     if (all) break;
     if ((spins & 0x3FFu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {  // everything retired: the flags must be there on the next look
         bool ok = true;
-        for (int k = 0; k < kReduceTerms; ++k) ok = ok && (c->h_flags[k] == seq);
+        for (int k = 0; k < n_flags; ++k) ok = ok && (flags[k] == seq);
         if (ok) break;
         return fail(c, ICPGPU_ERR_HIP, "reduction finished without publishing its result");
       }
@@ -480,6 +485,8 @@ int wait_sums(icpgpu_ctx* c, unsigned long long seq) {
   std::atomic_thread_fence(std::memory_order_acquire);
   return ICPGPU_OK;
 }
+
+int wait_sums(icpgpu_ctx* c, unsigned long long seq) { return wait_flags(c, c->h_flags, kReduceTerms, seq); }
 
 // One NN sweep + reduction with transform T; leaves the 17 sums in c->h_sums.  Waits for the result (by polling the
 // mailbox), not for the stream.
@@ -827,12 +834,19 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       float T[16];
       std::memcpy(T, guess, sizeof(T));
       gicp_apply_state(T, x);
-      // ~300 evaluations per align, each a dependent launch: the result comes back through the polled mailbox
+      // ~300 evaluations per align, each a dependent launch: ONE kernel of a few workgroups whose partial sums land in the
+      // polled host mailbox; the host adds them in workgroup order (deterministic)
       const unsigned long long seq = ++c->sums_seq;
-      if (launch_gicp_cost(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
-                           static_cast<double*>(c->partials.ptr), c->h_sums_dev, c->h_flags_dev, seq, c->stream) != hipSuccess)
+      const int nblk = gicp_direct_blocks(n_s);
+      if (launch_gicp_cost_direct(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
+                                  c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
         return false;
-      if (wait_sums(c, seq) != ICPGPU_OK) return false;
+      if (wait_flags(c, c->h_gicp_flags, nblk, seq) != ICPGPU_OK) return false;
+      for (int k = 0; k < kReduceTerms; ++k) {
+        double v = 0.0;
+        for (int b = 0; b < nblk; ++b) v += c->h_gicp[(size_t)b * kReduceTerms + k];
+        c->h_sums[k] = v;
+      }
       c->prof.gicp_cost_launches += 1;
       const double* s = c->h_sums;
       m_count = s[0];
@@ -988,6 +1002,18 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
     return bail("hipHostGetDevicePointer", e);
   c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
   c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
+  {
+    const size_t n_d = (size_t)kGicpDirectBlocks * kReduceTerms + 8 + kGicpDirectBlocks;  // partials, gap, flags
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_gicp), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
+        hipSuccess)
+      return bail("hipHostMalloc", e);
+    std::memset(c->h_gicp, 0, n_d * sizeof(double));
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_gicp_dev), c->h_gicp, 0)) != hipSuccess)
+      return bail("hipHostGetDevicePointer", e);
+    const size_t off = (size_t)kGicpDirectBlocks * kReduceTerms + 8;
+    c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
+    c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
+  }
   c->ev_ring.assign((size_t)kEventRing * 3, nullptr);
   for (auto& ev : c->ev_ring)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1053,6 +1079,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
     release(G->leftover);
   }
   if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_gicp) (void)hipHostFree(c->h_gicp);
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
