@@ -357,7 +357,7 @@ hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials,
                      static_cast<unsigned long long*>(nullptr), 0ull);
-  return launch_reduce_final(partials, blocks, sums_out, flags, seq, stream);
+  return launch_reduce_final(partials, blocks, false, sums_out, flags, seq, stream);
 }
 
 int gicp_direct_blocks(int n_s) {

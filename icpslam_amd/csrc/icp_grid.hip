@@ -312,7 +312,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
       double v = 0.0;
 #pragma unroll
       for (int w = 0; w < WQ_WAVES; ++w) v += wterm[w][threadIdx.x];
-      partials[(size_t)blockIdx.x * kReduceTerms + threadIdx.x] = v;
+      partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;  // term-major: the final reduction reads rows
     }
   }
 }

@@ -48,8 +48,9 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
 
 // sums_out may be host-mapped pinned memory.  flags (nullable, 17 entries, host-mapped): every term's workgroup stores
 // `seq` there after its sum (system-scope release), so the host can poll instead of synchronising the stream.
-hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, unsigned long long* flags,
-                               unsigned long long seq, hipStream_t stream);
+// term_major: partials are laid out [term][block] (what launch_nn_grid_search writes) instead of [block][term].
+hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,
+                               unsigned long long* flags, unsigned long long seq, hipStream_t stream);
 
 hipError_t launch_transform(const float4* src, int n_s, const Xform& T, float4* out, hipStream_t stream);
 
@@ -92,7 +93,7 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 // Exact NN of T*src[i] among the grid's points, guaranteed whenever the NN lies within the cutoff the grid was built
 // for; otherwise the point is reported unmatched (empty key).  One wave per query (see icp_grid.hip).
 //   keys      : optional (nullptr to skip) 8-byte keys with ORIGINAL target indices
-//   partials  : optional fused a3+a4 reduction: grid_search_blocks(n_s) partials of 17 doubles
+//   partials  : optional fused a3+a4 reduction: 17 x grid_search_blocks(n_s) doubles, TERM-major (partials[k * blocks + b])
 //   unmatched : optional compaction of unmatched source indices (count at unmatched_count[0], pre-zeroed)
 // flags: kGridSrcInCellOrder (XCD-contiguous workgroup mapping), kGridPackShortRows (sparse targets: four short rows per step)
 static constexpr int kGridSrcInCellOrder = 1, kGridPackShortRows = 2;

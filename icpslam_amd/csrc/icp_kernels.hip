@@ -214,12 +214,19 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
 // then a fixed shuffle + LDS tree -> bitwise reproducible run to run.
 // `flags` (optional) lets a host that polls pinned memory see the result without a stream synchronisation: each
 // workgroup publishes `seq` after its sum, with system-scope release ordering.
-__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks,
+// term_major: partials[k * n_blocks + b] (coalesced reads here; the fused grid search writes this layout) instead of
+// partials[b * 17 + k].
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks, int term_major,
                                                            double* __restrict__ sums, unsigned long long* flags,
                                                            unsigned long long seq) {
   const int k = blockIdx.x;
   double v = 0.0;
-  for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[(size_t)b * kReduceTerms + k];
+  if (term_major) {
+    const double* __restrict__ row = partials + (size_t)k * n_blocks;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) v += row[b];
+  } else {
+    for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[(size_t)b * kReduceTerms + k];
+  }
   v = wave_sum(v);
   __shared__ double w[4];
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
@@ -304,13 +311,13 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
-  return launch_reduce_final(partials, blocks, sums_out, flags, seq, stream);
+  return launch_reduce_final(partials, blocks, false, sums_out, flags, seq, stream);
 }
 
-hipError_t launch_reduce_final(const double* partials, int n_blocks, double* sums_out, unsigned long long* flags,
-                               unsigned long long seq, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(256), 0, stream, partials, n_blocks, sums_out, flags,
-                     seq);
+hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,
+                               unsigned long long* flags, unsigned long long seq, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(256), 0, stream, partials, n_blocks, term_major ? 1 : 0,
+                     sums_out, flags, seq);
   return hipGetLastError();
 }
 

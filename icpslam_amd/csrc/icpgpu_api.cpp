@@ -518,7 +518,7 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
                                      nullptr, c->stream));
     EVREC(ev[1]);
-    HIP_TRY(c, launch_reduce_final(partials, blocks, d_sums, c->h_flags_dev, seq, c->stream));
+    HIP_TRY(c, launch_reduce_final(partials, blocks, /*term_major=*/true, d_sums, c->h_flags_dev, seq, c->stream));
   } else {
     if (use_grid) {
       if ((rc = nn_keys_grid(c, T, keys))) return rc;
