@@ -99,3 +99,38 @@ def test_map_shim_matches_oracle(built, tmp_path):
     assert int(v[20]) == len(ref)
     c = nn.astype(np.float64)
     assert abs(float(v[21]) - (c[:, 0] + 2 * c[:, 1] + 3 * c[:, 2] + c[:, 3]).sum()) <= 1e-2
+
+
+def _build_c_demo(tmp_path):
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "c_abi_demo.c"), "-o", str(exe), "-L", libdir, "-licpgpu",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_plain_c_binding_compiles_as_c99_and_fails_loudly_without_gpu(built, tmp_path):
+    import torch
+    exe = _build_c_demo(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    src, tgt, _ = synth.make_pair(100, 100, seed=1)
+    r = _run(exe, tmp_path, src, tgt, 10)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_binding_matches_oracle(built, tmp_path):
+    """INTEGRATION.md section 3 as a C99 program: align + fitness, promote, align the other way round."""
+    exe = _build_c_demo(tmp_path)
+    src, tgt, _ = synth.make_pair(6000, 7000, seed=3)
+    r = _run(exe, tmp_path, src, tgt, 10)
+    assert r.returncode == 0, r.stderr
+    lines = [ln.split() for ln in r.stdout.strip().splitlines()]
+    for vals, (s, t) in zip(lines, ((src, tgt), (tgt, src))):
+        ref = oracle.icp_align(s, t, oracle.default_params(), want_fitness=True)
+        T = np.array([float(v) for v in vals[4:20]]).reshape(4, 4).T
+        assert int(vals[0]) == int(ref["converged"]) and int(vals[1]) == ref["iterations"] and int(vals[2]) == ref["n_corr"]
+        assert abs(float(vals[3]) - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+        assert np.abs(T[:3, :3] - ref["T"][:3, :3]).max() <= 1e-4 and np.linalg.norm(T[:3, 3] - ref["T"][:3, 3]) <= 1e-3
