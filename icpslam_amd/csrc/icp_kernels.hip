@@ -238,9 +238,26 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
 }
 
 // a6: output cloud. 32 B/point of HBM traffic, float4 in / float4 out.
+// Four independent 16-B loads in flight per lane (4 KiB per wave) before the first store; streaming stores.
 __global__ __launch_bounds__(256) void transform_kernel(const float4* __restrict__ src, int n, Xform T,
                                                         float4* __restrict__ out) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int stride = gridDim.x * 256;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    float4 s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = src[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v4f o;
+      float ox, oy, oz;
+      xform_point(T, s[k].x, s[k].y, s[k].z, ox, oy, oz);
+      o.x = ox; o.y = oy; o.z = oz; o.w = 1.0f;
+      __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(out + i + k * stride));
+    }
+  }
+  for (; i < n; i += stride) {
     const float4 s = src[i];
     float4 o;
     xform_point(T, s.x, s.y, s.z, o.x, o.y, o.z);
@@ -323,8 +340,9 @@ hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_m
 
 hipError_t launch_transform(const float4* src, int n_s, const Xform& T, float4* out, hipStream_t stream) {
   if (n_s <= 0) return hipSuccess;
-  int blocks = (n_s + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (n_s + 1023) / 1024;  // 4 points per lane
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(transform_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, T, out);
   return hipGetLastError();
 }
