@@ -76,6 +76,16 @@ def _effective_cpus() -> int:
     return n
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(src, tgt, iters: int, budget_s: float):
     """The oracle (C restatement of PCL's ICP, kd-tree NN, single thread like PCL 1.8) timed on this box's host."""
     import oracle
@@ -103,7 +113,7 @@ def cpu_baseline(src, tgt, iters: int, budget_s: float):
     return {"value": done / t_used, "unit": "iterations/s", "cores": 1, "kind": "port", "many_cores": many,
             "sample": f"{aligns} full align(s) of the same {src.shape[0]}x{tgt.shape[0]} pair, {done} iterations, "
                       f"{t_used:.1f} s incl. kd-tree build; oracle/icp_oracle.c (restatement, not PCL binaries)",
-            "host_cpus": os.cpu_count(), "usable_cpus": _effective_cpus()}
+            "host_cpus": os.cpu_count(), "usable_cpus": _effective_cpus(), "cpu_model": _cpu_model()}
 
 
 def main():
