@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
   if (i >= n) return;
   const float4 s = cloud[i];
   double C[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
+  bool have_patch = false;
   if (finite3g(s.x, s.y, s.z)) {
     int cx, cy, cz;
     cell_of_g(g, s.x, s.y, s.z, cx, cy, cz);
@@ -227,28 +228,44 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
     sx = wave_sum_d(sx); sy = wave_sum_d(sy); sz = wave_sum_d(sz);
     xx = wave_sum_d(xx); yx = wave_sum_d(yx); yy2 = wave_sum_d(yy2);
     zx = wave_sum_d(zx); zy = wave_sum_d(zy); zz2 = wave_sum_d(zz2);
-    if (cnt == GK) {
+    if (cnt == GK) {  // hand the sample covariance (6 distinct entries) to gicp_cov_finish_kernel
       const double k = (double)GK;
       const double mx = sx / k, my = sy / k, mz = sz / k;
-      double A[9];
-      A[0] = xx / k - mx * mx;
-      A[3] = A[1] = yx / k - my * mx;
-      A[4] = yy2 / k - my * my;
-      A[6] = A[2] = zx / k - mz * mx;
-      A[7] = A[5] = zy / k - mz * my;
-      A[8] = zz2 / k - mz * mz;
-      double u[3];
-      smallest_singular_direction(A, u);
-      const double f = 1.0 - kGicpEpsilon;
-      C[0] = 1.0 - f * u[0] * u[0];
-      C[1] = -f * u[0] * u[1];
-      C[2] = -f * u[0] * u[2];
-      C[3] = 1.0 - f * u[1] * u[1];
-      C[4] = -f * u[1] * u[2];
-      C[5] = 1.0 - f * u[2] * u[2];
+      C[0] = xx / k - mx * mx;
+      C[1] = yx / k - my * mx;
+      C[2] = zx / k - mz * mx;
+      C[3] = yy2 / k - my * my;
+      C[4] = zy / k - mz * my;
+      C[5] = zz2 / k - mz * mz;
+      have_patch = true;
     }
   }
+  if (!have_patch) C[0] = __longlong_as_double(0x7FF8000000000000ll);  // marker: identity covariance
   if (lane < 6) cov6[(size_t)i * 6 + lane] = C[lane];
+}
+
+// The 3x3 decomposition, ONE LANE PER POINT: inside the search kernel every lane of the wave repeated it (several thousand
+// double-precision instructions per point, the largest part of that kernel's time); here 64 points share a wave.
+__global__ __launch_bounds__(256) void gicp_cov_finish_kernel(int n, double* __restrict__ cov6) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double* c = cov6 + (size_t)i * 6;
+  const double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3], a4 = c[4], a5 = c[5];
+  double C[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
+  if (a0 == a0) {  // not the marker
+    const double A[9] = {a0, a1, a2, a1, a3, a4, a2, a4, a5};
+    double u[3];
+    smallest_singular_direction(A, u);
+    const double f = 1.0 - kGicpEpsilon;
+    C[0] = 1.0 - f * u[0] * u[0];
+    C[1] = -f * u[0] * u[1];
+    C[2] = -f * u[0] * u[2];
+    C[3] = 1.0 - f * u[1] * u[1];
+    C[4] = -f * u[1] * u[2];
+    C[5] = 1.0 - f * u[2] * u[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) c[k] = C[k];
 }
 
 // ---- Mahalanobis matrices --------------------------------------------------------------------------------------
@@ -339,6 +356,7 @@ hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sor
                                    const GridDesc& g, double* cov6, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6);
+  hipLaunchKernelGGL(gicp_cov_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, cov6);
   return hipGetLastError();
 }
 
