@@ -170,10 +170,15 @@ class LineFunction {
   double f(double alpha) {
     if (alpha == f_key_) return f_alpha_;
     move(alpha);
+    // One device reduction yields the value AND the gradient (same sums), so the gradient is cached here as well: GSL
+    // asks for df(alpha) right after f(alpha) on every accepted trial point, which would otherwise be a second launch
+    // producing bit for bit the same numbers.
     GicpEval e;
-    ok_ = ok_ && eval_(x_alpha_, false, e);
+    ok_ = ok_ && eval_(x_alpha_, true, e);
     f_alpha_ = e.f;
     f_key_ = alpha;
+    g_alpha_ = e.g;
+    g_key_ = alpha;
     return f_alpha_;
   }
   double df(double alpha) {
@@ -278,9 +283,10 @@ Line line_search(LineFunction& fn, double alpha1, double& alpha_out) {
 
 }  // namespace
 
-GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double gradient_tol) {
+GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double gradient_tol, const GicpEval* at_x) {
   GicpEval e0;
-  if (!eval(x, true, e0)) return GicpSolve::DeviceError;
+  if (at_x) e0 = *at_x;  // the caller has just evaluated value and gradient at x
+  else if (!eval(x, true, e0)) return GicpSolve::DeviceError;
   double f = e0.f;
   Vec6 g = e0.g, x0 = x, g0 = g, p;
   double g0norm = norm(g0);

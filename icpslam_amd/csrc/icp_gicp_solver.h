@@ -28,6 +28,7 @@ using GicpEvalFn = std::function<bool(const Vec6& x, bool want_gradient, GicpEva
 
 enum class GicpSolve { Ok, NotEnoughPoints, DidNotConverge, DeviceError };
 // runs <= max_inner BFGS steps from x (gradient tolerance 1e-2, PCL's line-search constants); x is updated in place
-GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double gradient_tol);
+// at_x (nullable): value and gradient at the start point if the caller already has them (saves one evaluation)
+GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double gradient_tol, const GicpEval* at_x = nullptr);
 
 }  // namespace icpgpu

@@ -869,14 +869,14 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     // number of correspondences (one evaluation at the current state; it is also the BFGS start, cached by the solver)
     Vec6 x = gicp_state_from_matrix(transformation);
     GicpEval probe;
-    if (!eval(x, false, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+    if (!eval(x, true, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
     n_corr = (unsigned)m_count;
     std::memcpy(previous, transformation, sizeof(previous));
     if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
       state = ICPGPU_CONV_NO_CORRESPONDENCES;
       break;
     }
-    const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2);
+    const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
     if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
     if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
       state = ICPGPU_NOT_CONVERGED;
