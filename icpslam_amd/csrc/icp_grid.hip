@@ -141,34 +141,50 @@ __global__ __launch_bounds__(256) void scan_sums_kernel(const int* __restrict__ 
     m = max(m, __shfl_down(m, off, 64));
     sq += __shfl_down(sq, off, 64);
   }
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-  if ((threadIdx.x & 63) == 0 && m > 0) {  // empty stretches of the table (most of it) skip the atomics
-    atomicMax(&stats[1], m);
-    atomicAdd(reinterpret_cast<unsigned long long*>(stats + 2), sq);
+  // one set of atomics per WORKGROUP, and none for the empty stretches of the table (most of it): same-address atomics
+  // cost ~12 ns each on this part
+  __shared__ int wmax[4];
+  __shared__ unsigned long long wsq[4];
+  if ((threadIdx.x & 63) == 0) {
+    wmax[threadIdx.x >> 6] = m;
+    wsq[threadIdx.x >> 6] = sq;
   }
-  if (threadIdx.x == 0 && tot > 0) atomicAdd(&stats[4], tot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    block_sums[blockIdx.x] = tot;
+    if (tot > 0) {
+      atomicMax(&stats[1], max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+      atomicAdd(reinterpret_cast<unsigned long long*>(stats + 2), (wsq[0] + wsq[1]) + (wsq[2] + wsq[3]));
+      atomicAdd(&stats[4], tot);
+    }
+  }
 }
 
 __global__ __launch_bounds__(1024) void scan_top_kernel(int* __restrict__ block_sums, int nb, int* __restrict__ stats) {
   // one workgroup: each thread owns a contiguous slice of the block sums
-  __shared__ int part[1024];
   const int per = (nb + 1023) / 1024;
   const int lo = threadIdx.x * per, hi = min(nb, lo + per);
   int s = 0;
   for (int k = lo; k < hi; ++k) s += block_sums[k];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int t = 0; t < 1024; ++t) {
-      const int v = part[t];
-      part[t] = run;
-      run += v;
-    }
-    stats[0] = run;  // number of binned points
+  // exclusive scan of the 1024 slice sums: 64-lane shuffle scans + one scan of the 16 wave totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
   }
+  __shared__ int wtot[16];
+  if (lane == 63) wtot[wave] = incl;
   __syncthreads();
-  int run = part[threadIdx.x];
+  int base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += wtot[w];
+    total += wtot[w];
+  }
+  if (threadIdx.x == 0) stats[0] = total;  // number of binned points
+  int run = base + incl - s;
   for (int k = lo; k < hi; ++k) {
     const int v = block_sums[k];
     block_sums[k] = run;
