@@ -324,7 +324,8 @@ hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, 
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
                          float thr, double* partials, double* sums_out, unsigned long long* flags, unsigned long long seq,
                          hipStream_t stream) {
-  int blocks = (n_s + RED_BLOCK - 1) / RED_BLOCK;
+  // ~4 points per lane: the 17-term workgroup reduction at the end costs more than a point does
+  int blocks = (n_s + 4 * RED_BLOCK - 1) / (4 * RED_BLOCK);
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
