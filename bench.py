@@ -128,10 +128,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # one rank per GPU over RCCL.  ICPGPU_BENCH_BACKEND=gloo (tests only) exercises the same multi-process logic with all
+    # ranks sharing the visible GPUs, e.g. two ranks on a 1-GPU box.
+    backend = os.environ.get("ICPGPU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from icpslam_amd import NN_AUTO, NN_BRUTE, NN_GRID, Context
 
@@ -150,7 +159,7 @@ def main():
     def gather(res):
         """Result gather, the only inter-GPU traffic of the path: T (16 f32) + iterations + converged + n_corr + mse."""
         rec = torch.tensor(list(res["T"].reshape(-1)) + [res["iterations"], float(res["converged"]), res["n_corr"],
-                                                          res["mse"]], dtype=torch.float64, device="cuda")
+                                                          res["mse"]], dtype=torch.float64, device=coll_dev)
         if world > 1:
             allrec = [torch.empty_like(rec) for _ in range(world)]
             dist.all_gather(allrec, rec)
@@ -168,7 +177,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

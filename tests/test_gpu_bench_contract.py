@@ -35,3 +35,19 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0
+
+
+def test_bench_two_ranks_through_torchrun():
+    """The N > 1 path as the driver launches it (torch.distributed.run, one process per rank), with the gloo backend so
+    that both ranks can share this box's single GPU: barrier, max-over-ranks timing, aggregate value, one JSON line."""
+    env = dict(os.environ, ICPGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--workload", "50kx50k"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    # whole-job aggregate: both ranks' iterations over the slowest rank's time
+    assert abs(d["value"] - 2 * 1e3 * d["config"]["iters_per_step"] / d["ms_per_step"]) <= 1e-6 * d["value"]
