@@ -28,3 +28,40 @@ def test_gpu_matches_golden(ctx, path):
     assert np.abs(T[:3, :3] - Tg[:3, :3]).max() <= 1e-4                       # BASELINE.json: 1e-4 (R)
     assert np.linalg.norm(T[:3, 3] - Tg[:3, 3]) <= 1e-3                       # BASELINE.json: 1e-3 m (t)
     assert abs(got["fitness"] - float(g["fitness"])) <= 1e-6 * max(1.0, float(g["fitness"]))
+
+
+# ---- fixtures of the widened rows (tests/golden/make_golden_widened.py) ---------------------------------------------------
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rows_f", name))
+
+
+def test_voxel_filter_matches_golden(ctx):
+    g = _golden("voxel_2k.npz")
+    assert np.array_equal(ctx.voxel_grid(g["cloud"], float(g["leaf"])).view(np.uint32), g["expected"].view(np.uint32))
+    assert np.array_equal(ctx.voxel_grid(g["cloud"], 0.05).view(np.uint32), g["expected_small_leaf"].view(np.uint32))
+
+
+def test_map_matches_golden(ctx):
+    g = _golden("map_3scans.npz")
+    ctx.map_reset(float(g["resolution"]))
+    for k in range(g["scans"].shape[0]):
+        assert ctx.map_add_points(g["scans"][k], g["poses"][k]) == int(g["added"][k]) and ctx.map_size() == int(g["sizes"][k])
+    assert np.array_equal(ctx.map_points().view(np.uint32), g["map_points"].view(np.uint32))
+    ctx.set_source(g["probe"])
+    nn = ctx.map_nn_target(g["probe_pose"], g["probe_pose_inv"])
+    assert np.array_equal(np.ascontiguousarray(nn).view(np.uint32), g["nn_cloud"].view(np.uint32))
+
+
+def test_gicp_matches_golden(ctx):
+    from icpslam_amd import GICP
+    g = _golden("gicp_1k5.npz")
+    ctx.set_params(ctx.default_params(), method=GICP)
+    ctx.set_source(g["src"])
+    ctx.set_target(g["tgt"])
+    r = ctx.align(want_fitness=True)
+    assert r["iterations"] == int(g["iterations"]) and r["converged"] == bool(g["converged"]) and r["n_corr"] == int(g["n_corr"])
+    assert np.abs(r["T"][:3, :3] - g["T"][:3, :3]).max() <= 1e-4 and np.linalg.norm(r["T"][:3, 3] - g["T"][:3, 3]) <= 1e-3
+    assert abs(r["fitness"] - float(g["fitness"])) <= 1e-6
+    cov = ctx.gicp_covariances(of_target=True)
+    assert np.abs(cov - g["cov_tgt"]).max() <= 1e-6

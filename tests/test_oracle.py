@@ -202,3 +202,32 @@ def test_voxel_grid_properties():
     means /= counts[:, None]
     np.testing.assert_allclose(out[:, :3], means, atol=1e-4)
     assert (out[:, 3] == 1.0).all()
+
+
+# ---- fixtures of the widened rows (tests/golden/make_golden_widened.py) ---------------------------------------------------
+def _golden(name):
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rows_f", name))
+
+
+def test_voxel_oracle_matches_golden():
+    g = _golden("voxel_2k.npz")
+    assert np.array_equal(oracle.voxel_grid(g["cloud"], float(g["leaf"])).view(np.uint32), g["expected"].view(np.uint32))
+    assert np.array_equal(oracle.voxel_grid(g["cloud"], 0.05).view(np.uint32), g["expected_small_leaf"].view(np.uint32))
+
+
+def test_map_oracle_matches_golden():
+    g = _golden("map_3scans.npz")
+    m = oracle.VoxelMap(float(g["resolution"]))
+    for k in range(g["scans"].shape[0]):
+        assert m.add_points(g["scans"][k], g["poses"][k]) == int(g["added"][k]) and len(m) == int(g["sizes"][k])
+    assert np.array_equal(m.points().view(np.uint32), g["map_points"].view(np.uint32))
+    nn = m.nn_cloud(g["probe"], g["probe_pose"], g["probe_pose_inv"])
+    assert np.array_equal(nn.view(np.uint32), g["nn_cloud"].view(np.uint32))
+
+
+def test_gicp_oracle_matches_golden():
+    g = _golden("gicp_1k5.npz")
+    r = oracle.icp_align(g["src"], g["tgt"], oracle.default_params(method=oracle.GICP), want_fitness=True)
+    assert r["iterations"] == int(g["iterations"]) and r["converged"] == bool(g["converged"]) and r["n_corr"] == int(g["n_corr"])
+    assert np.abs(r["T"] - g["T"]).max() <= 1e-6 and abs(r["fitness"] - float(g["fitness"])) <= 1e-9
+    assert np.abs(oracle.gicp_covariances(g["tgt"]) - g["cov_tgt"]).max() <= 1e-9
