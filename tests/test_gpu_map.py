@@ -122,3 +122,40 @@ def test_refine_and_grow_matches_the_oracle_flow(ctx):
             assert np.linalg.norm(resid[:3, 3]) < 0.08
         assert mapper.map_size == len(ref)
     assert np.array_equal(_bits(mapper.map_cloud()), _bits(ref.points()))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_map_against_oracle(ctx, seed):
+    """Random resolutions, poses, batch sizes and shapes (clumps, sheets, duplicates, non-finite points): the map and the
+    nn cloud stay bit-identical to the sequential oracle."""
+    rng = np.random.default_rng(500 + seed)
+    res = float(rng.choice([0.07, 0.25, 0.5, 1.3, 4.0]))
+    ref = oracle.VoxelMap(res)
+    ctx.set_params(ctx.default_params())
+    ctx.map_reset(res)
+    for k in range(int(rng.integers(2, 5))):
+        n = int(rng.integers(50, 40000))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            p = rng.uniform(-25, 25, (n, 3))
+        elif kind == 1:
+            p = rng.uniform(-25, 25, (n, 3))
+            p[:, 2] = rng.normal(0.0, 0.02, n)                    # a sheet: many points per voxel column
+        else:
+            c = rng.uniform(-10, 10, (8, 3))
+            p = c[rng.integers(0, 8, n)] + rng.normal(0, 0.3, (n, 3))
+        cloud = np.ones((n, 4), np.float32)
+        cloud[:, :3] = p.astype(np.float32)
+        cloud[rng.integers(0, n, 3), :3] = np.nan
+        cloud[n // 2: n // 2 + 20] = cloud[n // 2]                 # exact duplicates
+        pose = synth.pose_matrix(*rng.uniform(-3, 3, 3), *rng.uniform(-0.3, 0.3, 3))
+        assert ctx.map_add_points(cloud, pose) == ref.add_points(cloud, pose)
+    assert ctx.map_size() == len(ref)
+    assert np.array_equal(_bits(ctx.map_points()), _bits(ref.points()))
+    q = np.ones((3000, 4), np.float32)
+    q[:, :3] = rng.uniform(-30, 30, (3000, 3)).astype(np.float32)
+    q[7, :3] = np.inf
+    pose = synth.pose_matrix(*rng.uniform(-1, 1, 3), *rng.uniform(-0.2, 0.2, 3))
+    pinv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
+    ctx.set_source(q)
+    assert np.array_equal(_bits(ctx.map_nn_target(pose, pinv)), _bits(ref.nn_cloud(q, pose, pinv)))

@@ -54,3 +54,19 @@ def test_filtered_source_feeds_icp(ctx):
     assert (got["iterations"], got["n_corr"], got["converged"]) == (ref["iterations"], ref["n_corr"], ref["converged"])
     assert np.abs(got["T"] - ref["T"]).max() <= 1e-4
     assert abs(got["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_voxel_filter_against_oracle(ctx, seed):
+    import oracle
+    rng = np.random.default_rng(700 + seed)
+    n = int(rng.integers(1, 60000))
+    leaf = float(rng.choice([0.03, 0.1, 0.2, 0.77, 5.0]))
+    scale = float(rng.choice([2.0, 30.0, 300.0]))
+    cloud = np.ones((n, 4), np.float32)
+    cloud[:, :3] = rng.normal(0, scale, (n, 3)).astype(np.float32)
+    if n > 40:
+        cloud[10:30] = cloud[10]                                  # exact duplicates share a voxel
+    out = ctx.voxel_grid(cloud, leaf)
+    ref = oracle.voxel_grid(cloud, leaf)                          # returns the input unchanged on index overflow, like PCL
+    assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
