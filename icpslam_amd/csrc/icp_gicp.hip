@@ -315,33 +315,56 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
   double acc[kReduceTerms];
 #pragma unroll
   for (int k = 0; k < kReduceTerms; ++k) acc[k] = 0.0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_s; i += gridDim.x * 256) {
-    const unsigned long long key = keys[i];
-    const unsigned int j = (unsigned int)key;
-    const float d2 = __uint_as_float((unsigned int)(key >> 32));
-    if (j == 0xFFFFFFFFu || !(d2 < thr)) continue;
-    const float4 s = src[i];
-    const float4 q = tgt[j];
-    float px, py, pz, bx, by, bz;
-    xform_point(T, s.x, s.y, s.z, px, py, pz);
-    xform_point(base, s.x, s.y, s.z, bx, by, bz);
-    const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);
-    const double* M = maha6 + (size_t)i * 6;
-    const double t0 = M[0] * r0 + M[1] * r1 + M[2] * r2;
-    const double t1 = M[1] * r0 + M[3] * r1 + M[4] * r2;
-    const double t2 = M[2] * r0 + M[4] * r1 + M[5] * r2;
-    acc[0] += 1.0;
-    acc[1] += r0 * t0 + r1 * t1 + r2 * t2;
-    acc[2] += t0;
-    acc[3] += t1;
-    acc[4] += t2;
-    const double pb[3] = {(double)bx, (double)by, (double)bz};
-    const double tt[3] = {t0, t1, t2};
+  // Four correspondences per lane and trip, their loads issued together: key -> (target point, Mahalanobis matrix) is a
+  // dependent chain of random reads, and with <= 64 workgroups in direct mode every lane owns several correspondences --
+  // one after the other they made this kernel 14-16 us long (latency, not bandwidth).
+  const int stride = gridDim.x * 256;
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n_s; i0 += 4 * stride) {
+    unsigned long long key[4];
+    bool use[4];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * stride;
+      key[u] = i < n_s ? keys[i] : kEmptyKey;
+    }
+    float4 sv[4], qv[4];
+    double M[4][6];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[5 + 3 * r + c] += pb[r] * tt[c];
-    acc[14] += (double)d2;
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * stride, n_s - 1);
+      const unsigned int j = (unsigned int)key[u];
+      const float d2 = __uint_as_float((unsigned int)(key[u] >> 32));
+      use[u] = j != 0xFFFFFFFFu && d2 < thr;
+      sv[u] = src[i];
+      qv[u] = tgt[use[u] ? j : 0u];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) M[u][k] = maha6[(size_t)i * 6 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!use[u]) continue;
+      const float4 s = sv[u], q = qv[u];
+      const float d2 = __uint_as_float((unsigned int)(key[u] >> 32));
+      float px, py, pz, bx, by, bz;
+      xform_point(T, s.x, s.y, s.z, px, py, pz);
+      xform_point(base, s.x, s.y, s.z, bx, by, bz);
+      const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);
+      const double t0 = M[u][0] * r0 + M[u][1] * r1 + M[u][2] * r2;
+      const double t1 = M[u][1] * r0 + M[u][3] * r1 + M[u][4] * r2;
+      const double t2 = M[u][2] * r0 + M[u][4] * r1 + M[u][5] * r2;
+      acc[0] += 1.0;
+      acc[1] += r0 * t0 + r1 * t1 + r2 * t2;
+      acc[2] += t0;
+      acc[3] += t1;
+      acc[4] += t2;
+      const double pb[3] = {(double)bx, (double)by, (double)bz};
+      const double tt[3] = {t0, t1, t2};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[5 + 3 * r + c] += pb[r] * tt[c];
+      acc[14] += (double)d2;
+    }
   }
   block_reduce_store<4>(acc, partials);
   // "direct" mode (flags != nullptr): partials IS the host mailbox and there is no second kernel -- the host adds the few

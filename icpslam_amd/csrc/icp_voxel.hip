@@ -55,11 +55,31 @@ __global__ __launch_bounds__(256) void voxel_centroid_kernel(const float4* __res
   const int k = keys[i];
   float ax = 0.f, ay = 0.f, az = 0.f;
   int j = i;
-  for (; j < n && keys[j] == k; ++j) {
-    const float4 p = pts[vals[j]];
-    ax += p.x;
-    ay += p.y;
-    az += p.z;
+  // The sums must run in point order (PCL adds the points of a voxel in input order, in float), but the loads need not
+  // wait for each other: four members are fetched at once -- key, index and point are three DEPENDENT loads per member,
+  // and a voxel of nine points was 27 memory round trips in a row.
+  for (bool more = true; more;) {
+    int kk[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(j + u, n - 1);
+      kk[u] = keys[idx];
+      vv[u] = vals[idx];
+    }
+    float4 pp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pp[u] = pts[vv[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (more && j < n && kk[u] == k) {
+        ax += pp[u].x;
+        ay += pp[u].y;
+        az += pp[u].z;
+        ++j;
+      } else {
+        more = false;
+      }
+    }
   }
   const float cnt = (float)(j - i);
   out[slots[i]] = make_float4(ax / cnt, ay / cnt, az / cnt, 1.0f);
