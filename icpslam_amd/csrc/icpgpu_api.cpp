@@ -329,9 +329,11 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
       }
     }
     // k-nearest-neighbour searches (GICP covariances) read whole 3x3x3 cubes: they want only a few points per cell
-    if (attempt == 0 && knn_population > 0.0 && pop > 2.0 * knn_population) {
-      const double h_new = std::max(h * std::sqrt(knn_population / pop), cut / 64.0);
-      if (h_new < 0.9 * h) {
+    if (attempt == 0 && knn_population > 0.0 && binned > 0 && (pop > 2.0 * knn_population || pop < 0.5 * knn_population)) {
+      // ... in both directions: over a sparse (voxel-filtered) cloud the 20 neighbours lie ~2.5 point spacings away, and
+      // cells that small make the search restart with cubes of 25 and 81 rows (22k-point cloud: 0.60 -> 0.35 ms)
+      const double h_new = std::min(std::max(h * std::sqrt(knn_population / pop), cut / 64.0), 8.0 * h);
+      if (h_new < 0.9 * h || h_new > 1.1 * h) {
         h = h_new;
         shrunk = true;
         continue;
@@ -740,7 +742,7 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   if (cov_version == version && cov.ptr) return ICPGPU_OK;
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
-  static const double knn_pop = [] { const char* e = std::getenv("ICPGPU_KNN_POP"); return e ? std::atof(e) : 6.0; }();
+  static const double knn_pop = [] { const char* e = std::getenv("ICPGPU_KNN_POP"); return e ? std::atof(e) : 8.0; }();
   int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G, nullptr, knn_pop);
   if (rc) return rc;
   if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
