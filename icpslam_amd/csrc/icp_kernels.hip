@@ -163,6 +163,45 @@ __global__ __launch_bounds__(NN_BLOCK) void nn_brute_kernel(const float4* __rest
   }
 }
 
+// Completion for a HANDFUL of listed points (the few far outliers a gate-less search leaves behind): lane = target point,
+// the listed queries are a wave-uniform outer loop.  The tiled kernel above costs a full pass over the target whatever
+// the number of queries (62 us at 50k targets for 9 points); this one is launch-bound.
+constexpr int kFewList = 64;
+__global__ __launch_bounds__(256) void nn_brute_few_kernel(const float4* __restrict__ src, const int* __restrict__ list,
+                                                           int n_list, const float4* __restrict__ tgt, int n_t, Xform T,
+                                                           unsigned long long* __restrict__ keys) {
+  for (int qi = 0; qi < n_list; ++qi) {
+    const int i = list[qi];
+    const float4 s = src[i];
+    float px, py, pz;
+    xform_point(T, s.x, s.y, s.z, px, py, pz);
+    unsigned long long best = kEmptyKey;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_t; j += gridDim.x * 256) {
+      const float4 q = tgt[j];
+      const float d = dist2(q.x, q.y, q.z, px, py, pz);
+      if (d < INFINITY) {  // like the tiled kernel: NaN and inf distances never win
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)j;
+        best = key < best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off, 64);
+      best = o < best ? o : best;
+    }
+    __shared__ unsigned long long wbest[4];  // one atomic per workgroup and query (same-address atomics are ~12 ns each)
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long b = wbest[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) b = wbest[w] < b ? wbest[w] : b;
+      if (b != kEmptyKey) atomicMin(&keys[i], b);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void fill_keys_kernel(unsigned long long* __restrict__ keys, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) keys[i] = kEmptyKey;
@@ -313,6 +352,14 @@ hipError_t launch_nn_brute(const float4* src, int n_s, const float4* tgt, int n_
 hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,
                                 const Xform& T, int num_cus, unsigned long long* keys, hipStream_t stream) {
   if (n_list <= 0 || n_t <= 0) return hipSuccess;
+  if (n_list <= kFewList && (long long)n_list * (long long)n_t <= (16ll << 20)) {
+    // (keys of listed points are empty on entry: the atomic-min merge is valid)
+    int blocks = (n_t + 767) / 768;  // ~3 targets per lane and query
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nn_brute_few_kernel, dim3(blocks), dim3(256), 0, stream, src, list, n_list, tgt, n_t, T, keys);
+    return hipGetLastError();
+  }
   const NnPlan plan = plan_nn_brute(n_list, n_t, 0, num_cus);
   dim3 grid(plan.grid_x, plan.splits), block(NN_BLOCK);
   // keys of listed points are empty on entry, so the atomic-min merge is always valid (splits is forced > 1)

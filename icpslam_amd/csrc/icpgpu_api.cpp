@@ -395,8 +395,14 @@ int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, co
   int* d_list = static_cast<int*>(G.unmatched.ptr);
   int* d_count = d_list + n_s;
   HIP_TRY(c, hipMemsetAsync(d_count, 0, sizeof(int), c->stream));
+  // A search WITHOUT a gate (getFitnessScore, icpgpu_nn, the map's nn cloud): the 1-2 % of the queries whose neighbour is
+  // beyond the gate the grid was built for would all go to the brute-force completion (62 us at 50k x 50k, more than the
+  // whole grid sweep).  Letting the cubes grow to 4x the gate settles nearly all of them in the grid: a few thousand
+  // cell rows for a few hundred queries.
+  GridDesc g_open = G.g;
+  g_open.r_max = std::min(4 * G.g.r_max, 48);
   HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, grid_flags(G, false), T, static_cast<const float4*>(G.sorted.ptr),
-                                   static_cast<const int*>(G.cell_start.ptr), G.g, 0.f, keys, nullptr, d_list, d_count,
+                                   static_cast<const int*>(G.cell_start.ptr), g_open, 0.f, keys, nullptr, d_list, d_count,
                                    c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
