@@ -46,31 +46,51 @@ __global__ __launch_bounds__(256) void voxel_flag_kernel(const int* __restrict__
 }
 
 // one lane per occupied cell: float32 sum of the cell's points in input order, then the mean
-__global__ __launch_bounds__(256) void voxel_centroid_kernel(const float4* __restrict__ pts, const int* __restrict__ keys,
-                                                             const int* __restrict__ vals, const int* __restrict__ flags,
-                                                             const int* __restrict__ slots, int n,
-                                                             float4* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+constexpr int VC_BLOCK = 1024;
+
+__global__ __launch_bounds__(VC_BLOCK) void voxel_centroid_kernel(const float4* __restrict__ pts, const int* __restrict__ keys,
+                                                                  const int* __restrict__ vals, const int* __restrict__ flags,
+                                                                  const int* __restrict__ slots, int n,
+                                                                  float4* __restrict__ out) {
+  // The sums must run in point order (PCL adds the points of a voxel in input order, in float), but the LOADS need not:
+  // every lane gathers the point at its own sorted position into LDS (one parallel round of dependent loads: index, then
+  // point), then the first lane of each voxel adds its members from LDS.  Members beyond this workgroup's 1024 positions
+  // (rare: the densest 0.2 m voxels of a raw scan hold ~150 points) are fetched eight at a time.
+  // Was: key, index and point re-read one member after the other -- 27 memory round trips in a row per 9-point voxel,
+  // several hundred for the densest one, which set the kernel's duration (90 us for 200k points).
+  __shared__ float4 sp[VC_BLOCK];
+  __shared__ int sk[VC_BLOCK];
+  const int base = blockIdx.x * VC_BLOCK, i = base + threadIdx.x;
+  const int block_end = min(n, base + VC_BLOCK);
+  int k = 0;
+  if (i < n) {
+    k = keys[i];
+    sk[threadIdx.x] = k;
+    sp[threadIdx.x] = pts[vals[i]];
+  }
+  __syncthreads();
   if (i >= n || !flags[i]) return;
-  const int k = keys[i];
   float ax = 0.f, ay = 0.f, az = 0.f;
   int j = i;
-  // The sums must run in point order (PCL adds the points of a voxel in input order, in float), but the loads need not
-  // wait for each other: four members are fetched at once -- key, index and point are three DEPENDENT loads per member,
-  // and a voxel of nine points was 27 memory round trips in a row.
-  for (bool more = true; more;) {
-    int kk[4], vv[4];
+  for (; j < block_end && sk[j - base] == k; ++j) {
+    const float4 p = sp[j - base];
+    ax += p.x;
+    ay += p.y;
+    az += p.z;
+  }
+  for (bool more = j == block_end && j < n; more;) {
+    int kk[8], vv[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int idx = min(j + u, n - 1);
       kk[u] = keys[idx];
       vv[u] = vals[idx];
     }
-    float4 pp[4];
+    float4 pp[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pp[u] = pts[vv[u]];
+    for (int u = 0; u < 8; ++u) pp[u] = pts[vv[u]];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (more && j < n && kk[u] == k) {
         ax += pp[u].x;
         ay += pp[u].y;
@@ -108,7 +128,8 @@ hipError_t launch_voxel_grid(const float4* pts, int n, float inv_leaf, const int
   hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(256), 0, stream, keys + n, n, flags);
   e = rocprim::exclusive_scan(temp, temp_bytes, flags, slots, 0, (size_t)n, rocprim::plus<int>(), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(voxel_centroid_kernel, dim3(blocks), dim3(256), 0, stream, pts, keys + n, vals + n, flags, slots, n, out);
+  hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n + VC_BLOCK - 1) / VC_BLOCK), dim3(VC_BLOCK), 0, stream, pts, keys + n,
+                     vals + n, flags, slots, n, out);
   // number of cells = slots[n-1] + flags[n-1]
   e = hipMemcpyAsync(d_n_out, slots + (n - 1), sizeof(int), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return e;
