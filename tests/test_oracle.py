@@ -231,3 +231,55 @@ def test_gicp_oracle_matches_golden():
     assert r["iterations"] == int(g["iterations"]) and r["converged"] == bool(g["converged"]) and r["n_corr"] == int(g["n_corr"])
     assert np.abs(r["T"] - g["T"]).max() <= 1e-6 and abs(r["fitness"] - float(g["fitness"])) <= 1e-9
     assert np.abs(oracle.gicp_covariances(g["tgt"]) - g["cov_tgt"]).max() <= 1e-9
+
+
+# ---- hypothesis-driven properties of the restatement ---------------------------------------------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+def _cloud_pair(seed, n):
+    rng = np.random.default_rng(seed)
+    # a bent sheet plus a few posts: enough structure for ICP to have a unique answer at a few hundred points
+    u, v = rng.uniform(-4, 4, n), rng.uniform(-4, 4, n)
+    pts = np.stack([u, v, 0.15 * np.sin(u) + 0.1 * v * v / 4], 1)
+    posts = rng.integers(0, n, n // 5)
+    pts[posts, 2] += rng.uniform(0.2, 1.5, posts.size)
+    T = synth.pose_matrix(*rng.uniform(-0.15, 0.15, 3), *rng.uniform(-0.03, 0.03, 3))
+    src = np.ones((n, 4), np.float32)
+    src[:, :3] = pts.astype(np.float32)
+    tgt = np.ones((n, 4), np.float32)
+    tgt[:, :3] = (pts @ T[:3, :3].T.astype(np.float64) + T[:3, 3] + rng.normal(0, 0.002, (n, 3))).astype(np.float32)
+    return src, tgt
+
+
+@settings(max_examples=15, deadline=None)
+@given(seed=st.integers(0, 10_000), n=st.integers(120, 400))
+def test_property_permutation_invariance(seed, n):
+    src, tgt = _cloud_pair(seed, n)
+    rng = np.random.default_rng(seed + 1)
+    a = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=8))
+    b = oracle.icp_align(src[rng.permutation(n)], tgt[rng.permutation(n)], oracle.default_params(max_iterations=8))
+    assert a["iterations"] == b["iterations"] and a["n_corr"] == b["n_corr"]
+    assert np.abs(a["T"] - b["T"]).max() <= 1e-5
+
+
+@settings(max_examples=15, deadline=None)
+@given(seed=st.integers(0, 10_000), n=st.integers(120, 400))
+def test_property_rigid_equivariance(seed, n):
+    src, tgt = _cloud_pair(seed, n)
+    rng = np.random.default_rng(seed + 2)
+    M = synth.pose_matrix(*rng.uniform(-5, 5, 3), *rng.uniform(-0.5, 0.5, 3)).astype(np.float64)
+    mv = lambda c: np.hstack([(c[:, :3].astype(np.float64) @ M[:3, :3].T + M[:3, 3]).astype(np.float32), c[:, 3:]])  # noqa: E731
+    a = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=8))
+    b = oracle.icp_align(mv(src), mv(tgt), oracle.default_params(max_iterations=8))
+    want = M @ a["T"].astype(np.float64) @ np.linalg.inv(M)
+    assert abs(a["n_corr"] - b["n_corr"]) <= max(2, n // 100)
+    assert np.abs(b["T"][:3, :3] - want[:3, :3]).max() <= 1e-3 and np.linalg.norm(b["T"][:3, 3] - want[:3, 3]) <= 5e-3
+
+
+@settings(max_examples=10, deadline=None)
+@given(seed=st.integers(0, 10_000), n=st.integers(60, 300))
+def test_property_identical_clouds_give_identity(seed, n):
+    src, _ = _cloud_pair(seed, n)
+    r = oracle.icp_align(src, src.copy(), oracle.default_params())
+    assert r["converged"] and r["n_corr"] == n and np.abs(r["T"] - np.eye(4)).max() <= 1e-6 and r["mse"] <= 1e-12
