@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
   else if (lane == 16) qi = 3;
 
   // preamble: lane -> (point lane/4, octant row lane%4)
-  float lpx = 0.f, lpy = 0.f, lpz = 0.f;
+  float lpx = 0.f, lpy = 0.f, lpz = 0.f, lmargin = 0.5f;
   int lcx = 0, lcy = 0, lcz = 0, llo = 0, llen = 0;
   bool lfin = false;
   {
@@ -279,12 +279,12 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
       lfin = finite3(lpx, lpy, lpz);
       if (lfin) {
         cell_of(g, lpx, lpy, lpz, lcx, lcy, lcz);
-        octant_row(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, llo, llen);
+        octant_row(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, llo, llen, lmargin);
       }
     }
   }
   const unsigned long long fin_mask = __ballot(lfin), row_mask = __ballot(llen > 0);
-  const float safe0 = 0.5f * g.h * kGridSafety, safe0_sq = safe0 * safe0;
+  const float lsafe = lmargin * g.h * kGridSafety, lsafe_sq = lsafe * lsafe;  // what the octant can certify, per point
   unsigned long long my_key = kEmptyKey;  // lane q keeps the key of point k0 + q
 
   for (int qq = 0; qq < qpw; ++qq) {
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
     const float px = readlane_f(lpx, l0), py = readlane_f(lpy, l0), pz = readlane_f(lpz, l0);
     if ((fin_mask >> l0) & 1ull) {
       sweep_rows(sorted, llo, llen, row_mask & (0xFull << l0), lane, px, py, pz, b);
-      found = merge_lanes(b) && __uint_as_float((unsigned int)(b.key >> 32)) <= safe0_sq;
+      found = merge_lanes(b) && __uint_as_float((unsigned int)(b.key >> 32)) <= readlane_f(lsafe_sq, l0);
       if (!found) {
         const int cx = __builtin_amdgcn_readlane(lcx, l0), cy = __builtin_amdgcn_readlane(lcy, l0),
                   cz = __builtin_amdgcn_readlane(lcz, l0);
@@ -329,6 +329,183 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
 #pragma unroll
       for (int w = 0; w < WQ_WAVES; ++w) v += wterm[w][threadIdx.x];
       partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;  // term-major: the final reduction reads rows
+    }
+  }
+}
+
+// ---- the same search, four queries at a time ------------------------------------------------------------------------
+// One wave still owns 16 source points and runs the same lane-parallel preamble, but the octant stage works on FOUR
+// points at once, 16 lanes each (a DPP row): lanes 16g..16g+15 hold points 4g..4g+3 of the wave after the preamble, so
+// in pass b group g takes point 4g+b and everything it needs already sits in its own row.  The four octant rows of a
+// point are walked as ONE list (lane s takes entries s, s+16, ...), the per-lane minima are merged inside the row with
+// 4+4 v_min_u32_dpp (no readlanes, no scalar tie logic), the winner's coordinates come back through ds_bpermute and the
+// 16 product terms of the fused reduction go one to a lane (the count is an integer, the d2 sum shares lane 0).  That
+// removes most of the per-point fixed cost of nn_wave_kernel (merge, term selection, scalar row set-up: ~70 of ~150 wave
+// instructions).  Points the octant cannot certify fall back to the wave-wide cube search, one at a time, as before.
+template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool PACK_SHORT_ROWS>
+__global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
+                                                           const float4* __restrict__ sorted,
+                                                           const int* __restrict__ cell_start, GridDesc g, float accept_thr,
+                                                           unsigned long long* __restrict__ keys,
+                                                           double* __restrict__ partials, int* __restrict__ unmatched,
+                                                           int* __restrict__ unmatched_count) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp_base = lane & 48, sub = lane & 15;
+  const int lb = xcd_map ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int k0 = lb * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
+
+  // fused reduction: lane s of a row owns one product term (term order of accumulate_pair; s = 0 takes the d2 sum, the
+  // count is kept as an integer)
+  double acc = 0.0;
+  int cnt = 0;
+  int qi = -1, pi = -1;
+  if (sub == 0) qi = 3;
+  else if (sub <= 3) pi = sub - 1;
+  else if (sub <= 6) qi = sub - 4;
+  else { qi = (sub - 7) / 3; pi = (sub - 7) % 3; }
+
+  // preamble: lane -> (point lane/4, octant row lane%4), as nn_wave_kernel
+  float lpx = 0.f, lpy = 0.f, lpz = 0.f, lmargin = 0.5f;
+  int lcx = 0, lcy = 0, lcz = 0, llo = 0, llen = 0;
+  bool lfin = false;
+  const int il = k0 + (lane >> 2) * stride;
+  const bool lvalid = (lane >> 2) < qpw && il < n_s;
+  if (lvalid) {
+    const float4 s = src[il];
+    xform_point(T, s.x, s.y, s.z, lpx, lpy, lpz);
+    lfin = finite3(lpx, lpy, lpz);
+    if (lfin) {
+      cell_of(g, lpx, lpy, lpz, lcx, lcy, lcz);
+      octant_row(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, llo, llen, lmargin);
+    }
+  }
+  const unsigned long long fin_mask = __ballot(lfin);
+  const float lsafe = lmargin * g.h * kGridSafety, lsafe_sq = lsafe * lsafe;  // what the octant can certify, per point
+  const int n_pass = (__popcll(__ballot(lvalid)) + 15) >> 4;  // 4 lanes per point, 4 points per pass
+
+  // Octant sizes differ a lot between points (median 135 candidates, 90th percentile 360 at 200k x 200k) and a pass
+  // lasts as long as its largest group, so the 16 points are ranked by candidate count (largest first, slots without a
+  // point last) and pass b takes ranks 4b..4b+3: four points of similar size.  Modelled on the 200k pair: 5.7 -> 4.0
+  // loads per point (the wave-per-point kernel: 3.9).
+  int slot_of_rank;  // lane 4r (..4r+3): the slot of the point with rank r
+  {
+    int cand = llen + __builtin_amdgcn_mov_dpp(llen, 0xB1, 0xF, 0xF, true);
+    cand += __builtin_amdgcn_mov_dpp(cand, 0x4E, 0xF, 0xF, true);  // all four rows of the slot
+    const unsigned int mine = ((lvalid ? (unsigned int)cand + 1u : 0u) << 4) | (unsigned int)(lane >> 2);  // unique per slot
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rank += (unsigned int)__builtin_amdgcn_readlane((int)mine, 4 * k) > mine ? 1 : 0;
+    slot_of_rank = __builtin_amdgcn_ds_permute((4 * rank + (lane & 3)) << 2, lane >> 2);
+  }
+
+  const char* __restrict__ sorted_bytes = reinterpret_cast<const char*>(sorted);
+  for (int pass = 0; pass < n_pass; ++pass) {
+    const int ql = 4 * lane_get_i(slot_of_rank, 4 * (4 * pass + (lane >> 4)));  // preamble lane (row 0) of this group's point
+    const int qi_src = k0 + (ql >> 2) * stride;                                 // its index in the source cloud
+    const bool valid = (ql >> 2) < qpw && qi_src < n_s;
+    const float px = lane_get_f(lpx, ql), py = lane_get_f(lpy, ql), pz = lane_get_f(lpz, ql);
+    const bool fin = (fin_mask >> ql) & 1ull;
+    const int lo0 = lane_get_i(llo, ql), lo1 = lane_get_i(llo, ql + 1), lo2 = lane_get_i(llo, ql + 2), lo3 = lane_get_i(llo, ql + 3);
+    const int n0 = lane_get_i(llen, ql), n1 = lane_get_i(llen, ql + 1), n2 = lane_get_i(llen, ql + 2), n3 = lane_get_i(llen, ql + 3);
+    // the four rows as one list of L entries: entry v lives at sorted[v + o_r] for the row r it falls into (all in
+    // bytes below, modulo 2^32: the launcher only picks this kernel for targets under 4 GiB).  A group with nothing to
+    // search (L = 0) re-reads sorted[0]: any real target point may be offered to an exact minimum.
+    const int e0 = n0, e1 = e0 + n1, e2 = e1 + n2, L = e2 + n3;
+    const unsigned int eb0 = (unsigned int)e0 << 4, eb1 = (unsigned int)e1 << 4, eb2 = (unsigned int)e2 << 4;
+    const unsigned int ob0 = (unsigned int)lo0 << 4, ob1 = (unsigned int)(lo1 - e0) << 4, ob2 = (unsigned int)(lo2 - e1) << 4,
+                       ob3 = L ? (unsigned int)(lo3 - e2) << 4 : 0u;
+    const unsigned int lastb = (unsigned int)max(L - 1, 0) << 4;
+    const int l_max = max(max(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)),
+                          max(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
+    // per lane: the best (d2, original index) key and where that entry sits (its coordinates are fetched once, after the merge)
+    unsigned long long bkey = kEmptyKey;
+    unsigned int bpos = 0u;
+    unsigned int vb = (unsigned int)sub << 4;
+    for (int done = 0; done < l_max; done += 32, vb += 512u) {
+      const unsigned int ua = min(vb, lastb), ub = min(vb + 256u, lastb);  // past the end: the last entry again (harmless)
+      const unsigned int fa = ua + (ua < eb0 ? ob0 : ua < eb1 ? ob1 : ua < eb2 ? ob2 : ob3);
+      const unsigned int fb = ub + (ub < eb0 ? ob0 : ub < eb1 ? ob1 : ub < eb2 ? ob2 : ob3);
+      const float4 qa = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)fa);
+      const float4 qb = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)fb);
+      __builtin_amdgcn_sched_barrier(0);  // both reads in flight before either is used
+      const unsigned long long ka = ((unsigned long long)__float_as_uint(dist2(qa.x, qa.y, qa.z, px, py, pz)) << 32) | __float_as_uint(qa.w);
+      const unsigned long long kb = ((unsigned long long)__float_as_uint(dist2(qb.x, qb.y, qb.z, px, py, pz)) << 32) | __float_as_uint(qb.w);
+      if (ka < bkey) { bkey = ka; bpos = fa; }
+      if (kb < bkey) { bkey = kb; bpos = fb; }
+    }
+    // merge inside the row: distance first, then the lowest original index among the ties
+    const unsigned int dbits = (unsigned int)(bkey >> 32), idx = (unsigned int)bkey;
+    const unsigned int dmin = row16_min_u32(dbits);
+    const unsigned int imin = row16_min_u32(dbits == dmin ? idx : 0xFFFFFFFFu);
+    const unsigned long long win = __ballot(dbits == dmin && idx == imin);  // >= 1 lane per row
+    const int owner = grp_base + __ffs((unsigned int)(win >> grp_base) & 0xFFFFu) - 1;
+    unsigned long long gkey = ((unsigned long long)dmin << 32) | imin;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if constexpr (FUSE_REDUCE) {
+      const float4 w = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)(unsigned int)lane_get_i((int)bpos, owner));
+      qx = w.x;
+      qy = w.y;
+      qz = w.z;
+    }
+    bool found = fin && __uint_as_float(dmin) <= lane_get_f(lsafe_sq, ql);  // an empty row has dmin = NaN bits: false
+
+    // not certified by the octant: the wave-wide cube search, one point at a time
+    unsigned long long need = __ballot(fin && !found && sub == 0);
+    while (need) {
+      const int gl = __ffsll((long long)need) - 1, sl = __builtin_amdgcn_readlane(ql, gl);
+      need &= need - 1;
+      const float ux = readlane_f(lpx, sl), uy = readlane_f(lpy, sl), uz = readlane_f(lpz, sl);
+      const int cx = __builtin_amdgcn_readlane(lcx, sl), cy = __builtin_amdgcn_readlane(lcy, sl),
+                cz = __builtin_amdgcn_readlane(lcz, sl);
+      // the octant's winner (if any) seeds the search: it bounds the ball the cubes have to cover
+      LaneBest c{((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(gkey >> 32), gl) << 32) |
+                     (unsigned int)__builtin_amdgcn_readlane((int)gkey, gl),
+                 readlane_f(qx, gl), readlane_f(qy, gl), readlane_f(qz, gl)};
+      const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, ux, uy, uz, cx, cy, cz, lane, c);
+      if (grp_base == gl) {
+        gkey = c.key;
+        qx = c.qx;
+        qy = c.qy;
+        qz = c.qz;
+        found = f2;
+      }
+    }
+
+    if constexpr (WRITE_KEYS) {
+      if (sub == 0 && valid) keys[qi_src] = found ? gkey : kEmptyKey;
+    }
+    if constexpr (LIST_UNMATCHED) {
+      if (sub == 0 && valid && !found) unmatched[atomicAdd(unmatched_count, 1)] = qi_src;
+    }
+    if constexpr (FUSE_REDUCE) {
+      const float d2 = __uint_as_float((unsigned int)(gkey >> 32));
+      if (found && d2 <= accept_thr) {
+        const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)qx : qi == 1 ? (double)qy : qi == 2 ? (double)qz : (double)d2);
+        const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
+        acc += a * c;
+        cnt += 1;
+      }
+    }
+  }
+  if constexpr (FUSE_REDUCE) {
+    __shared__ double wterm[WQ_WAVES * 4][16];
+    __shared__ int wcnt[WQ_WAVES * 4];
+    wterm[wave * 4 + (lane >> 4)][sub] = acc;
+    if (sub == 0) wcnt[wave * 4 + (lane >> 4)] = cnt;
+    __syncthreads();
+    if (threadIdx.x < kReduceTerms) {
+      double v = 0.0;
+      if (threadIdx.x == 0) {
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < WQ_WAVES * 4; ++k) n += wcnt[k];
+        v = (double)n;
+      } else {
+        const int s = threadIdx.x == 16 ? 0 : (int)threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < WQ_WAVES * 4; ++k) v += wterm[k][s];
+      }
+      partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
     }
   }
 }
@@ -381,8 +558,18 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 }
 
 // points per wave: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
+static bool quad_enabled() {
+  static const bool v = [] { const char* e = getenv("ICPGPU_QUAD"); return !e || atoi(e) != 0; }();  // 0: nn_wave_kernel
+  return v;
+}
+
 static int queries_per_wave(int n_s) {
   int q = n_s / 8192;
+  if (quad_enabled()) {  // four points per pass
+    static const int min_q = [] { const char* e = getenv("ICPGPU_QUAD_MINQ"); return e ? atoi(e) : 4; }();
+    q = (q + 3) & ~3;
+    if (q < min_q) q = min_q;
+  }
   if (q < 1) q = 1;
   if (q > WQ_MAX_QPW) q = WQ_MAX_QPW;
   return q;
@@ -402,9 +589,16 @@ hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xf
   const int qpw = queries_per_wave(n_s), xm = flags & kGridSrcInCellOrder;
   const bool pack = (flags & kGridPackShortRows) != 0;
   dim3 grid(blocks), block(WQ_BLOCK);
+  const bool quad = quad_enabled() && !(flags & kGridOver4GiB);
 #define ICP_LAUNCH_WQP(K, F, U, P)                                                                                      \
-  hipLaunchKernelGGL((nn_wave_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, g, \
-                     accept_thr, keys, partials, unmatched, unmatched_count)
+  do {                                                                                                                  \
+    if (quad)                                                                                                           \
+      hipLaunchKernelGGL((nn_quad_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
+                         g, accept_thr, keys, partials, unmatched, unmatched_count);                                    \
+    else                                                                                                                \
+      hipLaunchKernelGGL((nn_wave_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
+                         g, accept_thr, keys, partials, unmatched, unmatched_count);                                    \
+  } while (0)
 #define ICP_LAUNCH_WQ(K, F, U)              \
   do {                                      \
     if (pack) ICP_LAUNCH_WQP(K, F, U, true); \

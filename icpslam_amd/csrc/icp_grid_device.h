@@ -7,6 +7,10 @@
 #include "icp_device.h"
 #include "icp_kernels.h"
 
+#ifndef ICPGPU_BALL_PRUNING
+#define ICPGPU_BALL_PRUNING 1  // 0: walk whole cubes (the first version; for A/B measurements)
+#endif
+
 namespace icpgpu {
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) {
@@ -41,6 +45,20 @@ __device__ __forceinline__ unsigned int wave_min_u32(unsigned int v) {
   const unsigned int r0 = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned int)__builtin_amdgcn_readlane((int)v, 16),
                      r2 = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
   return min(min(r0, r1), min(r2, r3));  // scalar unit
+}
+
+// minimum of v over each row of 16 lanes, left in every lane of the row
+__device__ __forceinline__ unsigned int row16_min_u32(unsigned int v) {
+  v = min(v, dpp_move<0xB1>(v));
+  v = min(v, dpp_move<0x4E>(v));
+  v = min(v, dpp_move<0x141>(v));
+  return min(v, dpp_move<0x140>(v));
+}
+
+// value of v in another lane, per-lane source (ds_bpermute: the LDS crossbar, no memory access)
+__device__ __forceinline__ int lane_get_i(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ float lane_get_f(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {  // lane must be wave-uniform
@@ -155,12 +173,15 @@ __device__ __forceinline__ void sweep_rows_packed(const float4* __restrict__ sor
   sweep_rows(sorted, lo, len, longm, lane, px, py, pz, b);
 }
 
-// The 2x2x2 octant of cells a point leans towards: lane `sel` in 0..3 gets one of its four cell rows.  Every cell outside
-// the octant is at least h/2 away from the point, so a best distance <= 63/64 * h/2 found inside it is final.
+// The 2x2x2 octant of cells a point leans towards: lane `sel` in 0..3 gets one of its four cell rows.  Along each axis
+// the point sits at fraction f of its cell and the octant reaches max(f, 1 - f) >= 1/2 cells beyond it on the nearer
+// side, so every cell outside the octant is at least `margin` = the smallest of the three (in cells, 0.625 on average)
+// away: a best distance <= 63/64 * margin * h found inside the octant is final.
 __device__ __forceinline__ void octant_row(const int* __restrict__ cell_start, const GridDesc& g, float px, float py,
-                                           float pz, int cx, int cy, int cz, int sel, int& lo, int& len) {
+                                           float pz, int cx, int cy, int cz, int sel, int& lo, int& len, float& margin) {
   const float fx = (px - g.ox) * g.inv_h - (float)cx, fy = (py - g.oy) * g.inv_h - (float)cy, fz = (pz - g.oz) * g.inv_h - (float)cz;
   const int ax = cx + (fx < 0.5f ? -1 : 0), ay = cy + (fy < 0.5f ? -1 : 0), az = cz + (fz < 0.5f ? -1 : 0);
+  margin = fminf(fminf(fmaxf(fx, 1.0f - fx), fmaxf(fy, 1.0f - fy)), fmaxf(fz, 1.0f - fz));
   const int x0 = max(ax, 0), x1 = min(ax + 1, g.nx - 1);
   const int yy = ay + (sel & 1), zz = az + ((sel >> 1) & 1);
   lo = 0;
@@ -173,24 +194,48 @@ __device__ __forceinline__ void octant_row(const int* __restrict__ cell_start, c
 }
 
 // Cubes of Chebyshev radius 1, 2, 4, ... (capped at r_max) around cell (cx, cy, cz) until the best distance is provably
-// inside the cube; px..cz are wave-uniform.  On return b holds the wave-uniform winner.
+// inside the cube; px..cz are wave-uniform, and so is b on entry (the octant's winner, or kEmptyKey) and on return.
+//
+// Ball pruning: once some point is known at distance D (the octant's winner, then each cube's), the neighbour lies in
+// the ball of radius D, and a cube of 5^3 or 9^3 cells is mostly outside it.  Each lane drops its cell row when the row's
+// (y, z) slab is farther than D, and otherwise trims the row's x range to the chord of the ball: the walk then costs what
+// the ball holds, not what the cube holds.  Everything is done in cell units on the SAME float coordinates the binning
+// used; `slack` bounds what those can be off by (two roundings of a value below max(nx, ny, nz): < n * 2^-23 per point,
+// query and target, three axes), and D itself is inflated by 1/32 against the rounding of dist2.  The pruning only
+// removes cells that cannot hold a point closer than D; the certification test is unchanged.
 template <bool PACK_SHORT_ROWS>
 __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                            const GridDesc& g, float px, float py, float pz, int cx, int cy, int cz,
                                            unsigned int lane, LaneBest& b) {
+  const float fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h;
+  const float slack = 0.03125f + (float)max(g.nx, max(g.ny, g.nz)) * (4.0f / 8388608.0f);
   for (int rho = 1;; rho = min(2 * rho, g.r_max)) {
     const int side = 2 * rho + 1, nrows = side * side;
     const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
     const float inv_side = 1.0f / (float)side;
+    // radius of the ball in cells (+inf while nothing has been found: no pruning)
+    const float best = __uint_as_float((unsigned int)(b.key >> 32));  // kEmptyKey reads as a NaN
+    const float ball = sqrtf(best) * g.inv_h * 1.03125f + slack;
+    const float ball_sq = (ICPGPU_BALL_PRUNING && best < __builtin_inff()) ? ball * ball : __builtin_inff();
     for (int rb = 0; rb < nrows; rb += 64) {
       const int r = rb + (int)lane;  // lane -> one cell row of the cube; (y, z) by an exact float reciprocal
       const int zr = (int)(((float)r + 0.5f) * inv_side), yr = r - zr * side;
       const int yy = cy + yr - rho, zz = cz + zr - rho;
       int lo = 0, len = 0;
       if (r < nrows && x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-        const int row = zz * g.sz + yy * g.sy;
-        lo = cell_start[row + x0];
-        len = cell_start[row + x1 + 1] - lo;
+        // distance (in cells) from the query to the slab [yy, yy+1) x [zz, zz+1); 0 inside it
+        const float dy = fmaxf(fmaxf((float)yy - fy, fy - (float)(yy + 1)), 0.f);
+        const float dz = fmaxf(fmaxf((float)zz - fz, fz - (float)(zz + 1)), 0.f);
+        const float rem = ball_sq - dy * dy - dz * dz;
+        if (rem >= 0.f) {
+          const float w = sqrtf(rem);
+          const int xa = (int)fmaxf(floorf(fx - w), (float)x0), xb = (int)fminf(floorf(fx + w), (float)x1);
+          if (xa <= xb) {
+            const int row = zz * g.sz + yy * g.sy;
+            lo = cell_start[row + xa];
+            len = cell_start[row + xb + 1] - lo;
+          }
+        }
       }
       if constexpr (PACK_SHORT_ROWS) sweep_rows_packed(sorted, lo, len, __ballot(len > 0), lane, px, py, pz, b);
       else sweep_rows(sorted, lo, len, __ballot(len > 0), lane, px, py, pz, b);

@@ -91,12 +91,14 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
                               const int* orig_index, float4* sorted, hipStream_t stream);
 
 // Exact NN of T*src[i] among the grid's points, guaranteed whenever the NN lies within the cutoff the grid was built
-// for; otherwise the point is reported unmatched (empty key).  One wave per query (see icp_grid.hip).
+// for; otherwise the point is reported unmatched (empty key).  nn_quad_kernel / nn_wave_kernel (see icp_grid.hip).
 //   keys      : optional (nullptr to skip) 8-byte keys with ORIGINAL target indices
 //   partials  : optional fused a3+a4 reduction: 17 x grid_search_blocks(n_s) doubles, TERM-major (partials[k * blocks + b])
 //   unmatched : optional compaction of unmatched source indices (count at unmatched_count[0], pre-zeroed)
-// flags: kGridSrcInCellOrder (XCD-contiguous workgroup mapping), kGridPackShortRows (sparse targets: four short rows per step)
-static constexpr int kGridSrcInCellOrder = 1, kGridPackShortRows = 2;
+// flags: kGridSrcInCellOrder (XCD-contiguous workgroup mapping), kGridPackShortRows (sparse targets: four short rows per
+// step in the cube search), kGridOver4GiB (2^28 or more binned points: nn_quad_kernel's 32-bit byte offsets do not reach,
+// nn_wave_kernel takes over)
+static constexpr int kGridSrcInCellOrder = 1, kGridPackShortRows = 2, kGridOver4GiB = 4;
 hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream);

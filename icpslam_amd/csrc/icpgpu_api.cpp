@@ -282,7 +282,9 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
       nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
       ny = (long long)std::floor((hi[1] - lo[1]) / h) + 3;
       nz = (long long)std::floor((hi[2] - lo[2]) / h) + 3;
-      if (nx * ny * nz <= kMaxGridCells && nx < (1 << 20) && ny < (1 << 20) && nz < (1 << 20)) break;
+      // at most 2^14 cells per axis: the float cell coordinates the search reasons with are then exact to 2^-9 of a
+      // cell, well inside the 1/64 safety margin of its distance tests (icp_grid_device.h)
+      if (nx * ny * nz <= kMaxGridCells && nx < (1 << 14) && ny < (1 << 14) && nz < (1 << 14)) break;
       h *= 1.15;
       if (!std::isfinite(h)) return ICPGPU_OK;
     }
@@ -383,7 +385,8 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
 constexpr double kPackRowsBelowPopulation = 30.0;  // see sweep_rows_packed
 
 int grid_flags(const GridIndex& G, bool src_in_cell_order) {
-  return (src_in_cell_order ? kGridSrcInCellOrder : 0) | (G.point_population < kPackRowsBelowPopulation ? kGridPackShortRows : 0);
+  return (src_in_cell_order ? kGridSrcInCellOrder : 0) | (G.point_population < kPackRowsBelowPopulation ? kGridPackShortRows : 0) |
+         (G.n_binned >= (1 << 28) ? kGridOver4GiB : 0);
 }
 
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
