@@ -233,7 +233,7 @@ def main():
             g_ms = prof.grid_ms / max(1, prof.grid_timed)
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
             roofline = {
-                "kernel": "nn_wave_kernel<fused> (uniform-grid exact NN + rejection + 17-term reduction)",
+                "kernel": "nn_quad_kernel<fused> (uniform-grid exact NN, four points per wave pass, + rejection + 17-term reduction)",
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic.get("nn_grid_hbm_bytes_per_launch"), "avg_launch_ms": g_ms,
                 "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
-                                                           int* __restrict__ unmatched_count) {
+                                                           int* __restrict__ unmatched_count, float4* __restrict__ prev_nn,
+                                                           int use_prev) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp_base = lane & 48, sub = lane & 15;
   const int lb = xcd_map ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -370,13 +371,25 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
   bool lfin = false;
   const int il = k0 + (lane >> 2) * stride;
   const bool lvalid = (lane >> 2) < qpw && il < n_s;
+  // Temporal coherence: prev_nn[i] holds the neighbour point i found in the previous sweep over the SAME target (NaN:
+  // none).  Whatever the transform is now, that point is a target point, so its distance bounds the new neighbour's:
+  // only the part of the octant inside that ball is read (near convergence: 1-2 cells of the 8).
+  float lbx = 0.f, lby = 0.f, lbz = 0.f, lbound = __builtin_nanf("");
   if (lvalid) {
     const float4 s = src[il];
+    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (use_prev) pq = prev_nn[il];
     xform_point(T, s.x, s.y, s.z, lpx, lpy, lpz);
     lfin = finite3(lpx, lpy, lpz);
     if (lfin) {
       cell_of(g, lpx, lpy, lpz, lcx, lcy, lcz);
-      octant_row(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, llo, llen, lmargin);
+      if (use_prev) {
+        lbx = pq.x;
+        lby = pq.y;
+        lbz = pq.z;
+        lbound = dist2(pq.x, pq.y, pq.z, lpx, lpy, lpz);  // the expression consider() uses: the same bits when it is met again
+      }
+      octant_row_in_ball(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, ball_cells_sq(g, lbound), llo, llen, lmargin);
     }
   }
   const unsigned long long fin_mask = __ballot(lfin);
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
     const int owner = grp_base + __ffs((unsigned int)(win >> grp_base) & 0xFFFFu) - 1;
     unsigned long long gkey = ((unsigned long long)dmin << 32) | imin;
     float qx = 0.f, qy = 0.f, qz = 0.f;
-    if constexpr (FUSE_REDUCE) {
+    if (FUSE_REDUCE || prev_nn) {
       const float4 w = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)(unsigned int)lane_get_i((int)bpos, owner));
       qx = w.x;
       qy = w.y;
@@ -457,10 +470,19 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
       const float ux = readlane_f(lpx, sl), uy = readlane_f(lpy, sl), uz = readlane_f(lpz, sl);
       const int cx = __builtin_amdgcn_readlane(lcx, sl), cy = __builtin_amdgcn_readlane(lcy, sl),
                 cz = __builtin_amdgcn_readlane(lcz, sl);
-      // the octant's winner (if any) seeds the search: it bounds the ball the cubes have to cover
+      // the octant's winner (if any) seeds the search: it bounds the ball the cubes have to cover ...
       LaneBest c{((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(gkey >> 32), gl) << 32) |
                      (unsigned int)__builtin_amdgcn_readlane((int)gkey, gl),
                  readlane_f(qx, gl), readlane_f(qy, gl), readlane_f(qz, gl)};
+      // ... unless last sweep's neighbour is closer (it may lie outside the octant).  It enters with the highest index:
+      // the cubes meet the point itself again, same distance bits, and its real index wins the tie.
+      const float pb = readlane_f(lbound, sl);
+      if (pb < __builtin_inff() && !(__uint_as_float((unsigned int)(c.key >> 32)) <= pb)) {
+        c.key = ((unsigned long long)__float_as_uint(pb) << 32) | 0xFFFFFFFFull;
+        c.qx = readlane_f(lbx, sl);
+        c.qy = readlane_f(lby, sl);
+        c.qz = readlane_f(lbz, sl);
+      }
       const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, ux, uy, uz, cx, cy, cz, lane, c);
       if (grp_base == gl) {
         gkey = c.key;
@@ -471,6 +493,10 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
       }
     }
 
+    if (prev_nn && sub == 0 && valid) {
+      const float none = __builtin_nanf("");
+      prev_nn[qi_src] = found ? make_float4(qx, qy, qz, 0.f) : make_float4(none, none, none, 0.f);
+    }
     if constexpr (WRITE_KEYS) {
       if (sub == 0 && valid) keys[qi_src] = found ? gkey : kEmptyKey;
     }
@@ -557,23 +583,24 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
   return hipGetLastError();
 }
 
-// points per wave: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
+// nn_quad_kernel takes over from nn_wave_kernel at 32k points (measured: 5k 12.1 vs 9.6 us, 10k 17.2 vs 13.8, 20k-30k equal,
+// 50k 25 vs 28, 200k 58 vs 71): below that the chip is filled by giving every wave a single point.
 static bool quad_enabled() {
   static const bool v = [] { const char* e = getenv("ICPGPU_QUAD"); return !e || atoi(e) != 0; }();  // 0: nn_wave_kernel
   return v;
 }
+static bool use_quad(int n_s) { return quad_enabled() && n_s >= 4 * 8192; }
 
+// points per wave: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
 static int queries_per_wave(int n_s) {
   int q = n_s / 8192;
-  if (quad_enabled()) {  // four points per pass
-    static const int min_q = [] { const char* e = getenv("ICPGPU_QUAD_MINQ"); return e ? atoi(e) : 4; }();
-    q = (q + 3) & ~3;
-    if (q < min_q) q = min_q;
-  }
+  if (use_quad(n_s)) q = (q + 3) & ~3;  // four points per pass
   if (q < 1) q = 1;
   if (q > WQ_MAX_QPW) q = WQ_MAX_QPW;
   return q;
 }
+
+bool grid_search_keeps_prev(int n_s, int flags) { return use_quad(n_s) && !(flags & kGridOver4GiB); }
 
 int grid_search_blocks(int n_s) {
   const int per_block = WQ_WAVES * queries_per_wave(n_s);
@@ -583,18 +610,20 @@ int grid_search_blocks(int n_s) {
 
 hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
-                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream) {
+                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream,
+                                 float4* prev_nn, bool use_prev) {
   if (n_s <= 0) return hipSuccess;
   const int blocks = grid_search_blocks(n_s);
   const int qpw = queries_per_wave(n_s), xm = flags & kGridSrcInCellOrder;
   const bool pack = (flags & kGridPackShortRows) != 0;
   dim3 grid(blocks), block(WQ_BLOCK);
-  const bool quad = quad_enabled() && !(flags & kGridOver4GiB);
+  const bool quad = use_quad(n_s) && !(flags & kGridOver4GiB);
 #define ICP_LAUNCH_WQP(K, F, U, P)                                                                                      \
   do {                                                                                                                  \
     if (quad)                                                                                                           \
       hipLaunchKernelGGL((nn_quad_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
-                         g, accept_thr, keys, partials, unmatched, unmatched_count);                                    \
+                         g, accept_thr, keys, partials, unmatched, unmatched_count, prev_nn,                    \
+                         (prev_nn && use_prev) ? 1 : 0);                                                                \
     else                                                                                                                \
       hipLaunchKernelGGL((nn_wave_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
                          g, accept_thr, keys, partials, unmatched, unmatched_count);                                    \

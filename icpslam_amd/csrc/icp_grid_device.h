@@ -193,6 +193,46 @@ __device__ __forceinline__ void octant_row(const int* __restrict__ cell_start, c
   }
 }
 
+// cells^2 radius of the ball that must be searched when a target point is known at squared distance d2 (NaN or +inf:
+// nothing known, no pruning).  See grow_cubes for the two safety terms.
+__device__ __forceinline__ float grid_slack(const GridDesc& g) {
+  return 0.03125f + (float)max(g.nx, max(g.ny, g.nz)) * (4.0f / 8388608.0f);
+}
+__device__ __forceinline__ float ball_cells_sq(const GridDesc& g, float d2) {
+  const float ball = sqrtf(d2) * g.inv_h * 1.03125f + grid_slack(g);
+  return d2 < __builtin_inff() ? ball * ball : __builtin_inff();
+}
+
+// octant_row for a point whose neighbour is known to lie within the ball of ball_sq (cells^2): rows of the octant
+// outside the ball come back empty, the others trimmed to the ball's chord.
+__device__ __forceinline__ void octant_row_in_ball(const int* __restrict__ cell_start, const GridDesc& g, float px, float py,
+                                                   float pz, int cx, int cy, int cz, int sel, float ball_sq, int& lo,
+                                                   int& len, float& margin) {
+  const float ux = (px - g.ox) * g.inv_h, uy = (py - g.oy) * g.inv_h, uz = (pz - g.oz) * g.inv_h;
+  const float fx = ux - (float)cx, fy = uy - (float)cy, fz = uz - (float)cz;
+  const int ax = cx + (fx < 0.5f ? -1 : 0), ay = cy + (fy < 0.5f ? -1 : 0), az = cz + (fz < 0.5f ? -1 : 0);
+  margin = fminf(fminf(fmaxf(fx, 1.0f - fx), fmaxf(fy, 1.0f - fy)), fmaxf(fz, 1.0f - fz));
+  int x0 = max(ax, 0), x1 = min(ax + 1, g.nx - 1);
+  const int yy = ay + (sel & 1), zz = az + ((sel >> 1) & 1);
+  lo = 0;
+  len = 0;
+  if (x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
+    const float dy = fmaxf(fmaxf((float)yy - uy, uy - (float)(yy + 1)), 0.f);
+    const float dz = fmaxf(fmaxf((float)zz - uz, uz - (float)(zz + 1)), 0.f);
+    const float rem = ball_sq - dy * dy - dz * dz;
+    if (rem >= 0.f) {
+      const float w = sqrtf(rem);
+      x0 = (int)fmaxf(floorf(ux - w), (float)x0);
+      x1 = (int)fminf(floorf(ux + w), (float)x1);
+      if (x0 <= x1) {
+        const int row = zz * g.sz + yy * g.sy;
+        lo = cell_start[row + x0];
+        len = cell_start[row + x1 + 1] - lo;
+      }
+    }
+  }
+}
+
 // Cubes of Chebyshev radius 1, 2, 4, ... (capped at r_max) around cell (cx, cy, cz) until the best distance is provably
 // inside the cube; px..cz are wave-uniform, and so is b on entry (the octant's winner, or kEmptyKey) and on return.
 //
@@ -208,7 +248,7 @@ __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, co
                                            const GridDesc& g, float px, float py, float pz, int cx, int cy, int cz,
                                            unsigned int lane, LaneBest& b) {
   const float fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h;
-  const float slack = 0.03125f + (float)max(g.nx, max(g.ny, g.nz)) * (4.0f / 8388608.0f);
+  const float slack = grid_slack(g);
   for (int rho = 1;; rho = min(2 * rho, g.r_max)) {
     const int side = 2 * rho + 1, nrows = side * side;
     const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);

@@ -101,8 +101,13 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 static constexpr int kGridSrcInCellOrder = 1, kGridPackShortRows = 2, kGridOver4GiB = 4;
 hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
-                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream);
+                                 double* partials, int* unmatched, int* unmatched_count, hipStream_t stream,
+                                 float4* prev_nn = nullptr, bool use_prev = false);
 int grid_search_blocks(int n_s);
+// prev_nn (optional, n_s float4): the neighbour each point found, written by every sweep of nn_quad_kernel and, with
+// use_prev, read back by the next one as an upper bound that prunes its search (valid for ANY transform, but only against
+// the same target points and the same src array).  True when launch_nn_grid_search would use it for this size.
+bool grid_search_keeps_prev(int n_s, int flags);
 
 // brute force for a list of source indices (fallback for points the grid could not match); keys pre-filled empty.
 hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,

@@ -56,6 +56,18 @@ struct GridIndex {
   DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
 };
 
+// The neighbour every query found in the last grid sweep (nn_quad_kernel): an upper bound for the next sweep of the same
+// queries over the same target, whatever the transform (icp_grid.hip).  `valid` is cleared at the start of every
+// alignment, so an alignment never depends on the one before it.
+struct PrevNeighbours {
+  DeviceBuf buf;
+  bool valid = false;
+  const void* src = nullptr;     // query array the entries are indexed by
+  const void* sorted = nullptr;  // grid they were found in
+  int n = 0;
+  uint64_t grid_version = 0, src_version = 0;
+};
+
 // The mapper's one-point-per-voxel map (icp_map.hip; octree_mapper.cpp:55-90).
 struct VoxelMap {
   bool defined = false;   // resolution set by icpgpu_map_reset
@@ -91,6 +103,7 @@ struct icpgpu_ctx {
   DeviceBuf keys, partials, sums, out, idx, d2;
   GridIndex grid;            // acceleration structure over the current target
   GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
+  PrevNeighbours prev;       // last sweep's neighbours (search bound of the next sweep)
   VoxelMap map;              // the mapper's map
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
   uint64_t src_version = 1;  // bumped whenever the source cloud changes
@@ -389,6 +402,30 @@ int grid_flags(const GridIndex& G, bool src_in_cell_order) {
          (G.n_binned >= (1 << 28) ? kGridOver4GiB : 0);
 }
 
+// The previous-neighbour buffer for a sweep of src_pts[0..n_q) over G, or nullptr when the kernel chosen for this size
+// keeps none (ICPGPU_PREV=0 switches the mechanism off: A/B measurements).  use = the entries come from a sweep of the
+// same queries over the same target points.
+int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, float4*& buf, bool& use) {
+  static const bool enabled = [] { const char* e = std::getenv("ICPGPU_PREV"); return !e || std::atoi(e) != 0; }();
+  buf = nullptr;
+  use = false;
+  if (!enabled || !grid_search_keeps_prev(n_q, flags)) return ICPGPU_OK;
+  PrevNeighbours& P = c->prev;
+  const void* before = P.buf.ptr;
+  int rc = ensure(c, P.buf, (size_t)n_q * sizeof(float4));
+  if (rc) return rc;
+  use = P.valid && P.buf.ptr == before && P.src == src_pts && P.n == n_q && P.sorted == G.sorted.ptr &&
+        P.grid_version == G.version && P.src_version == c->src_version;
+  P.valid = true;
+  P.src = src_pts;
+  P.sorted = G.sorted.ptr;
+  P.n = n_q;
+  P.grid_version = G.version;
+  P.src_version = c->src_version;
+  buf = static_cast<float4*>(P.buf.ptr);
+  return ICPGPU_OK;
+}
+
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
 // the brute-force kernel. Does not synchronise except for the 4-byte unmatched count.
 int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t, const Xform& T,
@@ -404,9 +441,12 @@ int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, co
   // cell rows for a few hundred queries.
   GridDesc g_open = G.g;
   g_open.r_max = std::min(4 * G.g.r_max, 48);
+  float4* prev = nullptr;
+  bool use_prev = false;
+  if ((rc = prev_neighbours(c, G, src_pts, n_s, grid_flags(G, false), prev, use_prev))) return rc;
   HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, grid_flags(G, false), T, static_cast<const float4*>(G.sorted.ptr),
                                    static_cast<const int*>(G.cell_start.ptr), g_open, 0.f, keys, nullptr, d_list, d_count,
-                                   c->stream));
+                                   c->stream, prev, use_prev));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const int n_un = c->h_ints[0];
@@ -525,14 +565,25 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
     const int blocks = grid_search_blocks(n_q);
     if ((rc = ensure(c, c->partials, (size_t)blocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
+    float4* prev = nullptr;
+    bool use_prev = false;
+    if ((rc = prev_neighbours(c, c->grid, src_pts, n_q, grid_flags(c->grid, ordered), prev, use_prev))) return rc;
     HIP_TRY(c, launch_nn_grid_search(src_pts, n_q, grid_flags(c->grid, ordered), T, static_cast<const float4*>(c->grid.sorted.ptr),
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
-                                     nullptr, c->stream));
+                                     nullptr, c->stream, prev, use_prev));
     EVREC(ev[1]);
     HIP_TRY(c, launch_reduce_final(partials, blocks, /*term_major=*/true, d_sums, c->h_flags_dev, seq, c->stream));
   } else {
+    const float4* red_src = c->src.data();
+    int red_n = n_s;
     if (use_grid) {
-      if ((rc = nn_keys_grid(c, T, keys))) return rc;
+      // the cell-ordered copy of the source when there is one, as in the gated sweep: the sums do not depend on the order,
+      // and the neighbours the last gated sweep left behind (same array) bound this search too
+      if (source_ordered(c)) {
+        red_src = static_cast<const float4*>(c->src_grid.sorted.ptr);
+        red_n = c->src_grid.n_binned;
+      }
+      if ((rc = nn_keys_grid(c, c->grid, red_src, red_n, c->tgt.data(), n_t, T, keys))) return rc;
     } else {
       const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
       if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
@@ -542,7 +593,7 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
     EVREC(ev[1]);
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    HIP_TRY(c, launch_reduce(c->src.data(), n_s, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
+    HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
   }
   EVREC(ev[2]);
   if (timed) c->pending.push_back({slot, use_grid});
@@ -649,6 +700,7 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
     if (rc) return rc;
     c->dev_ms_accum = 0.0;
     c->call_sweeps = c->call_timed = 0;
+    c->prev.valid = false;  // every alignment starts cold
   }
 
   Mat4d final_T = mat4_identity();
@@ -775,6 +827,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   c->prof.aligns += 1;
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   const icpgpu_params& P = c->params;
+  c->prev.valid = false;  // every alignment starts cold
   float guess[16];
   if (guess_in) std::memcpy(guess, guess_in, sizeof(guess));
   else mat4f_identity(guess);
@@ -827,9 +880,13 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     // correspondences: exact NN keys (only those with d2 < r^2 are used, so the grid's cutoff search is complete)
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (grid_ready(c)) {
+      float4* prev = nullptr;  // each outer iteration's neighbours bound the next one's search
+      bool use_prev = false;
+      int prc = prev_neighbours(c, c->grid, c->src.data(), n_s, grid_flags(c->grid, false), prev, use_prev);
+      if (prc) return prc;
       HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, grid_flags(c->grid, false), Tq, static_cast<const float4*>(c->grid.sorted.ptr),
                                        static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, keys, nullptr, nullptr,
-                                       nullptr, c->stream));
+                                       nullptr, c->stream, prev, use_prev));
     } else {
       const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
       if (plan.splits > 1) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));

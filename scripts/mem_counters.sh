@@ -23,7 +23,7 @@ acc = collections.defaultdict(list)
 for path in glob.glob("$O/p*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
-        if "nn_wave_kernel<false, true, false" in r["Kernel_Name"]:
+        if ("nn_quad_kernel<false, true, false" in r["Kernel_Name"] or "nn_wave_kernel<false, true, false" in r["Kernel_Name"]):
             per[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (d, c), v in per.items():
         acc[c].append(v)

@@ -6,7 +6,7 @@ import csv, glob, json, os, sys
 
 root, size = sys.argv[1], sys.argv[2]
 KEY = "x".join(f"{int(v) // 1000}k" for v in size.split("x"))  # bench.py workload name, e.g. 200kx200k
-KERNELS = {"grid": "nn_wave_kernel<false, true, false", "brute": "nn_brute_kernel<0, 4>"}
+KERNELS = {"grid": "nn_quad_kernel<false, true, false", "brute": "nn_brute_kernel<0, 4>"}  # 200k: the quad kernel
 
 
 def per_launch(mode, ctr):

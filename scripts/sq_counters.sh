@@ -18,7 +18,7 @@ for sub in ("a", "b"):
     for path in glob.glob("$O/%s/**/*counter_collection.csv" % sub, recursive=True):
         per = collections.defaultdict(float)
         for r in csv.DictReader(open(path)):
-            if "nn_wave_kernel<false, true, false" in r["Kernel_Name"]:
+            if ("nn_quad_kernel<false, true, false" in r["Kernel_Name"] or "nn_wave_kernel<false, true, false" in r["Kernel_Name"]):
                 per[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
         for (d, c), v in per.items():
             acc[c].append(v)
