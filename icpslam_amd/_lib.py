@@ -39,7 +39,8 @@ class Profile(C.Structure):
                 ("gicp_cov_launches", C.c_uint64), ("gicp_cov_ms", C.c_double), ("gicp_cost_launches", C.c_uint64),
                 ("map_inserts", C.c_uint64), ("map_insert_ms", C.c_double), ("map_points_in", C.c_uint64),
                 ("map_nn_launches", C.c_uint64), ("map_nn_ms", C.c_double),
-                ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64)]
+                ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64),
+                ("grid_bounded", C.c_uint64)]
 
 
 class Pose(C.Structure):

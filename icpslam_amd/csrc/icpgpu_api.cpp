@@ -416,6 +416,7 @@ int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, in
   if (rc) return rc;
   use = P.valid && P.buf.ptr == before && P.src == src_pts && P.n == n_q && P.sorted == G.sorted.ptr &&
         P.grid_version == G.version && P.src_version == c->src_version;
+  c->prof.grid_bounded += use ? 1 : 0;
   P.valid = true;
   P.src = src_pts;
   P.sorted = G.sorted.ptr;
@@ -1298,6 +1299,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.iterations += p.iterations; c->prof.aligns += p.aligns;
     c->prof.grid_launches += p.grid_launches; c->prof.grid_ms += p.grid_ms; c->prof.grid_bytes += p.grid_bytes;
     c->prof.nn_timed += p.nn_timed; c->prof.grid_timed += p.grid_timed; c->prof.reduce_timed += p.reduce_timed;
+    c->prof.grid_bounded += p.grid_bounded;
     c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
     c->prof.voxel_launches += p.voxel_launches; c->prof.voxel_ms += p.voxel_ms; c->prof.voxel_bytes += p.voxel_bytes;
     c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;

@@ -133,6 +133,7 @@ typedef struct {
   uint64_t nn_timed;          /* launches behind nn_ms / grid_ms / reduce_ms: kernel timing is sampled, because the three */
   uint64_t grid_timed;        /*   event records around a sweep are barrier packets that cost 6-7 us per iteration */
   uint64_t reduce_timed;
+  uint64_t grid_bounded;      /* grid sweeps whose searches were pruned by the neighbours the previous sweep found */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

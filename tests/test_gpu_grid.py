@@ -216,3 +216,60 @@ def test_fuzz_grid_keys_equal_brute_force(ctx, seed):
         if sv[1] > 1e-6 * sv[0]:          # a plane of correspondences at least: the rotation is determined
             assert np.allclose(res[NN_GRID]["T"], res[NN_BRUTE]["T"], atol=1e-5)
             assert np.allclose(res[NN_GRID]["T"], tr["final"], atol=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_quad_kernel_and_previous_neighbour_bound(ctx, seed):
+    """Clouds large enough for nn_quad_kernel (>= 32k queries), searched several times in a row under different poses
+    WITHOUT re-setting the clouds: from the second search on, every query's search is pruned by the distance to the
+    neighbour it found under the previous pose (icp_grid.hip).  Small steps, large jumps and a jump back: every search must
+    still return the brute-force kernel's keys bit for bit, ties included."""
+    rng = np.random.default_rng(7000 + seed)
+    kinds = ["uniform", "planes", "clusters", "line", "lattice"]
+    ks, kt = kinds[seed % 5], kinds[(seed // 2 + 1) % 5]
+    n_s, n_t = int(rng.integers(33000, 70000)), int(rng.integers(5000, 90000))
+    src, tgt = _fuzz_cloud(rng, n_s, ks), _fuzz_cloud(rng, n_t, kt)
+    if seed % 3 == 0:
+        tgt[rng.integers(0, n_t, 20), :3] = np.nan
+        src[rng.integers(0, n_s, 20), :3] = np.inf
+    if seed % 4 == 1:
+        tgt[n_t // 2:n_t // 2 + 500] = tgt[:500]          # exact duplicates: lowest index must win
+    gate = float(rng.choice([0.07, 0.4, 1.0, 3.0]))
+    ctx.set_params(ctx.default_params(), nn_mode=NN_GRID, max_correspondence_distance=gate)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    T0 = synth.pose_matrix(*rng.uniform(-1, 1, 3), *rng.uniform(-0.2, 0.2, 3))
+    poses = [T0]
+    for step in (0.01, 0.05, 0.3, 3.0, 0.0):
+        poses.append(synth.pose_matrix(*rng.uniform(-step, step, 3), *rng.uniform(-step / 5, step / 5, 3)) @ poses[-1])
+    poses.append(T0)                                       # back where the first neighbours came from
+    for k, T in enumerate(poses):
+        ctx.set_params(ctx.default_params(), nn_mode=NN_GRID, max_correspondence_distance=gate)
+        ctx.profile_reset()
+        ig, dg = ctx.nn(T)
+        prof = ctx.profile()
+        assert prof.grid_launches == 1 and prof.grid_bounded == (1 if k else 0)   # pruned from the second search on
+        ctx.set_params(ctx.default_params(), nn_mode=NN_BRUTE, max_correspondence_distance=gate)
+        ib, db = ctx.nn(T)
+        assert np.array_equal(ig, ib), f"pose {k}: {np.count_nonzero(ig != ib)} indices differ"
+        assert np.array_equal(dg.view(np.uint32), db.view(np.uint32)), f"pose {k}"
+
+
+@pytest.mark.parametrize("n,seed", [(40000, 31), (120000, 32)])
+def test_quad_kernel_alignment_equals_brute_force_alignment(ctx, n, seed):
+    """Whole alignments through nn_quad_kernel (fused sums, previous-neighbour bound from the second iteration on, at 120k
+    also the cell-ordered source) against the brute-force path: same iteration count, same correspondences, same transform."""
+    src, tgt, _ = synth.make_pair(n, n, seed=seed)
+    res = {}
+    for mode in (NN_GRID, NN_BRUTE):
+        ctx.set_params(ctx.default_params(), nn_mode=mode, max_iterations=12, force_iterations=1)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        ctx.profile_reset()
+        res[mode] = ctx.align(want_fitness=True)
+        # 12 gated sweeps + the fitness sweep; all but the first of the alignment are bounded
+        assert ctx.profile().grid_bounded == (12 if mode == NN_GRID else 0)
+    g, b = res[NN_GRID], res[NN_BRUTE]
+    assert g["iterations"] == b["iterations"] == 12 and g["n_corr"] == b["n_corr"]
+    assert np.abs(g["T"] - b["T"]).max() <= 1e-6
+    assert abs(g["mse"] - b["mse"]) <= 1e-9 * max(1.0, b["mse"]) and abs(g["fitness"] - b["fitness"]) <= 1e-9 * max(1.0, b["fitness"])
