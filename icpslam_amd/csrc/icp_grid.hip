@@ -374,7 +374,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
   // Temporal coherence: prev_nn[i] holds the neighbour point i found in the previous sweep over the SAME target (NaN:
   // none).  Whatever the transform is now, that point is a target point, so its distance bounds the new neighbour's:
   // only the part of the octant inside that ball is read (near convergence: 1-2 cells of the 8).
-  float lbx = 0.f, lby = 0.f, lbz = 0.f, lbound = __builtin_nanf("");
+  float lbound = __builtin_nanf("");
   if (lvalid) {
     const float4 s = src[il];
     float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -384,9 +384,6 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
     if (lfin) {
       cell_of(g, lpx, lpy, lpz, lcx, lcy, lcz);
       if (use_prev) {
-        lbx = pq.x;
-        lby = pq.y;
-        lbz = pq.z;
         lbound = dist2(pq.x, pq.y, pq.z, lpx, lpy, lpz);  // the expression consider() uses: the same bits when it is met again
       }
       octant_row_in_ball(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, ball_cells_sq(g, lbound), llo, llen, lmargin);
@@ -478,10 +475,11 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
       // the cubes meet the point itself again, same distance bits, and its real index wins the tie.
       const float pb = readlane_f(lbound, sl);
       if (pb < __builtin_inff() && !(__uint_as_float((unsigned int)(c.key >> 32)) <= pb)) {
+        const float4 pq = prev_nn[k0 + (sl >> 2) * stride];  // not yet overwritten: this point's pass is this one
         c.key = ((unsigned long long)__float_as_uint(pb) << 32) | 0xFFFFFFFFull;
-        c.qx = readlane_f(lbx, sl);
-        c.qy = readlane_f(lby, sl);
-        c.qz = readlane_f(lbz, sl);
+        c.qx = pq.x;
+        c.qy = pq.y;
+        c.qz = pq.z;
       }
       const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, ux, uy, uz, cx, cy, cz, lane, c);
       if (grp_base == gl) {
