@@ -492,8 +492,10 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
     }
 
     if (prev_nn && sub == 0 && valid) {
-      const float none = __builtin_nanf("");
-      prev_nn[qi_src] = found ? make_float4(qx, qy, qz, 0.f) : make_float4(none, none, none, 0.f);
+      // the best point met, certified or not (beyond the gate it is still a target point, hence a bound for the next
+      // sweep -- getFitnessScore's ungated one in particular); NaN when nothing was met at all
+      const float bd = __uint_as_float((unsigned int)(gkey >> 32)), none = __builtin_nanf("");
+      prev_nn[qi_src] = (fin && bd == bd) ? make_float4(qx, qy, qz, 0.f) : make_float4(none, none, none, 0.f);
     }
     if constexpr (WRITE_KEYS) {
       if (sub == 0 && valid) keys[qi_src] = found ? gkey : kEmptyKey;
