@@ -239,8 +239,8 @@ def main():
                 "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
                 "algorithmic_bytes_per_launch": alg_bytes_fused,
                 "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
-                        "(SURVEY.md 8(d) fused lower bound); an exact NN search is bound by L2 transactions and instruction issue "
-                        "(PMC: TCC ~74 % busy), not by HBM streaming -- DESIGN.md section 5",
+                        "(SURVEY.md 8(d) fused lower bound); an exact NN search is bound by instruction issue and cache transactions "
+                        "(PMC: VALU 68 % of the SIMD cycles), not by HBM streaming -- DESIGN.md section 5",
                 "brute_force_kernel": brute_roofline}
         else:
             nn_ms = prof.nn_ms / max(1, prof.nn_timed)
