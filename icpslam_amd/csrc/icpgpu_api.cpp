@@ -86,7 +86,8 @@ struct VoxelMap {
 constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
 constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
 constexpr double kDenseCellPopulation = 64.0;   // shrink the cells beyond this point-weighted population ...
-constexpr double kTargetCellPopulation = 18.0;  // ... down to about this one
+constexpr double kTargetCellPopulation = 36.0;  // ... down to about this one (18 until the search was ball-pruned: 200k x 1M from identity 77 -> 65 us)
+constexpr double kSparseCellPopulation = 20.0;  // double the cells below this one (2.5 until then: 50k x 50k from identity 31 -> 27 us)
 constexpr size_t kOrderSourceMin = 100000;      // AUTO: order the source by cell from this size on (see ensure_source_order)
 constexpr int kEventRing = 64;                   // sweeps whose kernel timing may be outstanding
 constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-force kernel is launch-latency bound anyway
@@ -243,7 +244,7 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
 }
 
 static double sparse_population() {  // ICPGPU_SPARSE_POP overrides (tuning experiments only)
-  static const double v = [] { const char* e = std::getenv("ICPGPU_SPARSE_POP"); return e ? std::atof(e) : 2.5; }();
+  static const double v = [] { const char* e = std::getenv("ICPGPU_SPARSE_POP"); return e ? std::atof(e) : kSparseCellPopulation; }();
   return v;
 }
 
@@ -336,7 +337,8 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
     const int binned = c->h_ints[10];
     const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
     if (attempt == 0 && adapt && pop > kDenseCellPopulation) {
-      const double h_new = std::max(h * std::sqrt(kTargetCellPopulation / pop), cut / 16.0);
+      static const double target_pop = [] { const char* e = std::getenv("ICPGPU_TARGET_POP"); return e ? std::atof(e) : kTargetCellPopulation; }();
+      const double h_new = std::max(h * std::sqrt(target_pop / pop), cut / 16.0);
       if (h_new < 0.9 * h) {
         h = h_new;
         shrunk = true;
