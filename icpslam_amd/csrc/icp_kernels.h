@@ -110,6 +110,11 @@ int grid_search_blocks(int n_s);
 bool grid_search_keeps_prev(int n_s, int flags);
 
 // brute force for a list of source indices (fallback for points the grid could not match); keys pre-filled empty.
+// the same for at most kFewQueries listed queries, whose number may live in device memory (count_ptr, else n_list): the
+// kernel then does nothing for 0 or more than kFewQueries of them and reports the number in *count_out (device-visible)
+static constexpr int kFewQueries = 64;
+hipError_t launch_nn_brute_few(const float4* src, const int* list, const int* count_ptr, int n_list, const float4* tgt, int n_t,
+                               const Xform& T, unsigned long long* keys, int* count_out, hipStream_t stream);
 hipError_t launch_nn_brute_list(const float4* src, const int* list, int n_list, const float4* tgt, int n_t,
                                 const Xform& T, int num_cus, unsigned long long* keys, hipStream_t stream);
 

@@ -431,8 +431,11 @@ int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, in
 
 // Exact NN keys for every source point via the grid: points the grid cannot match within its cutoff are finished by
 // the brute-force kernel. Does not synchronise except for the 4-byte unmatched count.
+// With `deferred` the completion runs without a host round trip: the few-queries kernel reads the number of unmatched
+// points on the device and leaves it in *deferred (mapped host memory); the caller looks at it once its own results have
+// arrived and calls complete_deferred_keys() in the rare case that there were too many for that kernel.
 int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t, const Xform& T,
-                 unsigned long long* keys) {
+                 unsigned long long* keys, int* deferred = nullptr) {
   int rc = ensure(c, G.unmatched, (size_t)(n_s + 1) * sizeof(int));
   if (rc) return rc;
   int* d_list = static_cast<int*>(G.unmatched.ptr);
@@ -450,12 +453,24 @@ int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, co
   HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, grid_flags(G, false), T, static_cast<const float4*>(G.sorted.ptr),
                                    static_cast<const int*>(G.cell_start.ptr), g_open, 0.f, keys, nullptr, d_list, d_count,
                                    c->stream, prev, use_prev));
+  if (deferred) {
+    HIP_TRY(c, launch_nn_brute_few(src_pts, d_list, d_count, 0, tgt_pts, n_t, T, keys, deferred, c->stream));
+    return ICPGPU_OK;
+  }
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const int n_un = c->h_ints[0];
   c->prof.grid_fallback_points += (uint64_t)n_un;
   if (n_un > 0)
     HIP_TRY(c, launch_nn_brute_list(src_pts, d_list, n_un, tgt_pts, n_t, T, c->num_cus, keys, c->stream));
+  return ICPGPU_OK;
+}
+
+// the tiled brute-force completion for a deferred search that listed more than kFewQueries points
+int complete_deferred_keys(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t,
+                           const Xform& T, unsigned long long* keys, int n_un) {
+  const int* d_list = static_cast<const int*>(G.unmatched.ptr);
+  HIP_TRY(c, launch_nn_brute_list(src_pts, d_list, n_un, tgt_pts, n_t, T, c->num_cus, keys, c->stream));
   return ICPGPU_OK;
 }
 
@@ -560,6 +575,9 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
   const bool timed = c->timing_every <= 1 || (c->sweep_counter++ % (unsigned)c->timing_every) == 0;
 #define EVREC(e) do { if (timed) HIP_TRY(c, hipEventRecord((e), c->stream)); } while (0)
   EVREC(ev[0]);
+  const float4* red_src = nullptr;  // keys path: the array the keys index
+  int red_n = 0;
+  volatile int* few_host = nullptr;  // ungated grid search: number of points its grid stage left unmatched
   if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
     const bool ordered = source_ordered(c);
@@ -577,8 +595,8 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
     EVREC(ev[1]);
     HIP_TRY(c, launch_reduce_final(partials, blocks, /*term_major=*/true, d_sums, c->h_flags_dev, seq, c->stream));
   } else {
-    const float4* red_src = c->src.data();
-    int red_n = n_s;
+    red_src = c->src.data();
+    red_n = n_s;
     if (use_grid) {
       // the cell-ordered copy of the source when there is one, as in the gated sweep: the sums do not depend on the order,
       // and the neighbours the last gated sweep left behind (same array) bound this search too
@@ -586,7 +604,10 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
         red_src = static_cast<const float4*>(c->src_grid.sorted.ptr);
         red_n = c->src_grid.n_binned;
       }
-      if ((rc = nn_keys_grid(c, c->grid, red_src, red_n, c->tgt.data(), n_t, T, keys))) return rc;
+      few_host = reinterpret_cast<volatile int*>(c->h_sums + 20);  // a spare slot of the mailbox
+      *few_host = -1;
+      if ((rc = nn_keys_grid(c, c->grid, red_src, red_n, c->tgt.data(), n_t, T, keys, reinterpret_cast<int*>(c->h_sums_dev + 20))))
+        return rc;
     } else {
       const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
       if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
@@ -613,7 +634,18 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
   }
   c->prof.reduce_launches += 1;
   c->prof.reduce_bytes += (use_grid && !open_range) ? 136ull * (uint64_t)grid_search_blocks(n_s) : 40ull * (uint64_t)n_s + 136;
-  return wait_sums(c, seq);
+  rc = wait_sums(c, seq);
+  if (rc || !few_host) return rc;
+  // ungated search: the few-queries kernel completed the unmatched points unless there were too many for it (then the sums
+  // just received miss them: tiled brute-force completion and a second reduction)
+  const int n_un = *few_host;
+  c->prof.grid_fallback_points += (uint64_t)(n_un > 0 ? n_un : 0);
+  if (n_un <= kFewQueries) return ICPGPU_OK;
+  if ((rc = complete_deferred_keys(c, c->grid, red_src, red_n, c->tgt.data(), n_t, T, keys, n_un))) return rc;
+  const unsigned long long seq2 = ++c->sums_seq;
+  HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq2, c->stream));
+  c->prof.reduce_launches += 1;
+  return wait_sums(c, seq2);
 }
 
 int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {

@@ -273,3 +273,29 @@ def test_quad_kernel_alignment_equals_brute_force_alignment(ctx, n, seed):
     assert g["iterations"] == b["iterations"] == 12 and g["n_corr"] == b["n_corr"]
     assert np.abs(g["T"] - b["T"]).max() <= 1e-6
     assert abs(g["mse"] - b["mse"]) <= 1e-9 * max(1.0, b["mse"]) and abs(g["fitness"] - b["fitness"]) <= 1e-9 * max(1.0, b["fitness"])
+
+
+@pytest.mark.parametrize("n,gate,many", [(6000, 1.0, False), (45000, 1.0, False), (20000, 0.05, True), (45000, 0.05, True)])
+def test_fitness_completion_paths(ctx, n, gate, many):
+    """getFitnessScore has no gate: points the grid stage leaves unmatched are completed by brute force -- up to 64 of them
+    by the few-queries kernel without a host round trip (the count stays on the device), more than that by the tiled
+    kernel after the first sums came back.  Both must give the brute-force path's score, and the oracle's."""
+    rng = np.random.default_rng(n)
+    if many:   # sparse uniform clouds, tiny gate: (nearly) every point is left to the completion
+        src, tgt = _fuzz_cloud(rng, n, "uniform"), _fuzz_cloud(rng, n, "uniform")
+    else:
+        src, tgt, _ = synth.make_pair(n, n, seed=n)
+    got = {}
+    for mode in (NN_GRID, NN_BRUTE):
+        ctx.set_params(ctx.default_params(), nn_mode=mode, max_correspondence_distance=gate, max_iterations=3)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        ctx.profile_reset()
+        got[mode] = ctx.align(want_fitness=True)
+        if mode == NN_GRID:
+            left = ctx.profile().grid_fallback_points
+            assert (left > 64) == many, left
+    g, b = got[NN_GRID], got[NN_BRUTE]
+    assert g["n_corr"] == b["n_corr"] and abs(g["fitness"] - b["fitness"]) <= 1e-9 * max(1.0, b["fitness"])
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_correspondence_distance=gate, max_iterations=3), want_fitness=True)
+    assert abs(g["fitness"] - ref["fitness"]) <= 1e-6 * max(1.0, ref["fitness"])
