@@ -306,13 +306,10 @@ __global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned 
 
 // ---- one BFGS evaluation ---------------------------------------------------------------------------------------
 // terms: 0 = m, 1 = sum r^T M r, 2..4 = sum M r, 5..13 = sum (base p)(M r)^T (row-major), 14 = sum d2 of the NN sweep
-__global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict__ src, int n_s,
-                                                        const float4* __restrict__ tgt,
-                                                        const unsigned long long* __restrict__ keys, float thr, Xform T,
-                                                        Xform base, const double* __restrict__ maha6,
-                                                        double* __restrict__ partials, unsigned long long* flags,
-                                                        unsigned long long seq) {
-  double acc[kReduceTerms];
+__device__ __forceinline__ void gicp_accumulate(double (&acc)[kReduceTerms], const float4* __restrict__ src, int n_s,
+                                                const float4* __restrict__ tgt,
+                                                const unsigned long long* __restrict__ keys, float thr, const Xform& T,
+                                                const Xform& base, const double* __restrict__ maha6) {
 #pragma unroll
   for (int k = 0; k < kReduceTerms; ++k) acc[k] = 0.0;
   // Four correspondences per lane and trip, their loads issued together: key -> (target point, Mahalanobis matrix) is a
@@ -366,11 +363,79 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
       acc[14] += (double)d2;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict__ src, int n_s,
+                                                        const float4* __restrict__ tgt,
+                                                        const unsigned long long* __restrict__ keys, float thr, Xform T,
+                                                        Xform base, const double* __restrict__ maha6,
+                                                        double* __restrict__ partials, unsigned long long* flags,
+                                                        unsigned long long seq) {
+  double acc[kReduceTerms];
+  gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
   block_reduce_store<4>(acc, partials);
   // "direct" mode (flags != nullptr): partials IS the host mailbox and there is no second kernel -- the host adds the few
   // workgroups' partials itself.  The 17 stores above come from wave 0, like this flag, so the release orders them.
   if (flags != nullptr && threadIdx.x == 0)
     __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- resident evaluation server ------------------------------------------------------------------------------------
+// A BFGS run is ~35 DEPENDENT evaluations of a few microseconds of work each; launched one by one they cost 11 us apiece,
+// most of it launch and dispatch latency.  This kernel stays resident for the whole run instead (<= kGicpDirectBlocks
+// workgroups, all co-resident by construction).  The command line -- 12 floats of T, then a sequence number -- lives in
+// FINE-GRAINED DEVICE memory that the host writes through the PCIe BAR (posted writes, delivered in order: the number is
+// written last, behind a store fence), so every workgroup polls it locally: a poll is an uncached read of HBM, not a PCIe
+// round trip (polling a line in HOST memory from one workgroup and relaying it through device memory with release /
+// acquire fences was measured first: 13 us per evaluation, slower than a launch).  Every workgroup then evaluates its
+// share and stores its 17 partials + flag into the host mailbox exactly like gicp_cost_kernel's direct mode.  Sequence
+// number kGicpServerExit ends the run; so does 50 ms without a command (the host fell asleep or died: never leave a
+// spinning kernel behind -- the host notices the idle stream and goes back to single launches).
+__global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restrict__ src, int n_s,
+                                                          const float4* __restrict__ tgt,
+                                                          const unsigned long long* __restrict__ keys, float thr, Xform base,
+                                                          const double* __restrict__ maha6, double* __restrict__ host_partials,
+                                                          unsigned long long* host_flags, unsigned int* cmd,
+                                                          unsigned int first_seq, unsigned int seq_hi) {
+  __shared__ Xform s_T;
+  __shared__ unsigned int s_seq;
+  const long long patience = 5000000;  // 50 ms of the 100 MHz wall clock
+  unsigned int expect = first_seq;
+  for (;;) {
+    if (threadIdx.x < 16) {
+      // lanes 0..11 fetch T once lane 12 has seen the number (the line is uncached: every load reads memory)
+      unsigned int got = kGicpServerExit;
+      const long long t0 = (long long)wall_clock64();
+      for (;;) {
+        const unsigned int v = __hip_atomic_load(&cmd[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == expect || v == kGicpServerExit) {
+          got = v;
+          break;
+        }
+        if ((long long)wall_clock64() - t0 > patience) break;  // got stays kGicpServerExit
+      }
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the loads below are issued after the one above has returned
+      if (threadIdx.x < 12) s_T.m[threadIdx.x] = __uint_as_float(__hip_atomic_load(&cmd[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (threadIdx.x == 12) s_seq = got;
+    }
+    __syncthreads();
+    const unsigned int seq = s_seq;
+    if (seq == kGicpServerExit) {
+      // acknowledge: the host does not reuse the command line before this kernel has left
+      if (blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(&host_flags[0], ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    const Xform T = s_T;
+    double acc[kReduceTerms];
+    gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
+    block_reduce_store<4>(acc, host_partials);
+    if (threadIdx.x == 0)
+      __hip_atomic_store(&host_flags[blockIdx.x], ((unsigned long long)seq_hi << 32) | seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    expect = seq + 1u;
+    if (expect == kGicpServerExit) expect = 0u;
+    __syncthreads();  // s_T / s_seq are rewritten in the next round
+  }
 }
 
 }  // namespace
@@ -413,6 +478,14 @@ hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt
                                    unsigned long long* host_flags, unsigned long long seq, hipStream_t stream) {
   hipLaunchKernelGGL(gicp_cost_kernel, dim3(gicp_direct_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base,
                      maha6, host_partials, host_flags, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_gicp_server(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                              const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
+                              unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream) {
+  hipLaunchKernelGGL(gicp_server_kernel, dim3(gicp_direct_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base,
+                     maha6, host_partials, host_flags, cmd, first_seq, seq_hi);
   return hipGetLastError();
 }
 

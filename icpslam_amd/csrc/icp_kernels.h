@@ -144,6 +144,15 @@ hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt
                                    const Xform& T, const Xform& base, const double* maha6, double* host_partials,
                                    unsigned long long* host_flags, unsigned long long seq, hipStream_t stream);
 
+// Resident variant for a whole BFGS run (icp_gicp.hip): the kernel waits for commands in a line of fine-grained device
+// memory the host writes through the BAR (cmd: 12 floats of T, then the sequence number), evaluates, answers through
+// host_partials / host_flags like the direct kernel (flag = seq_hi << 32 | sequence number) and leaves on sequence number
+// kGicpServerExit (acknowledged by host_flags[0] = ~0) or after 50 ms without a command.
+static constexpr unsigned int kGicpServerExit = 0xFFFFFFFFu;
+hipError_t launch_gicp_server(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                              const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
+                              unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream);
+
 // ---- the mapper's one-point-per-voxel map (icp_map.hip), SURVEY.md 8(f4) --------------------------------------------
 struct MapDesc {
   double ox, oy, oz;  // lattice origin = first inserted point - resolution / 2 (PCL OctreePointCloud bounding-box rule)

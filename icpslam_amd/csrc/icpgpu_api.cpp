@@ -17,6 +17,9 @@
 #include <cstring>
 #include <new>
 #include <atomic>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <string>
 #include <thread>
 #include <vector>
@@ -94,6 +97,15 @@ constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-fo
 
 }  // namespace
 
+static bool gicp_server_enabled() {  // ICPGPU_GICP_SERVER=0: every GICP evaluation is its own launch
+#if defined(__x86_64__)
+  static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_SERVER"); return !e || std::atoi(e) != 0; }();
+  return v;
+#else
+  return false;  // the command protocol relies on x86 store ordering
+#endif
+}
+
 struct icpgpu_ctx {
   int device = 0;
   int num_cus = 256;
@@ -125,6 +137,9 @@ struct icpgpu_ctx {
   double* h_gicp_dev = nullptr;
   volatile unsigned long long* h_gicp_flags = nullptr;
   unsigned long long* h_gicp_flags_dev = nullptr;
+  // resident evaluation server (icp_gicp.hip): its command line, fine-grained device memory the host writes through the BAR
+  unsigned int* gicp_cmd = nullptr;
+  bool gicp_server_on = false;
   // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
   std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
   struct PendingSweep { int slot; bool grid; };
@@ -856,7 +871,87 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   return ICPGPU_OK;
 }
 
+// ---- the resident evaluation server of a BFGS run (gicp_server_kernel) ---------------------------------------------
+// A command is four 16-byte chunks {3 floats of T, sequence number}; each chunk is ONE aligned 16-byte store, so the
+// device never sees half a chunk, and it acts once all four carry the number it waits for.
+static void gicp_server_command(icpgpu_ctx* c, unsigned int seq, const Xform& T) {
+#if defined(__x86_64__)
+  // T first, the number last, a store fence in between and behind: posted writes reach the device in that order
+  volatile unsigned int* line = c->gicp_cmd;
+  for (int k = 0; k < 12; ++k) {
+    unsigned int w;
+    std::memcpy(&w, &T.m[k], sizeof w);
+    line[k] = w;
+  }
+  _mm_sfence();
+  line[12] = seq;
+  _mm_sfence();
+#else
+  (void)c; (void)seq; (void)T;
+#endif
+}
+
+// Start the server for the evaluations numbered sums_seq + 1, + 2, ... (queued behind whatever the stream still holds).
+static int gicp_server_start(icpgpu_ctx* c, int n_s, const unsigned long long* keys, float thr, const Xform& base,
+                             const double* maha) {
+  c->gicp_server_on = false;
+  if (!c->gicp_cmd) return ICPGPU_OK;
+  unsigned int next = (unsigned int)(c->sums_seq + 1);
+  if (next == kGicpServerExit || next == 0u) {  // keep the two reserved numbers out of the run's first command
+    c->sums_seq += 2;
+    next = (unsigned int)(c->sums_seq + 1);
+  }
+  Xform none{};
+  gicp_server_command(c, next - 1u, none);  // a number the server does not wait for: the line may still hold an old exit
+  HIP_TRY(c, launch_gicp_server(c->src.data(), n_s, c->tgt.data(), keys, thr, base, maha, c->h_gicp_dev, c->h_gicp_flags_dev,
+                                c->gicp_cmd, next, (unsigned int)((c->sums_seq + 1) >> 32), c->stream));
+  c->gicp_server_on = true;
+  return ICPGPU_OK;
+}
+
+static void gicp_server_stop(icpgpu_ctx* c) {
+  if (!c->gicp_server_on) return;
+  Xform none{};
+  gicp_server_command(c, kGicpServerExit, none);
+  c->gicp_server_on = false;
+  // wait for the poller's acknowledgement (a few microseconds): the command line is about to be reused
+  for (unsigned spins = 1; c->h_gicp_flags[0] != ~0ull; ++spins) {
+    if ((spins & 0x3FFu) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) break;  // gone already (or an error: the caller's next call reports it)
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+
+// 0: the flags arrived; 1: the stream went idle without them (the server gave up waiting); < 0: error
+static int wait_flags_server(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_flags, unsigned long long seq) {
+  for (unsigned spins = 1;; ++spins) {
+    bool all = true;
+    for (int k = 0; k < n_flags; ++k) all = all && (flags[k] == seq);
+    if (all) break;
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        bool ok = true;
+        for (int k = 0; k < n_flags; ++k) ok = ok && (flags[k] == seq);
+        if (ok) break;
+        return 1;
+      }
+      if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a GICP evaluation: %s", hipGetErrorString(q));
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  struct ServerGuard {  // whatever way this function is left, no server stays behind
+    icpgpu_ctx* c;
+    ~ServerGuard() { gicp_server_stop(c); }
+  } server_guard{c};
   const auto t_start = std::chrono::steady_clock::now();
   init_result(res);
   c->prof.aligns += 1;
@@ -939,16 +1034,30 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       gicp_apply_state(T, x);
       // ~300 evaluations per align, each a dependent launch: ONE kernel of a few workgroups whose partial sums land in the
       // polled host mailbox; the host adds them in workgroup order (deterministic)
-      const unsigned long long seq = ++c->sums_seq;
+      unsigned long long seq = ++c->sums_seq;
+      if ((unsigned int)seq == kGicpServerExit) seq = (c->sums_seq += 2);  // (never a command number; the server skips it too)
       const int nblk = gicp_direct_blocks(n_s);
-      if (launch_gicp_cost_direct(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
-                                  c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
-        return false;
-      if (wait_flags(c, c->h_gicp_flags, nblk, seq) != ICPGPU_OK) return false;
-      for (int k = 0; k < kReduceTerms; ++k) {
-        double v = 0.0;
-        for (int b = 0; b < nblk; ++b) v += c->h_gicp[(size_t)b * kReduceTerms + k];
-        c->h_sums[k] = v;
+      bool have = false;
+      if (c->gicp_server_on) {  // the resident server evaluates; no launch
+        gicp_server_command(c, (unsigned int)seq, xform_from_f16(T));
+        const int w = wait_flags_server(c, c->h_gicp_flags, nblk, seq);
+        if (w < 0) return false;
+        have = w == 0;
+        if (!have) c->gicp_server_on = false;  // it gave up (50 ms without a command): single launches from here on
+      }
+      if (!have) {
+        if (launch_gicp_cost_direct(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
+                                    c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
+          return false;
+        if (wait_flags(c, c->h_gicp_flags, nblk, seq) != ICPGPU_OK) return false;
+      }
+      {  // workgroup by workgroup (every term still adds its partials in workgroup order): one sequential pass over lines the
+         // device has just written -- term by term the same loop strode through them 17 times, a cache miss per access
+        double v[kReduceTerms] = {};
+        const double* part = c->h_gicp;
+        for (int b = 0; b < nblk; ++b, part += kReduceTerms)
+          for (int k = 0; k < kReduceTerms; ++k) v[k] += part[k];
+        for (int k = 0; k < kReduceTerms; ++k) c->h_sums[k] = v[k];
       }
       c->prof.gicp_cost_launches += 1;
       const double* s = c->h_sums;
@@ -969,6 +1078,8 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       }
       return true;
     };
+    // the ~35 dependent evaluations of this outer iteration go to a resident kernel (queued behind the two kernels above)
+    if ((rc = gicp_server_start(c, n_s, keys, thr_excl, base, maha))) return rc;
     // number of correspondences (one evaluation at the current state; it is also the BFGS start, cached by the solver)
     Vec6 x = gicp_state_from_matrix(transformation);
     GicpEval probe;
@@ -980,6 +1091,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       break;
     }
     const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
+    gicp_server_stop(c);
     if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
     if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
       state = ICPGPU_NOT_CONVERGED;
@@ -1106,7 +1218,9 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
   c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
   {
-    const size_t n_d = (size_t)kGicpDirectBlocks * kReduceTerms + 8 + kGicpDirectBlocks;  // partials, gap, flags
+    const size_t n_flags_end = (size_t)kGicpDirectBlocks * kReduceTerms + 8 + kGicpDirectBlocks;  // partials, gap, flags
+    const size_t cmd_off = (n_flags_end + 7) & ~(size_t)7;                                        // 64-byte aligned
+    const size_t n_d = cmd_off + 8;                                                              // + the server's command line
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_gicp), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
         hipSuccess)
       return bail("hipHostMalloc", e);
@@ -1116,6 +1230,15 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
     const size_t off = (size_t)kGicpDirectBlocks * kReduceTerms + 8;
     c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
     c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
+    (void)cmd_off;
+  }
+  if (gicp_server_enabled()) {  // no such memory (no large BAR): the evaluations stay single launches
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_cmd), 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      c->gicp_cmd = nullptr;
+    } else if ((e = hipMemset(c->gicp_cmd, 0, 4096)) != hipSuccess) {
+      return bail("hipMemset", e);
+    }
   }
   c->ev_ring.assign((size_t)kEventRing * 3, nullptr);
   for (auto& ev : c->ev_ring)
@@ -1183,6 +1306,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   }
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_gicp) (void)hipHostFree(c->h_gicp);
+  if (c->gicp_cmd) (void)hipFree(c->gicp_cmd);
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);
