@@ -402,20 +402,21 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
   const long long patience = 5000000;  // 50 ms of the 100 MHz wall clock
   unsigned int expect = first_seq;
   for (;;) {
-    if (threadIdx.x < 16) {
-      // lanes 0..11 fetch T once lane 12 has seen the number (the line is uncached: every load reads memory)
-      unsigned int got = kGicpServerExit;
+    if (threadIdx.x < 64) {
+      // lane k < 13 reads word k of the line, all in ONE coalesced read per poll (the line is uncached: every load reads
+      // memory).  The words of T were posted before the number, so a read that returns the number returns them too.
+      unsigned int got = kGicpServerExit, word = 0u;
       const long long t0 = (long long)wall_clock64();
       for (;;) {
-        const unsigned int v = __hip_atomic_load(&cmd[12], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        word = __hip_atomic_load(&cmd[threadIdx.x & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned int v = (unsigned int)__builtin_amdgcn_readlane((int)word, 12);
         if (v == expect || v == kGicpServerExit) {
           got = v;
           break;
         }
         if ((long long)wall_clock64() - t0 > patience) break;  // got stays kGicpServerExit
       }
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);  // the loads below are issued after the one above has returned
-      if (threadIdx.x < 12) s_T.m[threadIdx.x] = __uint_as_float(__hip_atomic_load(&cmd[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      if (threadIdx.x < 12) s_T.m[threadIdx.x] = __uint_as_float(word);
       if (threadIdx.x == 12) s_seq = got;
     }
     __syncthreads();
