@@ -97,6 +97,8 @@ constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-fo
 
 }  // namespace
 
+constexpr size_t kMaxServerWorkers = 8;
+
 static bool gicp_server_enabled() {  // ICPGPU_GICP_SERVER=0: every GICP evaluation is its own launch
 #if defined(__x86_64__)
   static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_SERVER"); return !e || std::atoi(e) != 0; }();
@@ -140,6 +142,7 @@ struct icpgpu_ctx {
   // resident evaluation server (icp_gicp.hip): its command line, fine-grained device memory the host writes through the BAR
   unsigned int* gicp_cmd = nullptr;
   bool gicp_server_on = false;
+  bool gicp_server_allowed = true;  // align_batch with more than kMaxServerWorkers threads: single launches (below)
   // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
   std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
   struct PendingSweep { int slot; bool grid; };
@@ -895,7 +898,7 @@ static void gicp_server_command(icpgpu_ctx* c, unsigned int seq, const Xform& T)
 static int gicp_server_start(icpgpu_ctx* c, int n_s, const unsigned long long* keys, float thr, const Xform& base,
                              const double* maha) {
   c->gicp_server_on = false;
-  if (!c->gicp_cmd) return ICPGPU_OK;
+  if (!c->gicp_cmd || !c->gicp_server_allowed) return ICPGPU_OK;
   unsigned int next = (unsigned int)(c->sums_seq + 1);
   if (next == kGicpServerExit || next == 0u) {  // keep the two reserved numbers out of the run's first command
     c->sums_seq += 2;
@@ -1044,6 +1047,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         if (w < 0) return false;
         have = w == 0;
         if (!have) c->gicp_server_on = false;  // it gave up (50 ms without a command): single launches from here on
+        if (!have && std::getenv("ICPGPU_DEBUG")) fprintf(stderr, "[icpgpu] gicp server gave up at evaluation %llu\n", seq);
       }
       if (!have) {
         if (launch_gicp_cost_direct(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
@@ -1429,6 +1433,10 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     }
     w->params = c->params;
     w->nn_variant = c->nn_variant;
+    // Every worker's BFGS runs keep up to 64 workgroups resident and a host thread spinning.  8 workers fit the chip (and
+    // the box's cores) with room for everybody's searches; 16 were measured 5x SLOWER than single launches (servers wait
+    // for slots other servers hold until their 50 ms patience runs out).
+    w->gicp_server_allowed = n_workers <= kMaxServerWorkers;
     for (;;) {
       const size_t k = next.fetch_add(1);
       if (k >= n_pairs || first_error.load() != ICPGPU_OK) return;
