@@ -89,3 +89,29 @@ def test_gicp_sequence_reuses_covariances(ctx):
         assert dR <= R_TOL and dt <= T_TOL
         ctx.promote_source_to_target()
     assert ctx.profile().gicp_cov_launches == 3      # scan 1's covariances are computed once and reused as target
+
+
+def test_gicp_evaluation_server_changes_nothing():
+    """The resident evaluation server (icp_gicp.hip) and single launches per evaluation must give the same bits: same
+    kernels' arithmetic, same order of the host's additions.  The switch is read once per process, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from icpslam_amd import Context, GICP, synth\n"
+        "src, tgt, _ = synth.make_pair(9000, 9000, seed=77)\n"
+        "with Context(0) as ctx:\n"
+        "    ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10)\n"
+        "    ctx.set_source(src); ctx.set_target(tgt)\n"
+        "    r = ctx.align(want_fitness=True)\n"
+        "    p = ctx.profile()\n"
+        "print(r['T'].tobytes().hex(), r['iterations'], r['n_corr'], float(r['fitness']).hex(), p.gicp_cost_launches)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, ICPGPU_GICP_SERVER=flag, PYTHONPATH=root)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[flag] = res.stdout.strip().splitlines()[-1]
+    assert out["0"] == out["1"], (out["0"][:80], out["1"][:80])
