@@ -213,7 +213,10 @@ def test_fuzz_grid_keys_equal_brute_force(ctx, seed):
         sm = tr["sums"]
         S = sm[7:16].reshape(3, 3) / sm[0] - np.outer(sm[4:7] / sm[0], sm[1:4] / sm[0])
         sv = np.linalg.svd(S, compute_uv=False)
-        if sv[1] > 1e-6 * sv[0]:          # a plane of correspondences at least: the rotation is determined
+        scale2 = max(1.0, float(np.abs(sm[1:7] / sm[0]).max()) ** 2)
+        # a plane of correspondences at least, and a cross-covariance that is more than the rounding of its own sums (117
+        # points all matched to one target point leave S ~ 1e-13): only then is the rotation determined
+        if sv[1] > 1e-6 * sv[0] and sv[0] > 1e-9 * scale2:
             assert np.allclose(res[NN_GRID]["T"], res[NN_BRUTE]["T"], atol=1e-5)
             assert np.allclose(res[NN_GRID]["T"], tr["final"], atol=1e-4)
 
@@ -248,7 +251,8 @@ def test_fuzz_quad_kernel_and_previous_neighbour_bound(ctx, seed):
         ctx.profile_reset()
         ig, dg = ctx.nn(T)
         prof = ctx.profile()
-        assert prof.grid_launches == 1 and prof.grid_bounded == (1 if k else 0)   # pruned from the second search on
+        # pruned from the second search on (a degenerate target -- everything in one cell -- has no grid: brute force)
+        assert prof.grid_bounded == (1 if k and prof.grid_launches == 1 else 0)
         ctx.set_params(ctx.default_params(), nn_mode=NN_BRUTE, max_correspondence_distance=gate)
         ib, db = ctx.nn(T)
         assert np.array_equal(ig, ib), f"pose {k}: {np.count_nonzero(ig != ib)} indices differ"
