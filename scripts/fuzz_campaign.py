@@ -6,13 +6,18 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 from icpslam_amd import Context
 import test_gpu_grid as G
+import test_gpu_map as M
+import test_gpu_voxel as V
 
 first, last = int(sys.argv[1]), int(sys.argv[2])
 fails = 0
 t0 = time.time()
 with Context(0) as ctx:
     for seed in range(first, last):
-        for fn in (G.test_fuzz_grid_keys_equal_brute_force, G.test_fuzz_quad_kernel_and_previous_neighbour_bound):
+        fns = (G.test_fuzz_grid_keys_equal_brute_force, G.test_fuzz_quad_kernel_and_previous_neighbour_bound)
+        if os.environ.get("FUZZ_ALL"):  # the map and the voxel filter too (CPU oracle inside: slower)
+            fns += (M.test_fuzz_map_against_oracle, V.test_fuzz_voxel_filter_against_oracle)
+        for fn in fns:
             try:
                 fn(ctx, seed)
             except Exception:
