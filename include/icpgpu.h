@@ -95,7 +95,9 @@ typedef struct {
   double fitness;             /* getFitnessScore(): icp_odometer.cpp:201; NaN unless requested */
   double t_total_ms;          /* host wall time of the align call */
   double t_device_ms;         /* kernel time of the call on the context's stream: HIP-event time of the TIMED sweeps
-                               * (icpgpu_profile_set_sampling), scaled to all sweeps of the call */
+                               * (icpgpu_profile_set_sampling), scaled to all sweeps of the call.  An estimate: timings are
+                               * read without blocking, and one that was not ready at the end of the call counts towards
+                               * the next one (icpgpu_profile_get always waits and is exact) */
 } icpgpu_result;
 
 /* Kernel-level accounting since the last icpgpu_profile_reset(); times are HIP-event times on the
