@@ -5,9 +5,12 @@
 // /root/reference/src/icpslam/icp_odometer.cpp:198 and src/icpslam/octree_mapper.cpp:114).  ICP only keeps
 // correspondences closer than setMaxCorrespondenceDistance (icp_odometer.cpp:191, 1.0 m), so the search may stop at
 // that radius: target points are counting-sorted into a dense uniform grid once per target cloud, and each source
-// point scans the 3x3x3 cells around it, then shells of growing radius, until its best distance is provably smaller
-// than anything outside the scanned cube.  Same arithmetic contract as the brute-force kernel (icp_device.h), same
-// (d2, lowest original index) tie-break, so the keys are bit-identical to brute force for every matched point.
+// point scans the 2x2x2 octant of cells it leans towards, then cubes of growing radius, until its best distance is
+// provably smaller than anything outside what was scanned -- never more than the ball that a known target point (the
+// octant's winner, a cube's, or the neighbour found in the previous sweep) puts around it.  Same arithmetic contract as
+// the brute-force kernel (icp_device.h), same (d2, lowest original index) tie-break, so the keys are bit-identical to
+// brute force for every matched point.  Two kernels share the machinery (icp_grid_device.h): nn_quad_kernel (four
+// points per wave pass; clouds from 32k points) and nn_wave_kernel (one wave per point; small clouds).
 //
 // HBM-side layout: `sorted` = float4 {x, y, z, original-index bits}, cells x-fastest so a run of cells along x is ONE
 // contiguous range (9 range lookups for a 3x3x3 block); `cell_start` = int32 per cell (+1).
