@@ -119,7 +119,7 @@ typedef struct {
   double grid_ms;
   uint64_t grid_bytes;        /* algorithmic bytes: 16*(N_s+N_t) + output per launch */
   uint64_t grid_builds;       /* target grid (re)builds: bbox + counting sort */
-  double grid_build_ms;
+  double grid_build_ms;       /* host time inside the builds (two host round trips each; the last kernels overlap the caller) */
   uint64_t grid_fallback_points; /* points finished by the brute-force kernel (no neighbour within the cutoff) */
   uint64_t voxel_launches;    /* voxel-grid filter runs */
   double voxel_ms;            /* key + sort + flag/scan + centroid kernels */

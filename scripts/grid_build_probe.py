@@ -20,4 +20,4 @@ with Context(0) as ctx:
         p = ctx.profile()
         k = len(tgts) - 1
         print(f"target {n:8d}: set_target (H2D) {t_set/k*1e3:.3f} ms, first align(1 it) {t_first/k*1e3:.3f} ms, repeat align {((t4-t3))*1e3:.3f} ms, "
-              f"grid builds {p.grid_builds} ({p.grid_build_ms/max(1,p.grid_builds):.3f} ms each by events)", flush=True)
+              f"grid builds {p.grid_builds} ({p.grid_build_ms/max(1,p.grid_builds):.3f} ms each, host time)", flush=True)
