@@ -1,5 +1,7 @@
 """GPU parity of the grid-accelerated correspondence search: it must return exactly what brute force returns
 (same keys bit for bit) and the same alignment, on ordinary scans and on inputs that stress the grid."""
+import os
+
 import numpy as np
 import pytest
 
@@ -7,6 +9,9 @@ import oracle
 from icpslam_amd import NN_AUTO, NN_BRUTE, NN_GRID, synth
 
 pytestmark = pytest.mark.gpu
+
+# the A/B switches of DESIGN.md section 6 turn the previous-neighbour bound off; the suite still has to pass with them
+BOUND_ON = os.environ.get("ICPGPU_QUAD", "1") != "0" and os.environ.get("ICPGPU_PREV", "1") != "0"
 
 
 def _nn(ctx, src, tgt, T, mode, r=1.0):
@@ -252,7 +257,7 @@ def test_fuzz_quad_kernel_and_previous_neighbour_bound(ctx, seed):
         ig, dg = ctx.nn(T)
         prof = ctx.profile()
         # pruned from the second search on (a degenerate target -- everything in one cell -- has no grid: brute force)
-        assert prof.grid_bounded == (1 if k and prof.grid_launches == 1 else 0)
+        assert prof.grid_bounded == (1 if k and prof.grid_launches == 1 and BOUND_ON else 0)
         ctx.set_params(ctx.default_params(), nn_mode=NN_BRUTE, max_correspondence_distance=gate)
         ib, db = ctx.nn(T)
         assert np.array_equal(ig, ib), f"pose {k}: {np.count_nonzero(ig != ib)} indices differ"
@@ -272,7 +277,7 @@ def test_quad_kernel_alignment_equals_brute_force_alignment(ctx, n, seed):
         ctx.profile_reset()
         res[mode] = ctx.align(want_fitness=True)
         # 12 gated sweeps + the fitness sweep; all but the first of the alignment are bounded
-        assert ctx.profile().grid_bounded == (12 if mode == NN_GRID else 0)
+        assert ctx.profile().grid_bounded == (12 if mode == NN_GRID and BOUND_ON else 0)
     g, b = res[NN_GRID], res[NN_BRUTE]
     assert g["iterations"] == b["iterations"] == 12 and g["n_corr"] == b["n_corr"]
     assert np.abs(g["T"] - b["T"]).max() <= 1e-6
