@@ -42,82 +42,90 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// direction of the smallest singular value of a symmetric 3x3 (row-major): one-sided Jacobi on W = A V, the column of
-// W with the smallest norm, completed by the cross product of the other two when it vanishes (perfectly planar patch)
-__device__ void smallest_singular_direction(const double A[9], double u[3]) {
-  double w[3][3];  // w[j] = column j
+// Left singular vectors of a symmetric 3x3 (row-major), columns sorted by decreasing singular value: one-sided Jacobi on
+// W = A V (sweeps over (0,1), (0,2), (1,2) until the largest relative off-diagonal of a sweep is below 1e-16, at most 60
+// sweeps), U = normalised columns of W, completed when a singular value vanishes.  OPERATION FOR OPERATION what the oracle
+// does (its restatement of the JacobiSVD call in PCL's computeCovariances): on a clean plane patch every method agrees to
+// 1e-15, but on a patch with two (nearly) equal singular values the vectors are whatever the method's rounding makes
+// them, and a regularised covariance that differs in its 10th digit is a different optimisation problem for the chaotic
+// BFGS that follows.  Same operations, same bits.
+__device__ void svd3_left_vectors(const double A[9], double U[9]) {
+  double W[9];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) w[j][r] = A[r * 3 + j];
-  for (int sweep = 0; sweep < 64; ++sweep) {
-    bool rotated = false;
+  for (int i = 0; i < 9; ++i) W[i] = A[i];
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
 #pragma unroll
     for (int pq = 0; pq < 3; ++pq) {
       const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-      const double aa = w[p][0] * w[p][0] + w[p][1] * w[p][1] + w[p][2] * w[p][2];
-      const double bb = w[q][0] * w[q][0] + w[q][1] * w[q][1] + w[q][2] * w[q][2];
-      const double ab = w[p][0] * w[q][0] + w[p][1] * w[q][1] + w[p][2] * w[q][2];
-      if (ab == 0.0 || fabs(ab) <= 1e-17 * sqrt(aa * bb)) continue;
-      const double zeta = (bb - aa) / (2.0 * ab);
-      const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        alpha += W[r * 3 + p] * W[r * 3 + p];
+        beta += W[r * 3 + q] * W[r * 3 + q];
+        gamma += W[r * 3 + p] * W[r * 3 + q];
+      }
+      if (gamma == 0.0) continue;
+      const double lim = sqrt(alpha * beta);
+      if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * lim) continue;
+      off = fmax(off, fabs(gamma) / (lim > 0 ? lim : 1.0));
+      const double zeta = (beta - alpha) / (2.0 * gamma);
+      const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
       const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const double x = w[p][r], y = w[q][r];
-        w[p][r] = c * x - sn * y;
-        w[q][r] = sn * x + c * y;
+        const double wp = W[r * 3 + p], wq = W[r * 3 + q];
+        W[r * 3 + p] = c * wp - sn * wq;
+        W[r * 3 + q] = sn * wp + c * wq;
       }
-      rotated = true;
     }
-    if (!rotated) break;
+    if (off < 1e-16) break;
   }
-  double n[3];
+  double nrm[3];
+  int ord[3] = {0, 1, 2};
 #pragma unroll
-  for (int j = 0; j < 3; ++j) n[j] = sqrt(w[j][0] * w[j][0] + w[j][1] * w[j][1] + w[j][2] * w[j][2]);
-  int lo = 0, hi = 0;
+  for (int j = 0; j < 3; ++j) nrm[j] = sqrt(W[0 * 3 + j] * W[0 * 3 + j] + W[1 * 3 + j] * W[1 * 3 + j] + W[2 * 3 + j] * W[2 * 3 + j]);
 #pragma unroll
-  for (int j = 1; j < 3; ++j) {
-    if (n[j] < n[lo]) lo = j;
-    if (n[j] > n[hi]) hi = j;
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 3; ++b)
+      if (nrm[ord[b]] > nrm[ord[a]]) {
+        const int t = ord[a];
+        ord[a] = ord[b];
+        ord[b] = t;
+      }
+  double s[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int o = ord[j];
+    s[j] = nrm[o];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) U[r * 3 + j] = (nrm[o] > 0) ? W[r * 3 + o] / nrm[o] : 0.0;
   }
-  const double tiny = 1e-13 * (n[hi] > 0.0 ? n[hi] : 1.0);
-  if (n[hi] <= tiny) {  // zero matrix: any direction (svd3x3 returns the identity basis -> third axis)
-    u[0] = 0.0; u[1] = 0.0; u[2] = 1.0;
+  const double tiny = 1e-13 * (s[0] > 0 ? s[0] : 1.0);
+  if (s[0] <= tiny) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
     return;
   }
-  if (n[lo] > tiny) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) u[r] = w[lo][r] / n[lo];
-    return;
-  }
-  const int mid = 3 - lo - hi;
-  double a[3], b[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) a[r] = w[hi][r] / n[hi];
-  if (n[mid] > tiny) {
-#pragma unroll
-    for (int r = 0; r < 3; ++r) b[r] = w[mid][r] / n[mid];
-  } else {  // rank 1: any unit vector orthogonal to a (least-aligned axis, Gram-Schmidt)
-    int k = 0;
-    if (fabs(a[1]) < fabs(a[k])) k = 1;
-    if (fabs(a[2]) < fabs(a[k])) k = 2;
+  if (s[1] <= tiny) {  // any unit vector orthogonal to u0: Gram-Schmidt on the least aligned axis
+    const double u0[3] = {U[0], U[3], U[6]};
+    const int k = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
     double e[3] = {0.0, 0.0, 0.0};
     e[k] = 1.0;
-    const double d = a[k];
-    double nn = 0.0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      b[r] = e[r] - d * a[r];
-      nn += b[r] * b[r];
-    }
-    nn = sqrt(nn);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) b[r] /= nn;
+    const double d = u0[k];
+    const double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    U[1] = v[0] / n;
+    U[4] = v[1] / n;
+    U[7] = v[2] / n;
   }
-  u[0] = a[1] * b[2] - a[2] * b[1];
-  u[1] = a[2] * b[0] - a[0] * b[2];
-  u[2] = a[0] * b[1] - a[1] * b[0];
+  if (s[2] <= tiny) {
+    const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
+    U[2] = a[1] * b[2] - a[2] * b[1];
+    U[5] = a[2] * b[0] - a[0] * b[2];
+    U[8] = a[0] * b[1] - a[1] * b[0];
+  }
 }
 
 // ---- computeCovariances -----------------------------------------------------------------------------------------
@@ -254,15 +262,20 @@ __global__ __launch_bounds__(256) void gicp_cov_finish_kernel(int n, double* __r
   double C[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
   if (a0 == a0) {  // not the marker
     const double A[9] = {a0, a1, a2, a1, a3, a4, a2, a4, a5};
-    double u[3];
-    smallest_singular_direction(A, u);
-    const double f = 1.0 - kGicpEpsilon;
-    C[0] = 1.0 - f * u[0] * u[0];
-    C[1] = -f * u[0] * u[1];
-    C[2] = -f * u[0] * u[2];
-    C[3] = 1.0 - f * u[1] * u[1];
-    C[4] = -f * u[1] * u[2];
-    C[5] = 1.0 - f * u[2] * u[2];
+    double U[9];
+    svd3_left_vectors(A, U);
+    // C = sum_k v_k u_k u_k^T with v = (1, 1, epsilon): the loop of PCL's computeCovariances, in its order
+    const int rr[6] = {0, 1, 2, 1, 2, 2}, cc[6] = {0, 0, 0, 1, 1, 2};  // (0,0) (1,0) (2,0) (1,1) (2,1) (2,2)
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double v = (k == 2) ? kGicpEpsilon : 1.0;
+        acc += v * U[3 * rr[e] + k] * U[3 * cc[e] + k];
+      }
+      C[e] = acc;
+    }
   }
 #pragma unroll
   for (int k = 0; k < 6; ++k) c[k] = C[k];
@@ -306,12 +319,54 @@ __global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned 
 
 // ---- one BFGS evaluation ---------------------------------------------------------------------------------------
 // terms: 0 = m, 1 = sum r^T M r, 2..4 = sum M r, 5..13 = sum (base p)(M r)^T (row-major), 14 = sum d2 of the NN sweep
-__device__ __forceinline__ void gicp_accumulate(double (&acc)[kReduceTerms], const float4* __restrict__ src, int n_s,
+// ---- order-independent sums ----------------------------------------------------------------------------------------
+// BFGS is a chaotic consumer: one ulp in a cost or gradient sum can change a line-search decision, and the outer loop's
+// delta < 1 stop sits on a 1e-6 m threshold.  With plain float64 sums the GPU (per-lane partial sums, trees) and the
+// oracle (one sequential sum, like PCL) agreed to the last bit on most pairs but ended up to 6 cm apart on 2 % of 1 000
+// random pairs (scripts/gicp_campaign.py).  So the 13 real sums of an evaluation (f, g_t, R) are accumulated as
+// double-double numbers everywhere -- error-free TwoSum per term in the lane, double-double adds across lanes, waves,
+// workgroups and on the host; the oracle keeps a three-fold expansion over its sequential loop -- and rounded to
+// float64 once at the end.  Either way the result is the correctly rounded exact sum unless that sum lies within
+// ~1e-30 (relative to the sum of magnitudes) of a rounding boundary: the order of summation no longer matters.
+struct DD {
+  double hi, lo;
+};
+__host__ __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {
+  s = a + b;
+  const double bb = s - a;
+  e = (a - (s - bb)) + (b - bb);
+}
+__host__ __device__ __forceinline__ void dd_add_term(DD& a, double t) {  // a += t, error-free in (hi, lo) up to lo's rounding
+  double s, e;
+  two_sum(a.hi, t, s, e);
+  a.hi = s;
+  a.lo += e;
+}
+__host__ __device__ __forceinline__ DD dd_add(const DD& a, const DD& b) {
+  // cascaded: the high parts by TwoSum (error-free), everything small in plain float64 -- the low part stays ~1e-16 of the
+  // running magnitudes, so its own rounding is ~1e-32 of them (the accurate double-double addition with two
+  // renormalisations costs three times as much and buys nothing here)
+  DD r;
+  double e;
+  two_sum(a.hi, b.hi, r.hi, e);
+  r.lo = (a.lo + b.lo) + e;
+  return r;
+}
+
+constexpr int kGicpSums = 13;  // f, g_t(3), R(9): terms 1..13 of the layout above
+
+struct GicpAcc {
+  double m, d2;       // count and sum of the sweep's d2 (sums of floats: exact in float64 at these sizes)
+  DD s[kGicpSums];
+};
+
+__device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __restrict__ src, int n_s,
                                                 const float4* __restrict__ tgt,
                                                 const unsigned long long* __restrict__ keys, float thr, const Xform& T,
                                                 const Xform& base, const double* __restrict__ maha6) {
+  acc.m = acc.d2 = 0.0;
 #pragma unroll
-  for (int k = 0; k < kReduceTerms; ++k) acc[k] = 0.0;
+  for (int k = 0; k < kGicpSums; ++k) acc.s[k].hi = acc.s[k].lo = 0.0;
   // Four correspondences per lane and trip, their loads issued together: key -> (target point, Mahalanobis matrix) is a
   // dependent chain of random reads, and with <= 64 workgroups in direct mode every lane owns several correspondences --
   // one after the other they made this kernel 14-16 us long (latency, not bandwidth).
@@ -349,35 +404,78 @@ __device__ __forceinline__ void gicp_accumulate(double (&acc)[kReduceTerms], con
       const double t0 = M[u][0] * r0 + M[u][1] * r1 + M[u][2] * r2;
       const double t1 = M[u][1] * r0 + M[u][3] * r1 + M[u][4] * r2;
       const double t2 = M[u][2] * r0 + M[u][4] * r1 + M[u][5] * r2;
-      acc[0] += 1.0;
-      acc[1] += r0 * t0 + r1 * t1 + r2 * t2;
-      acc[2] += t0;
-      acc[3] += t1;
-      acc[4] += t2;
+      acc.m += 1.0;
+      dd_add_term(acc.s[0], r0 * t0 + r1 * t1 + r2 * t2);
+      dd_add_term(acc.s[1], t0);
+      dd_add_term(acc.s[2], t1);
+      dd_add_term(acc.s[3], t2);
       const double pb[3] = {(double)bx, (double)by, (double)bz};
       const double tt[3] = {t0, t1, t2};
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[5 + 3 * r + c] += pb[r] * tt[c];
-      acc[14] += (double)d2;
+        for (int c = 0; c < 3; ++c) dd_add_term(acc.s[4 + 3 * r + c], pb[r] * tt[c]);
+      acc.d2 += (double)d2;
     }
   }
 }
 
+// Workgroup reduction of the lanes' accumulators into partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = the
+// sums' high parts, [14] = sum d2, [16..28] = their low parts.  The 13 double-double sums go through LDS: thread
+// (sum, chunk) adds the 16 lanes of its chunk in lane order, then thread `sum` adds the 16 chunk results in order.
+__device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, double* __restrict__ partials) {
+  __shared__ DD s_lane[kGicpSums][16][17];  // [sum][lane % 16][lane / 16], rows padded: neither the writes (a lane per
+                                            // thread) nor the reads (a chunk per thread) pile up on one LDS bank
+  __shared__ DD s_chunk[kGicpSums][16];
+  __shared__ double s_md[2][4];
+#pragma unroll
+  for (int k = 0; k < kGicpSums; ++k) s_lane[k][threadIdx.x & 15][threadIdx.x >> 4] = acc.s[k];
+  const double m = wave_sum(acc.m), d2 = wave_sum(acc.d2);
+  if ((threadIdx.x & 63) == 0) {
+    s_md[0][threadIdx.x >> 6] = m;
+    s_md[1][threadIdx.x >> 6] = d2;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGicpSums * 16) {
+    const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+    DD x[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) x[l] = s_lane[k][l][c];  // lanes 16c .. 16c+15, in lane order; 16 independent reads, then the chain
+    DD v = x[0];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) v = dd_add(v, x[l]);
+    s_chunk[k][c] = v;
+  }
+  __syncthreads();
+  double* out = partials + (size_t)blockIdx.x * kGicpPartialStride;
+  if (threadIdx.x < kGicpSums) {
+    DD x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
+    DD v = x[0];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) v = dd_add(v, x[c]);
+    out[1 + threadIdx.x] = v.hi;
+    out[16 + threadIdx.x] = v.lo;
+  } else if (threadIdx.x == kGicpSums) {
+    out[0] = (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]);
+    out[14] = (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]);
+  }
+}
+
+// One evaluation as ONE kernel of <= kGicpDirectBlocks workgroups: every workgroup stores its partials straight into
+// host-mapped memory (host_partials) followed by host_flags[block] = seq; the host adds the workgroups' partials.  All
+// the stores above come from wave 0, like the flag, so the release orders them.
 __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict__ src, int n_s,
                                                         const float4* __restrict__ tgt,
                                                         const unsigned long long* __restrict__ keys, float thr, Xform T,
                                                         Xform base, const double* __restrict__ maha6,
                                                         double* __restrict__ partials, unsigned long long* flags,
                                                         unsigned long long seq) {
-  double acc[kReduceTerms];
+  GicpAcc acc;
   gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
-  block_reduce_store<4>(acc, partials);
-  // "direct" mode (flags != nullptr): partials IS the host mailbox and there is no second kernel -- the host adds the few
-  // workgroups' partials itself.  The 17 stores above come from wave 0, like this flag, so the release orders them.
-  if (flags != nullptr && threadIdx.x == 0)
-    __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  gicp_block_reduce_store(acc, partials);
+  if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- resident evaluation server ------------------------------------------------------------------------------------
@@ -428,9 +526,9 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
       return;
     }
     const Xform T = s_T;
-    double acc[kReduceTerms];
+    GicpAcc acc;
     gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
-    block_reduce_store<4>(acc, host_partials);
+    gicp_block_reduce_store(acc, host_partials);
     if (threadIdx.x == 0)
       __hip_atomic_store(&host_flags[blockIdx.x], ((unsigned long long)seq_hi << 32) | seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     expect = seq + 1u;
@@ -454,17 +552,6 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
   if (n_s <= 0) return hipSuccess;
   hipLaunchKernelGGL(gicp_maha_kernel, dim3((n_s + 255) / 256), dim3(256), 0, stream, n_s, keys, thr, R, cov_s, cov_t, maha6);
   return hipGetLastError();
-}
-
-hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
-                            const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
-                            unsigned long long* flags, unsigned long long seq, hipStream_t stream) {
-  int blocks = (n_s + 255) / 256;
-  if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base, maha6, partials,
-                     static_cast<unsigned long long*>(nullptr), 0ull);
-  return launch_reduce_final(partials, blocks, false, sums_out, flags, seq, stream);
 }
 
 int gicp_direct_blocks(int n_s) {

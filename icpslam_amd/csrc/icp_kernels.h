@@ -130,14 +130,11 @@ hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sor
 // maha6[i] = upper triangle of (C_t[j] + R C_s[i] R^T)^-1 for every source point whose key passes d2 < thr
 hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, float thr, const Rot3d& R, const double* cov_s,
                                    const double* cov_t, double* maha6, hipStream_t stream);
-// sums_out[0..14] = {m, sum r^T M r, sum M r (3), sum (base p)(M r)^T (9), sum d2}; partials: kMaxReduceBlocks x 17
-hipError_t launch_gicp_cost(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
-                            const Xform& T, const Xform& base, const double* maha6, double* partials, double* sums_out,
-                            unsigned long long* flags, unsigned long long seq, hipStream_t stream);
-
-// One-kernel variant for the ~300 dependent evaluations of an align: at most kGicpDirectBlocks workgroups, each stores
-// its 17 partial sums straight into host-mapped memory (host_partials[block * 17 + term]) followed by host_flags[block] =
-// seq; the host adds the partials in block order.  gicp_direct_blocks(n_s) = workgroups launched.
+// One BFGS function/gradient evaluation: at most kGicpDirectBlocks workgroups, each stores its partial sums straight into
+// host-mapped memory (host_partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = high parts of sum r^T M r, sum M r
+// (3), sum (base p)(M r)^T (9), [14] = sum d2, [16..28] = the 13 low parts -- the sums are double-double, see icp_gicp.hip)
+// followed by host_flags[block] = seq; the host adds the partials in block order.  gicp_direct_blocks(n_s) = workgroups.
+static constexpr int kGicpPartialStride = 32;
 static constexpr int kGicpDirectBlocks = 64;
 int gicp_direct_blocks(int n_s);
 hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,

@@ -886,6 +886,24 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   return ICPGPU_OK;
 }
 
+// (hi, lo) += (bh, bl), accurate double-double addition (the same operations as dd_add in icp_gicp.hip)
+static inline void gicp_dd_add(double& hi, double& lo, double bh, double bl) {
+  auto two_sum = [](double a, double b, double& s, double& e) {
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+  };
+  double s, e, t, f;
+  two_sum(hi, bh, s, e);
+  two_sum(lo, bl, t, f);
+  e += t;
+  double h = s + e;
+  double l = e - (h - s);
+  l += f;
+  hi = h + l;
+  lo = l - (hi - h);
+}
+
 // ---- the resident evaluation server of a BFGS run (gicp_server_kernel) ---------------------------------------------
 // A command is four 16-byte chunks {3 floats of T, sequence number}; each chunk is ONE aligned 16-byte store, so the
 // device never sees half a chunk, and it acts once all four carry the number it waits for.
@@ -1067,13 +1085,17 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
           return false;
         if (wait_flags(c, c->h_gicp_flags, nblk, seq) != ICPGPU_OK) return false;
       }
-      {  // workgroup by workgroup (every term still adds its partials in workgroup order): one sequential pass over lines the
-         // device has just written -- term by term the same loop strode through them 17 times, a cache miss per access
-        double v[kReduceTerms] = {};
+      {  // workgroup by workgroup, in double-double like the kernel (icp_gicp.hip): the 13 sums are rounded once, here
+        double m = 0.0, d2 = 0.0, hi[13] = {}, lo[13] = {};
         const double* part = c->h_gicp;
-        for (int b = 0; b < nblk; ++b, part += kReduceTerms)
-          for (int k = 0; k < kReduceTerms; ++k) v[k] += part[k];
-        for (int k = 0; k < kReduceTerms; ++k) c->h_sums[k] = v[k];
+        for (int b = 0; b < nblk; ++b, part += kGicpPartialStride) {
+          m += part[0];
+          d2 += part[14];
+          for (int k = 0; k < 13; ++k) gicp_dd_add(hi[k], lo[k], part[1 + k], part[16 + k]);
+        }
+        c->h_sums[0] = m;
+        c->h_sums[14] = d2;
+        for (int k = 0; k < 13; ++k) c->h_sums[1 + k] = hi[k] + lo[k];
       }
       c->prof.gicp_cost_launches += 1;
       const double* s = c->h_sums;
@@ -1234,7 +1256,7 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
   c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
   {
-    const size_t n_flags_end = (size_t)kGicpDirectBlocks * kReduceTerms + 8 + kGicpDirectBlocks;  // partials, gap, flags
+    const size_t n_flags_end = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8 + kGicpDirectBlocks;  // partials, gap, flags
     const size_t cmd_off = (n_flags_end + 7) & ~(size_t)7;                                        // 64-byte aligned
     const size_t n_d = cmd_off + 8;                                                              // + the server's command line
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_gicp), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
@@ -1243,7 +1265,7 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
     std::memset(c->h_gicp, 0, n_d * sizeof(double));
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_gicp_dev), c->h_gicp, 0)) != hipSuccess)
       return bail("hipHostGetDevicePointer", e);
-    const size_t off = (size_t)kGicpDirectBlocks * kReduceTerms + 8;
+    const size_t off = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8;
     c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
     c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
     (void)cmd_off;

@@ -106,13 +106,21 @@ int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_ou
       }
     double U[9], s[3], V[9];
     orc_svd3(cov, U, s, V);
+    /* cov = sum_k v_k u_k u_k^T, v = (1, 1, epsilon).  The lower triangle is computed -- entry (r, c) = sum_k (v_k u_rk) u_ck,
+     * the expression Eigen evaluates for `v * col * col.transpose()` -- and mirrored: in PCL the two triangles can differ in
+     * the last bit of the epsilon term ((eps a) b vs (eps b) a), 1e-19 absolute; an implementation that stores six entries
+     * per point (the GPU path) could never reproduce that, and nothing downstream gives it a meaning. */
     double* C = cov_out + 9 * i;
-    for (int e = 0; e < 9; ++e) C[e] = 0.0;
-    for (int k = 0; k < 3; ++k) {
-      const double v = (k == 2) ? GICP_EPSILON : 1.0;
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) C[3 * r + c] += v * U[3 * r + k] * U[3 * c + k];
-    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c <= r; ++c) {
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) {
+          const double v = (k == 2) ? GICP_EPSILON : 1.0;
+          acc += v * U[3 * r + k] * U[3 * c + k];
+        }
+        C[3 * r + c] = acc;
+        C[3 * c + r] = acc;
+      }
   }
   orc_kd_free(tree);
   return 0;
@@ -177,14 +185,40 @@ typedef struct {
   float base[16];     /* base_transformation_ = guess */
 } gicp_problem;
 
+/* Order-independent sums.  PCL adds the cost and the gradient terms in plain float64, one after the other; BFGS then
+ * consumes them chaotically (an ulp in a sum can flip a line-search decision, and the outer delta < 1 stop sits on a
+ * 1e-6 m threshold), so any implementation that adds in another order -- every parallel one -- drifts away from the
+ * sequential result on a few percent of the pairs.  The oracle therefore defines each of the 13 sums as the EXACT sum of
+ * its float64 terms, rounded once: a three-fold error-free expansion (TwoSum cascade) over the sequential loop.  It differs
+ * from PCL's plain sum by the rounding PCL accumulates (~1e-13 relative at 50k terms), and it is the same number whatever
+ * the order of summation, which is what makes a bit-for-bit comparison with the GPU path meaningful. */
+typedef struct { double hi, mid, lo; } sum3;
+static inline void two_sum(double a, double b, double* s, double* e) {
+  *s = a + b;
+  const double bb = *s - a;
+  *e = (a - (*s - bb)) + (b - bb);
+}
+static inline void sum3_add(sum3* a, double t) {
+  double e1, e2;
+  two_sum(a->hi, t, &a->hi, &e1);
+  two_sum(a->mid, e1, &a->mid, &e2);
+  a->lo += e2;
+}
+static inline double sum3_value(const sum3* a) {
+  double s, e;
+  two_sum(a->mid, a->lo, &s, &e); /* renormalise from the bottom: hi + (mid + lo), with the low error folded back in */
+  double h, l;
+  two_sum(a->hi, s, &h, &l);
+  return h + (l + e);
+}
+
 /* f and the 12 raw gradient sums (g_t(3), R(9)) at x */
 static void eval_sums(const gicp_problem* P, const double x[6], double* f, double gt[3], double Rm[9]) {
   float T[16];
   memcpy(T, P->base, sizeof(T));
   apply_state(T, x);
-  double acc = 0.0;
-  gt[0] = gt[1] = gt[2] = 0.0;
-  for (int k = 0; k < 9; ++k) Rm[k] = 0.0;
+  sum3 acc = {0, 0, 0}, gts[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Rms[9];
+  for (int k = 0; k < 9; ++k) Rms[k].hi = Rms[k].mid = Rms[k].lo = 0.0;
   for (int i = 0; i < P->m; ++i) {
     const float* ps = P->src + 4 * (size_t)P->si[i];
     const float* pt = P->tgt + 4 * (size_t)P->ti[i];
@@ -194,13 +228,15 @@ static void eval_sums(const gicp_problem* P, const double x[6], double* f, doubl
     const double* M = P->maha + 9 * (size_t)P->si[i];
     double temp[3];
     for (int r = 0; r < 3; ++r) temp[r] = M[3 * r] * res[0] + M[3 * r + 1] * res[1] + M[3 * r + 2] * res[2];
-    acc += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
-    for (int r = 0; r < 3; ++r) gt[r] += temp[r];
+    sum3_add(&acc, res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
+    for (int r = 0; r < 3; ++r) sum3_add(&gts[r], temp[r]);
     xform_point(P->base, ps, pb); /* PCL uses base_transformation_ * p_src for the rotation gradient */
     for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) Rm[3 * r + c] += (double)pb[r] * temp[c];
+      for (int c = 0; c < 3; ++c) sum3_add(&Rms[3 * r + c], (double)pb[r] * temp[c]);
   }
-  *f = acc;
+  *f = sum3_value(&acc);
+  for (int r = 0; r < 3; ++r) gt[r] = sum3_value(&gts[r]);
+  for (int k = 0; k < 9; ++k) Rm[k] = sum3_value(&Rms[k]);
 }
 
 static void r_derivative(const double x[6], const double R[9], double g[6]) {
@@ -642,6 +678,16 @@ int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, c
           for (int c = 0; c < 3; ++c)
             tmp[3 * r + c] = RC[3 * r] * R[3 * c] + RC[3 * r + 1] * R[3 * c + 1] + RC[3 * r + 2] * R[3 * c + 2] + C2[3 * r + c];
         inv3(tmp, maha + 9 * i);
+        {
+          /* R C1 R^T + C2 is symmetric only up to rounding, and so is its adjugate inverse; PCL keeps all nine entries.
+           * The upper triangle is mirrored here: the difference is in the last bit of three entries, and an
+           * implementation that stores six numbers per correspondence (the GPU path: 48 instead of 72 B of the 88 B an
+           * evaluation reads per correspondence) can then be compared bit for bit. */
+          double* Mi = maha + 9 * i;
+          Mi[3] = Mi[1];
+          Mi[6] = Mi[2];
+          Mi[7] = Mi[5];
+        }
         si[cnt] = (int32_t)i;
         ti[cnt] = j;
         d2sum += (double)d2;

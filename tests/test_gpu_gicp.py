@@ -25,10 +25,12 @@ def test_covariances_match_oracle(ctx, n, seed):
     # symmetric, eigenvalues (1, 1, 1e-3)
     w = np.linalg.eigvalsh(got)
     np.testing.assert_allclose(w, np.tile([1e-3, 1.0, 1.0], (n, 1)), atol=1e-9)
-    # same plane normals as the oracle except where the 20-NN patch is (near-)degenerate: there the smallest direction is
-    # ill-conditioned and 1e-16 differences in the summation order rotate it -- allow a tiny fraction of such points
-    bad = np.abs(got - ref).reshape(n, -1).max(axis=1) > 1e-6
-    assert bad.mean() < 0.01
+    # The same bits as the oracle: the 20 neighbours are the exact ones, their moment sums are sums of float products in
+    # float64 (exact at scan ranges, so the order does not matter), and the decomposition + regularisation are the oracle's
+    # operations one for one (icp_gicp.hip).  A patch whose moment sums do round may differ in the last bits: allow 0.1 %.
+    bad = np.abs(got - ref).reshape(n, -1).max(axis=1) > 0.0
+    assert bad.mean() <= 0.001, bad.mean()
+    assert np.abs(got - ref).max() <= 1e-6
 
 
 @pytest.mark.parametrize("mode", [NN_GRID, NN_BRUTE])
@@ -40,12 +42,14 @@ def test_gicp_align_matches_oracle(ctx, mode, n, seed, iters):
     ctx.set_target(tgt)
     got = ctx.align(want_fitness=True, want_cloud=True)
     ref = oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_iterations=iters), want_fitness=True)
-    assert got["converged"] == ref["converged"]
-    assert abs(got["iterations"] - ref["iterations"]) <= 1          # the delta < 1 test sits on a 1e-6 m threshold
-    assert abs(got["n_corr"] - ref["n_corr"]) <= max(2, int(1e-4 * ref["n_corr"]))
+    # Bit for bit: the 13 sums of every BFGS evaluation are order-independent (double-double on the GPU, a three-fold
+    # expansion in the oracle) and the covariance regularisation is the same sequence of operations on both sides, so the
+    # chaotic parts (line search, the delta < 1 stop on a 1e-6 m threshold) see the same numbers.  With plain float64 sums
+    # 2 % of 1 000 random pairs ended more than 1 mm apart (scripts/gicp_campaign.py).
+    assert got["converged"] == ref["converged"] and got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"]
     dR, dt = _cmp(got, ref)
-    assert dR <= R_TOL and dt <= T_TOL
-    assert abs(got["fitness"] - ref["fitness"]) <= 1e-3 * max(1.0, ref["fitness"])
+    assert dR == 0.0 and dt == 0.0, (dR, dt)
+    assert abs(got["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
     assert got["cloud"].shape == src.shape
 
 
