@@ -15,8 +15,11 @@
  *                          (rotation entries scaled by 1/rotation_epsilon = 1/2e-3, the rest by 1/transformation_epsilon)
  * PCL is not in /root/reference; the constants above are PCL's constructor defaults the reference leaves untouched.
  *
- * Arithmetic choices shared with the HIP implementation (DESIGN.md section 3b): point transforms use the fmaf chain of
- * icp_oracle.c; NN keys are (d2, lowest index); the 20-NN set is the 20 smallest (d2, index) keys.
+ * Arithmetic choices shared with the HIP implementation (DESIGN.md section 3): point transforms use the fmaf chain of
+ * icp_oracle.c; NN keys are (d2, lowest index); the 20-NN set is the 20 smallest (d2, index) keys; the cost and gradient
+ * sums of a BFGS evaluation are the EXACT sums of their float64 terms, rounded once (eval_sums); the regularised covariance
+ * and the Mahalanobis inverse are stored symmetric (one triangle mirrored).  The last two differ from PCL's own
+ * evaluation by no more than its rounding error and are what lets a parallel implementation be compared bit for bit.
  */
 #include <float.h>
 #include <math.h>
