@@ -886,22 +886,14 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   return ICPGPU_OK;
 }
 
-// (hi, lo) += (bh, bl), accurate double-double addition (the same operations as dd_add in icp_gicp.hip)
+// (hi, lo) += (bh, bl): the cascaded double-double merge of icp_gicp.hip (TwoSum on the high parts, the small parts in
+// plain float64)
 static inline void gicp_dd_add(double& hi, double& lo, double bh, double bl) {
-  auto two_sum = [](double a, double b, double& s, double& e) {
-    s = a + b;
-    const double bb = s - a;
-    e = (a - (s - bb)) + (b - bb);
-  };
-  double s, e, t, f;
-  two_sum(hi, bh, s, e);
-  two_sum(lo, bl, t, f);
-  e += t;
-  double h = s + e;
-  double l = e - (h - s);
-  l += f;
-  hi = h + l;
-  lo = l - (hi - h);
+  const double s = hi + bh;
+  const double bb = s - hi;
+  const double e = (hi - (s - bb)) + (bh - bb);
+  hi = s;
+  lo = (lo + bl) + e;
 }
 
 // ---- the resident evaluation server of a BFGS run (gicp_server_kernel) ---------------------------------------------
