@@ -308,3 +308,22 @@ def test_fitness_completion_paths(ctx, n, gate, many):
     assert g["n_corr"] == b["n_corr"] and abs(g["fitness"] - b["fitness"]) <= 1e-9 * max(1.0, b["fitness"])
     ref = oracle.icp_align(src, tgt, oracle.default_params(max_correspondence_distance=gate, max_iterations=3), want_fitness=True)
     assert abs(g["fitness"] - ref["fitness"]) <= 1e-6 * max(1.0, ref["fitness"])
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_alignments_bit_identical_to_oracle(ctx, seed):
+    """A slice of scripts/align_campaign.py (300 pairs there): whole point-to-point alignments through nn_quad_kernel at random
+    sizes, gates and iteration limits return the oracle's transform bits, iteration and correspondence counts."""
+    rng = np.random.default_rng(50_000 + seed)
+    n_s, n_t = int(rng.integers(33_000, 60_000)), int(rng.integers(20_000, 80_000))
+    gate = float(rng.choice([0.3, 1.0, 2.0]))
+    iters = int(rng.choice([5, 10, 30]))
+    src, tgt, _ = synth.make_pair(n_s, n_t, seed=seed)
+    ctx.set_params(ctx.default_params(), max_iterations=iters, max_correspondence_distance=gate)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    got = ctx.align(want_fitness=True)
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=iters, max_correspondence_distance=gate), want_fitness=True)
+    assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"] and got["converged"] == ref["converged"]
+    assert np.array_equal(got["T"].view(np.uint32), np.asarray(ref["T"], np.float32).view(np.uint32))
+    assert abs(got["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
