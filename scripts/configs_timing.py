@@ -40,10 +40,15 @@ with Context(0) as ctx:
     pairs = [synth.make_pair(50000, 50000, seed=1000 + k)[:2] for k in range(64)]
     ctx.set_params(ctx.default_params(), max_iterations=10)
     ctx.align_batch([p[0] for p in pairs[:8]], [p[1] for p in pairs[:8]])
-    g, res = t_ms(lambda: ctx.align_batch([p[0] for p in pairs], [p[1] for p in pairs], want_fitness=True), 3)
+    reps = []
+    for _ in range(7):   # a noisy figure (8 host threads): median of 7, and the slowest (usually the first batch) beside it
+        t, res = t_ms(lambda: ctx.align_batch([p[0] for p in pairs], [p[1] for p in pairs], want_fitness=True))
+        reps.append(t)
+    g, g_worst = sorted(reps)[3], max(reps)
     its = sum(r["iterations"] for r in res)
     c, _ = t_ms(lambda: [oracle.icp_align(p[0], p[1], oracle.default_params(), want_fitness=True) for p in pairs[:4]])
-    print(f"C4  64 pairs of 50k (1/8 of 512), <=10 it + fitness, host buffers in: GPU {g:.1f} ms = {64e3/g:.0f} pairs/s, {its*1e3/g:.0f} it/s | "
+    print(f"C4  64 pairs of 50k (1/8 of 512), <=10 it + fitness, host buffers in: GPU median of 7 batches {g:.1f} ms = {64e3/g:.0f} pairs/s, "
+          f"{its*1e3/g:.0f} it/s (slowest batch {g_worst:.1f} ms = {64e3/g_worst:.0f} pairs/s) | "
           f"CPU oracle {c/4:.0f} ms per pair = {4e3/c:.2f} pairs/s on 1 core", flush=True)
     # C5: one GPU's share (250 consecutive pairs) of the 2000-scan sequence, 50k points per scan
     n_scans = int(os.environ.get("C5_SCANS", "251"))
