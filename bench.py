@@ -39,8 +39,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="200kx200k", choices=sorted(WORKLOADS))
     ap.add_argument("--iters", type=int, default=10, help="forced ICP iterations per scan pair")
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid"],
