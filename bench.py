@@ -165,9 +165,14 @@ def main():
             dist.all_gather(allrec, rec)
 
     last = {"T": np.eye(4, dtype=np.float32), "iterations": 0, "converged": False, "n_corr": 0, "mse": 0.0}
+    # Set-up, before the W warm-up steps: the result gather once (torch's allocator and RCCL's communicator are created
+    # lazily: milliseconds to seconds during which the GPU idles) and ~20 ms of alignments that bring the device back to
+    # its running state -- measured: with nothing but 3 warm-up steps the first timed steps ran 3 % below the steady rate.
+    gather(last)
+    for _ in range(20):
+        ctx.align()
     for _ in range(a.warmup):
         last = ctx.align()
-    gather(last)        # warm-up of the gather too: torch's allocator and RCCL's communicator are created lazily
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
