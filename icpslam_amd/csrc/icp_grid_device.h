@@ -246,10 +246,11 @@ __device__ __forceinline__ void octant_row_in_ball(const int* __restrict__ cell_
 template <bool PACK_SHORT_ROWS>
 __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                            const GridDesc& g, float px, float py, float pz, int cx, int cy, int cz,
-                                           unsigned int lane, LaneBest& b) {
+                                           unsigned int lane, LaneBest& b, int rho_first = 1) {
   const float fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h;
   const float slack = grid_slack(g);
-  for (int rho = 1;; rho = min(2 * rho, g.r_max)) {
+  // rho_first > 1: the caller has already covered everything within rho_first - 1/2 cells (stage 2 of nn_quad_kernel)
+  for (int rho = min(rho_first, g.r_max);; rho = min(2 * rho, g.r_max)) {
     const int side = 2 * rho + 1, nrows = side * side;
     const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
     const float inv_side = 1.0f / (float)side;

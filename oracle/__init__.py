@@ -18,6 +18,7 @@ P2P_SVD, GICP = 0, 1
 NN_KDTREE, NN_BRUTE = 0, 1
 PREC_F64, PREC_PCL_F32 = 0, 1
 ARITH_FMA, ARITH_FLANN = 0, 1
+GICP_SUMS_EXACT, GICP_SUMS_SEQUENTIAL, GICP_SUMS_SEQUENTIAL_REVERSED = 0, 1, 2
 STATE_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
                5: "NO_CORRESPONDENCES"}
 
@@ -26,7 +27,7 @@ class Params(C.Structure):
     _fields_ = [("method", C.c_int), ("max_iterations", C.c_int), ("transformation_epsilon", C.c_double),
                 ("max_correspondence_distance", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
                 ("min_correspondences", C.c_int), ("force_iterations", C.c_int), ("nn_mode", C.c_int),
-                ("precision", C.c_int), ("arith", C.c_int)]
+                ("precision", C.c_int), ("arith", C.c_int), ("gicp_sums", C.c_int)]
 
 
 class Result(C.Structure):
@@ -76,6 +77,7 @@ def lib():
         L.orc_voxel_grid.argtypes = [fp, C.c_size_t, C.c_float, fp]
         L.orc_voxel_grid.restype = C.c_long
         L.orc_gicp_covariances.argtypes = [fp, C.c_size_t, C.c_int, dp]
+        L.orc_gicp_covariances_ex.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, dp]
         L.orc_svd3.argtypes = [dp, dp, dp, dp]
         L.orc_svd3.restype = None
         L.orc_map_create.argtypes = [C.c_double]
@@ -195,10 +197,10 @@ def voxel_grid(cloud, leaf: float):
     return out[:n].copy()
 
 
-def gicp_covariances(cloud, arith=ARITH_FMA) -> np.ndarray:
+def gicp_covariances(cloud, arith=ARITH_FMA, pcl_order=False) -> np.ndarray:
     cloud, pc = _f32(cloud)
     out = np.zeros((cloud.shape[0], 9), np.float64)
-    rc = lib().orc_gicp_covariances(pc, cloud.shape[0], arith, out.ctypes.data_as(C.POINTER(C.c_double)))
+    rc = lib().orc_gicp_covariances_ex(pc, cloud.shape[0], arith, int(pcl_order), out.ctypes.data_as(C.POINTER(C.c_double)))
     if rc != 0:
         raise RuntimeError("orc_gicp_covariances: cloud smaller than k = 20")
     return out.reshape(-1, 3, 3)

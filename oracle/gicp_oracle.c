@@ -79,7 +79,7 @@ static void inv3(const double A[9], double Inv[9]) {
 /* ------------------------------------------------------------------------------------------ */
 /* computeCovariances                                                                          */
 /* ------------------------------------------------------------------------------------------ */
-int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_out /* n x 9 row-major */) {
+int orc_gicp_covariances_ex(const float* cloud, size_t n, int arith, int pcl_order, double* cov_out /* n x 9 row-major */) {
   if (n < GICP_K) return -1; /* PCL: "Number or points in cloud is less than k_correspondences_" */
   void* tree = orc_kd_build(cloud, n, arith);
   int32_t idx[GICP_K];
@@ -114,6 +114,17 @@ int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_ou
      * the last bit of the epsilon term ((eps a) b vs (eps b) a), 1e-19 absolute; an implementation that stores six entries
      * per point (the GPU path) could never reproduce that, and nothing downstream gives it a meaning. */
     double* C = cov_out + 9 * i;
+    if (pcl_order) {
+      /* ORC_GICP_SUMS_SEQUENTIAL: PCL's own loop, `cov.setZero(); for k: cov += v * col * col.transpose();` -- all nine
+       * entries accumulated over k, the two triangles keeping their last-bit differences */
+      for (int e = 0; e < 9; ++e) C[e] = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double v = (k == 2) ? GICP_EPSILON : 1.0;
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) C[3 * r + c] += v * U[3 * r + k] * U[3 * c + k];
+      }
+      continue;
+    }
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c <= r; ++c) {
         double acc = 0.0;
@@ -127,6 +138,10 @@ int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_ou
   }
   orc_kd_free(tree);
   return 0;
+}
+
+int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_out) {
+  return orc_gicp_covariances_ex(cloud, n, arith, 0, cov_out);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -186,6 +201,7 @@ typedef struct {
   int m;
   const double* maha; /* indexed by SOURCE index, 9 doubles each */
   float base[16];     /* base_transformation_ = guess */
+  int sequential;     /* 1: ORC_GICP_SUMS_SEQUENTIAL, PCL's plain float64 loop instead of the exact sums; 2: ..._REVERSED */
 } gicp_problem;
 
 /* Order-independent sums.  PCL adds the cost and the gradient terms in plain float64, one after the other; BFGS then
@@ -220,6 +236,31 @@ static void eval_sums(const gicp_problem* P, const double x[6], double* f, doubl
   float T[16];
   memcpy(T, P->base, sizeof(T));
   apply_state(T, x);
+  if (P->sequential) {
+    /* PCL's OptimizationFunctorWithIndices::operator() / fdf: `f += double(res.transpose() * temp)`,
+     * `g.head<3>() += temp`, `R += p_src3 * temp.transpose()` -- one float64 accumulator each, in correspondence order */
+    double acc = 0.0;
+    gt[0] = gt[1] = gt[2] = 0.0;
+    for (int k = 0; k < 9; ++k) Rm[k] = 0.0;
+    for (int ii = 0; ii < P->m; ++ii) {
+      const int i = P->sequential == 2 ? P->m - 1 - ii : ii; /* 2: the same loop run backwards (sensitivity probe) */
+      const float* ps = P->src + 4 * (size_t)P->si[i];
+      const float* pt = P->tgt + 4 * (size_t)P->ti[i];
+      float pp[3], pb[3];
+      xform_point(T, ps, pp);
+      const double res[3] = {(double)(pp[0] - pt[0]), (double)(pp[1] - pt[1]), (double)(pp[2] - pt[2])};
+      const double* M = P->maha + 9 * (size_t)P->si[i];
+      double temp[3];
+      for (int r = 0; r < 3; ++r) temp[r] = M[3 * r] * res[0] + M[3 * r + 1] * res[1] + M[3 * r + 2] * res[2];
+      acc += res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2];
+      for (int r = 0; r < 3; ++r) gt[r] += temp[r];
+      xform_point(P->base, ps, pb);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rm[3 * r + c] += (double)pb[r] * temp[c];
+    }
+    *f = acc;
+    return;
+  }
   sum3 acc = {0, 0, 0}, gts[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Rms[9];
   for (int k = 0; k < 9; ++k) Rms[k].hi = Rms[k].mid = Rms[k].lo = 0.0;
   for (int i = 0; i < P->m; ++i) {
@@ -636,8 +677,9 @@ int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, c
   double* maha = (double*)malloc(n_s * 9 * sizeof(double));
   int32_t* si = (int32_t*)malloc(n_s * sizeof(int32_t));
   int32_t* ti = (int32_t*)malloc(n_s * sizeof(int32_t));
-  orc_gicp_covariances(tgt, n_t, P->arith, Ct);
-  orc_gicp_covariances(src, n_s, P->arith, Cs);
+  const int seq = P->gicp_sums == ORC_GICP_SUMS_SEQUENTIAL ? 1 : P->gicp_sums == ORC_GICP_SUMS_SEQUENTIAL_REVERSED ? 2 : 0;
+  orc_gicp_covariances_ex(tgt, n_t, P->arith, seq, Ct);
+  orc_gicp_covariances_ex(src, n_s, P->arith, seq, Cs);
   void* tree = orc_kd_build(tgt, n_t, P->arith);
   for (size_t i = 0; i < n_s; ++i) {
     double* M = maha + 9 * i;
@@ -653,6 +695,7 @@ int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, c
   gicp_problem prob;
   prob.src = src; prob.tgt = tgt; prob.si = si; prob.ti = ti; prob.maha = maha;
   memcpy(prob.base, guess, sizeof(guess));
+  prob.sequential = seq;
   while (!converged) {
     float TG[16];
     mat4f_mul(transformation, guess, TG); /* query = transformation * (guess * p): applied as one float matrix */
@@ -681,7 +724,7 @@ int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, c
           for (int c = 0; c < 3; ++c)
             tmp[3 * r + c] = RC[3 * r] * R[3 * c] + RC[3 * r + 1] * R[3 * c + 1] + RC[3 * r + 2] * R[3 * c + 2] + C2[3 * r + c];
         inv3(tmp, maha + 9 * i);
-        {
+        if (!seq) {
           /* R C1 R^T + C2 is symmetric only up to rounding, and so is its adjugate inverse; PCL keeps all nine entries.
            * The upper triangle is mirrored here: the difference is in the last bit of three entries, and an
            * implementation that stores six numbers per correspondence (the GPU path: 48 instead of 72 B of the 88 B an

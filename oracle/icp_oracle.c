@@ -678,6 +678,7 @@ void orc_default_params(orc_params* p) {
   p->nn_mode = ORC_NN_KDTREE;
   p->precision = ORC_PREC_F64;
   p->arith = ORC_ARITH_FMA;
+  p->gicp_sums = ORC_GICP_SUMS_EXACT;
 }
 
 int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, const orc_params* P,

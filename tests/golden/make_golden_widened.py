@@ -7,8 +7,10 @@ Like make_golden.py these are data only (inputs + expected outputs); the referen
   * map_3scans -- the mapper's map (octree_mapper.cpp:55-90): expected map after each insertion and the nn cloud from the
                   NumPy restatement in THIS file (dictionary of voxels, brute-force float64-free nearest neighbour with
                   the float32 contract of DESIGN.md section 3), independent of oracle/map_oracle.c.
-  * gicp_1k5   -- GICP (icp_odometer.cpp:188): expected transform / iterations from oracle/gicp_oracle.c (the only
-                  restatement of PCL's BFGS there is: a regression pin for both the oracle and the HIP path).
+  * gicp_1k5   -- GICP (icp_odometer.cpp:188): expected transform / iterations / covariances from the NumPy restatement
+                  oracle/gicp_oracle_np.py (SciPy kd-tree, LAPACK SVD and inverse, PCL's sequential float64 sums), which
+                  was written independently of oracle/gicp_oracle.c; this script refuses to write the fixture unless the C
+                  restatement (in its PCL-ordered mode) lands within the BASELINE tolerance of it.
 """
 import os
 import sys
@@ -122,12 +124,26 @@ def main():
                         probe_pose_inv=pinv, nn_cloud=m.nn_cloud(probe, poses[2], pinv))
     print("map", added, sizes, "nn", m.nn_cloud(probe, poses[2], pinv).shape)
     # f1
+    from oracle import gicp_oracle_np as gnp
     a, b, _ = synth.make_pair(1500, 1500, seed=93)
-    r = oracle.icp_align(a, b, oracle.default_params(method=oracle.GICP), want_fitness=True)
-    cov = oracle.gicp_covariances(b)
+    r = gnp.gicp_align(a, b, sums="sequential")
+    cov = gnp.covariances(b)
+    c = oracle.icp_align(a, b, oracle.default_params(method=oracle.GICP, gicp_sums=oracle.GICP_SUMS_SEQUENTIAL), want_fitness=True)
+    dR = np.abs(r["T"][:3, :3].astype(np.float64) - c["T"][:3, :3]).max()
+    dt = np.linalg.norm(r["T"][:3, 3].astype(np.float64) - c["T"][:3, 3])
+    assert dR <= 1e-4 and dt <= 1e-3 and r["n_corr"] == c["n_corr"], (dR, dt)
+    assert np.abs(cov - oracle.gicp_covariances(b, pcl_order=True)).max() <= 1e-9
+    # fitness (mean squared NN distance after the transform) with the float32 contract, brute force in NumPy
+    moved = gnp.transform_f32(a, r["T"])
+    d = (b[None, :, :3] - moved[:, None, :]).astype(np.float64)
+    d2 = (d[..., 0] * d[..., 0]).astype(f32).astype(np.float64)
+    d2 = (d[..., 1] * d[..., 1] + d2).astype(f32).astype(np.float64)
+    d2 = (d[..., 2] * d[..., 2] + d2).astype(f32)
+    fitness = float(d2.min(axis=1).astype(np.float64).sum() / a.shape[0])
     np.savez_compressed(os.path.join(OUT, "gicp_1k5.npz"), src=a, tgt=b, T=r["T"], converged=r["converged"],
-                        iterations=r["iterations"], n_corr=r["n_corr"], fitness=r["fitness"], cov_tgt=cov)
-    print("gicp", r["iterations"], r["converged"], r["n_corr"])
+                        iterations=r["iterations"], n_corr=r["n_corr"], fitness=fitness, cov_tgt=cov)
+    print("gicp (NumPy restatement)", r["iterations"], r["converged"], r["n_corr"], "C restatement:", c["iterations"],
+          "dR %.1e dt %.1e" % (dR, dt), "fitness", fitness, c["fitness"])
 
 
 if __name__ == "__main__":

@@ -139,3 +139,51 @@ def test_gicp_random_pairs_bit_identical_to_oracle(ctx, seed):
     assert got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"] and got["converged"] == ref["converged"]
     assert np.array_equal(got["T"].view(np.uint32), np.asarray(ref["T"], np.float32).view(np.uint32))
     assert abs(got["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+
+
+def test_gicp_vs_pcl_ordered_evaluation(ctx):
+    """What the reference literally runs is PCL's evaluation: ONE float64 accumulator per sum, in correspondence order, and
+    all nine entries of the covariance / Mahalanobis matrices (oracle mode GICP_SUMS_SEQUENTIAL).  The GPU path is
+    bit-identical to the order-independent definition (exact sums, symmetric matrices: the tests above), which differs
+    from PCL's by PCL's own rounding -- and BFGS amplifies rounding: measured over 400 random pairs on the CPU
+    (exact vs sequential 391 within tolerance, worst 2.1e-4 / 2.4 mm; sequential vs the SAME loop run backwards 390, worst
+    1.6e-4 / 3.1 mm: a pure re-ordering of PCL's own sums moves the result just as far).  This test pins the GPU's distance
+    to the PCL-ordered evaluation on 200 random pairs: at least 95 % within the BASELINE tolerance (1e-4 / 1e-3 m), nothing
+    farther than 1e-3 / 1 cm, and the same again for the yardstick (sequential vs reversed sequential)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def make(seed):
+        rng = np.random.default_rng(90_000 + seed)
+        n_s, n_t = int(rng.integers(3_000, 12_000)), int(rng.integers(3_000, 12_000))
+        gate = float(rng.choice([0.5, 1.0, 2.0]))
+        src, tgt, _ = synth.make_pair(n_s, n_t, seed=seed)
+        return src, tgt, gate
+
+    def ref(seed):
+        src, tgt, gate = make(seed)
+        out = []
+        for mode in (oracle.GICP_SUMS_SEQUENTIAL, oracle.GICP_SUMS_SEQUENTIAL_REVERSED):
+            out.append(oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_iterations=10,
+                                                                       max_correspondence_distance=gate, gicp_sums=mode)))
+        return out
+
+    seeds = list(range(1000, 1200))
+    with ThreadPoolExecutor(8) as ex:   # the oracle releases the GIL (ctypes)
+        refs = list(ex.map(ref, seeds))
+    gpu, yard, same_iters = [], [], 0
+    for seed, (seq, rev) in zip(seeds, refs):
+        src, tgt, gate = make(seed)
+        ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10, max_correspondence_distance=gate)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        got = ctx.align()
+        gpu.append(_cmp(got, seq))
+        yard.append(_cmp(rev, seq))
+        same_iters += got["iterations"] == seq["iterations"]
+    for name, v in (("GPU vs PCL-ordered", gpu), ("PCL-ordered vs the same loop backwards", yard)):
+        ok = sum(dR <= R_TOL and dt <= T_TOL for dR, dt in v)
+        worst = (max(dR for dR, _ in v), max(dt for _, dt in v))
+        print(f"{name}: {ok}/{len(v)} within 1e-4 / 1e-3 m, worst dR {worst[0]:.2e} dt {worst[1]:.2e} m")
+        assert ok >= 0.95 * len(v), (name, ok)
+        assert worst[0] <= 1e-3 and worst[1] <= 1e-2, (name, worst)
+    print(f"same outer-iteration count as the PCL-ordered evaluation: {same_iters}/{len(seeds)}")

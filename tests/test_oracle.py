@@ -226,10 +226,16 @@ def test_map_oracle_matches_golden():
 
 
 def test_gicp_oracle_matches_golden():
+    """The fixture comes from the NumPy restatement (tests/golden/make_golden_widened.py); the C restatement must land
+    within the BASELINE tolerance of it in both of its summation modes (BFGS is chaotic in its sums: the outer iteration
+    count may differ by one or two)."""
     g = _golden("gicp_1k5.npz")
-    r = oracle.icp_align(g["src"], g["tgt"], oracle.default_params(method=oracle.GICP), want_fitness=True)
-    assert r["iterations"] == int(g["iterations"]) and r["converged"] == bool(g["converged"]) and r["n_corr"] == int(g["n_corr"])
-    assert np.abs(r["T"] - g["T"]).max() <= 1e-6 and abs(r["fitness"] - float(g["fitness"])) <= 1e-9
+    for mode in (oracle.GICP_SUMS_SEQUENTIAL, oracle.GICP_SUMS_EXACT):
+        r = oracle.icp_align(g["src"], g["tgt"], oracle.default_params(method=oracle.GICP, gicp_sums=mode), want_fitness=True)
+        assert r["converged"] == bool(g["converged"]) and abs(r["iterations"] - int(g["iterations"])) <= 2
+        assert abs(r["n_corr"] - int(g["n_corr"])) <= 0.001 * int(g["n_corr"])
+        assert np.abs(r["T"][:3, :3] - g["T"][:3, :3]).max() <= 1e-4 and np.linalg.norm(r["T"][:3, 3] - g["T"][:3, 3]) <= 1e-3
+        assert abs(r["fitness"] - float(g["fitness"])) <= 1e-4 * float(g["fitness"])
     assert np.abs(oracle.gicp_covariances(g["tgt"]) - g["cov_tgt"]).max() <= 1e-9
 
 
@@ -283,3 +289,52 @@ def test_property_identical_clouds_give_identity(seed, n):
     src, _ = _cloud_pair(seed, n)
     r = oracle.icp_align(src, src.copy(), oracle.default_params())
     assert r["converged"] and r["n_corr"] == n and np.abs(r["T"] - np.eye(4)).max() <= 1e-6 and r["mse"] <= 1e-12
+
+
+# ---- GICP: two restatements, three summation orders ---------------------------------------------------------------------
+@pytest.mark.parametrize("n,seed", [(1500, 1), (3000, 2), (2500, 5)])
+def test_gicp_two_restatements_agree(n, seed):
+    """oracle/gicp_oracle.c (hand-written kd-tree, Jacobi SVD, adjugate inverse, BFGS in C) against oracle/gicp_oracle_np.py
+    (SciPy kd-tree, LAPACK SVD / inverse, BFGS in Python), both in PCL's summation order and in the exact-sum definition:
+    within the BASELINE tolerance (on most pairs they even agree bit for bit), same correspondences."""
+    from oracle import gicp_oracle_np as gnp
+    src, tgt, _ = synth.make_pair(n, n, seed=seed)
+    for sums, mode in (("sequential", oracle.GICP_SUMS_SEQUENTIAL), ("exact", oracle.GICP_SUMS_EXACT)):
+        a = gnp.gicp_align(src, tgt, sums=sums)
+        b = oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, gicp_sums=mode))
+        assert a["converged"] == b["converged"] and abs(a["iterations"] - b["iterations"]) <= 3
+        assert abs(a["n_corr"] - b["n_corr"]) <= 0.001 * b["n_corr"]
+        assert np.abs(a["T"][:3, :3].astype(np.float64) - b["T"][:3, :3]).max() <= 1e-4
+        assert np.linalg.norm(a["T"][:3, 3].astype(np.float64) - b["T"][:3, 3]) <= 1e-3
+    c_np = gnp.covariances(tgt)
+    assert np.abs(c_np - oracle.gicp_covariances(tgt, pcl_order=True)).max() <= 1e-9
+    assert np.abs(c_np - oracle.gicp_covariances(tgt)).max() <= 1e-9
+
+
+def test_gicp_summation_order_sensitivity():
+    """The exact-sum definition the GPU path is compared with bit for bit, PCL's sequential sums, and the sequential loop
+    run backwards: 24 random pairs, every pairing within the BASELINE tolerance on at least 22 of them, and the exact
+    definition no farther from PCL's order than PCL's order is from its own reversal (x3: small sample).  400 pairs (not
+    in the suite, 30 s): 391 / 390 / 390 within tolerance, worst 2.4 / 3.1 / 3.1 mm."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(seed):
+        rng = np.random.default_rng(90_000 + seed)
+        n_s, n_t = int(rng.integers(3_000, 8_000)), int(rng.integers(3_000, 8_000))
+        gate = float(rng.choice([0.5, 1.0, 2.0]))
+        src, tgt, _ = synth.make_pair(n_s, n_t, seed=seed)
+        r = [oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_correspondence_distance=gate, gicp_sums=m))
+             for m in (oracle.GICP_SUMS_EXACT, oracle.GICP_SUMS_SEQUENTIAL, oracle.GICP_SUMS_SEQUENTIAL_REVERSED)]
+
+        def d(a, b):
+            return (float(np.abs(a["T"][:3, :3].astype(np.float64) - b["T"][:3, :3]).max()),
+                    float(np.linalg.norm(a["T"][:3, 3].astype(np.float64) - b["T"][:3, 3])))
+        return d(r[0], r[1]), d(r[1], r[2])
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(one, range(24)))
+    for k in (0, 1):
+        assert sum(dR <= 1e-4 and dt <= 1e-3 for dR, dt in (r[k] for r in res)) >= 22
+    worst_exact = max(r[0][1] for r in res)
+    worst_yard = max(r[1][1] for r in res)
+    assert worst_exact <= max(3.0 * worst_yard, 1e-3), (worst_exact, worst_yard)
