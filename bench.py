@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the ICP hot path on MI355X.
 
-One "step" = one scan-pair registration through the C-ABI: `--iters` forced point-to-point ICP iterations
-(NN correspondence search + rejection + covariance reduction + host SVD each) on clouds already resident in HBM.
-Default workload = BASELINE.json's metric configuration: a 200k x 200k KITTI-shaped synthetic scan pair
-(SURVEY.md section 8(d) headline pair, seed 4 + rank), 10 iterations per step (ICP_MAX_ITERS of the reference's
-odometer, /root/reference/include/icpslam/icp_odometer.h:65).
+One "step" = one pass of the hot path over one batch of synthetic input, through the C-ABI:
+  * pair workloads (default 200kx200k = BASELINE.json's metric configuration, SURVEY.md 8(d) headline pair, seed 4 + rank):
+    one scan-pair registration of `--iters` forced point-to-point ICP iterations (NN correspondence search + rejection +
+    covariance reduction + host SVD each) on clouds already resident in HBM; 10 iterations per step = ICP_MAX_ITERS of the
+    reference's odometer (/root/reference/include/icpslam/icp_odometer.h:65);
+  * batch50k (BASELINE config 4): this rank's share of 512 independent 50k-point scan pairs (64 per rank at 8 ranks)
+    through icpgpu_align_batch (<= 10 iterations + getFitnessScore each, host buffers in), then the result gather
+    (icpslam_amd.sharding.gather_records: one all_gather of 184-byte records, RCCL on GPUs).
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); independent scan pairs shard across ranks with
-no data-path collective (weak scaling: fixed work per GPU); the only communication is the result gather at the end
-of the timed region.  value = iterations executed by all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); independent scan pairs shard across ranks with no
+data-path collective (weak scaling: fixed work per GPU); the only communication is the result gather at the end of the
+timed region.  value = iterations executed by all ranks / max-over-ranks time.  `python bench.py --gpus N` without a
+launcher re-executes itself under torch.distributed.run with N ranks on 127.0.0.1.
 
 Prints ONE JSON line on rank 0.
 """
@@ -18,6 +22,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +31,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak == FP32 (f32-in) MFMA dense peak
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak (packed FMA) == FP32 (f32-in) MFMA dense peak
+N_SIMDS = 256 * 4          # 256 CUs x 4 SIMD16
+CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: peak engine clock
+# a wave64 VALU instruction occupies its SIMD16 for 4 cycles: the chip issues at most N_SIMDS * clock / 4 of them per second
+VALU_ISSUE_PEAK_GINST = N_SIMDS * CLOCK_GHZ / 4.0
 
 WORKLOADS = {
     # name: (n_src, n_tgt, kind)
@@ -33,30 +43,66 @@ WORKLOADS = {
     "50kx50k": (50000, 50000, "pair"),
     "200kx200k": (200000, 200000, "pair"),
     "200kx1M": (200000, 1000000, "submap"),
+    "batch50k": (50000, 50000, "batch"),
 }
+BATCH_TOTAL_PAIRS_AT_8 = 512      # BASELINE config 4: 512 pairs over 8 GPUs = 64 per GPU (weak scaling: 64 per rank)
+BATCH_PAIRS_PER_RANK = BATCH_TOTAL_PAIRS_AT_8 // 8
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="default 50 (pair workloads) / 5 (batch50k)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 10 (pair workloads) / 2 (batch50k)")
     ap.add_argument("--workload", default="200kx200k", choices=sorted(WORKLOADS))
-    ap.add_argument("--iters", type=int, default=10, help="forced ICP iterations per scan pair")
+    ap.add_argument("--iters", type=int, default=10, help="ICP iterations per scan pair (forced for the pair workloads)")
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid"],
                     help="correspondence search: auto (grid-accelerated exact NN where it helps), brute (LDS-tiled)")
+    ap.add_argument("--pairs-per-rank", type=int, default=BATCH_PAIRS_PER_RANK, help="batch50k: scan pairs per rank and step")
+    ap.add_argument("--setup-aligns", type=int, default=20,
+                    help="untimed alignments before the W warm-up steps (bring the device to its running state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (e2e rate, GICP, brute force)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
-    return ap.parse_args()
+    a = ap.parse_args()
+    batch = WORKLOADS[a.workload][2] == "batch"
+    if a.steps is None:
+        a.steps = 5 if batch else 50
+    if a.warmup is None:
+        a.warmup = 2 if batch else 10
+    return a
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_self_launch(a) -> None:
+    """`python bench.py --gpus N` with no launcher around it: become N ranks (one process per GPU) by re-executing under
+    torch.distributed.run on 127.0.0.1.  Under a launcher (WORLD_SIZE set) the world must be the one --gpus names."""
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return
+    if a.gpus <= 1:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def make_workload(name: str, seed: int):
     from icpslam_amd import synth
     n_s, n_t, kind = WORKLOADS[name]
-    if kind == "pair":
-        src, tgt, _ = synth.make_pair(n_s, n_t, seed)
-    else:
+    if kind == "submap":
         src, tgt, _ = synth.make_scan_vs_submap(n_s, n_t, seed)
+    else:
+        src, tgt, _ = synth.make_pair(n_s, n_t, seed)
     return src, tgt
 
 
@@ -86,38 +132,51 @@ def _cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(src, tgt, iters: int, budget_s: float):
-    """The oracle (C restatement of PCL's ICP, kd-tree NN, single thread like PCL 1.8) timed on this box's host."""
+def cpu_baseline(pairs, iters: int, force: bool, budget_s: float):
+    """The oracle (C restatement of PCL's ICP, kd-tree NN, single thread like PCL 1.8) timed on this box's host, on a bounded
+    sample of the same workload.  Every align builds its kd-tree, as PCL does for every scan (`icp` is a stack object at
+    icp_odometer.cpp:188): the build is part of the reference's per-pair cost."""
     import oracle
     oracle.build()
-    p = oracle.default_params(max_iterations=iters, force_iterations=1)
-    done, t_used = 0, 0.0
+    p = oracle.default_params(max_iterations=iters, force_iterations=1 if force else 0)
+    done, aligns, t_used = 0, 0, 0.0
     t0 = time.perf_counter()
     while True:
+        src, tgt = pairs[aligns % len(pairs)]
         r = oracle.icp_align(src, tgt, p)
         done += r["iterations"]
+        aligns += 1
         t_used = time.perf_counter() - t0
-        if t_used >= budget_s or done >= 10 * iters:
+        if t_used >= budget_s or aligns >= 10:
             break
-    aligns = done // max(1, iters)
-    # the same work on many cores at once (independent aligns of the same pair; ctypes releases the GIL): what a CPU-only
-    # host could do for the BATCH configs.  A single alignment cannot use them: PCL's ICP is single-threaded.
+    # the same work on many cores at once (independent aligns; ctypes releases the GIL): what a CPU-only host could do for
+    # the BATCH configs.  A single alignment cannot use them: PCL's ICP is single-threaded.
     from concurrent.futures import ThreadPoolExecutor
     n_thr = max(1, min(64, _effective_cpus()))
     t1 = time.perf_counter()
     with ThreadPoolExecutor(n_thr) as ex:
-        its = list(ex.map(lambda _: oracle.icp_align(src, tgt, p)["iterations"], range(n_thr)))
+        its = list(ex.map(lambda k: oracle.icp_align(*pairs[k % len(pairs)], p)["iterations"], range(n_thr)))
     t_all = time.perf_counter() - t1
-    many = {"value": sum(its) / t_all, "unit": "iterations/s", "cores": n_thr,
-            "sample": f"{n_thr} concurrent aligns of the same pair, one per thread, {t_all:.1f} s"}
-    return {"value": done / t_used, "unit": "iterations/s", "cores": 1, "kind": "port", "many_cores": many,
-            "sample": f"{aligns} full align(s) of the same {src.shape[0]}x{tgt.shape[0]} pair, {done} iterations, "
-                      f"{t_used:.1f} s incl. kd-tree build; oracle/icp_oracle.c (restatement, not PCL binaries)",
+    many = {"value": sum(its) / t_all, "unit": "iterations/s", "cores": n_thr, "pairs_per_sec": n_thr / t_all,
+            "sample": f"{n_thr} concurrent aligns, one per thread, {t_all:.1f} s"}
+    n_s, n_t = pairs[0][0].shape[0], pairs[0][1].shape[0]
+    return {"value": done / t_used, "unit": "iterations/s", "cores": 1, "kind": "port", "pairs_per_sec": aligns / t_used,
+            "many_cores": many,
+            "sample": f"{aligns} full align(s) of {n_s}x{n_t} pair(s), {done} iterations, {t_used:.1f} s incl. the kd-tree "
+                      f"build of every align (PCL rebuilds it per scan); oracle/icp_oracle.c (restatement, not PCL binaries)",
             "host_cpus": os.cpu_count(), "usable_cpus": _effective_cpus(), "cpu_model": _cpu_model()}
+
+
+def _load_json(name: str) -> dict:
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
 
 
 def main():
     a = parse()
+    maybe_self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,65 +200,129 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world == a.gpus
 
-    from icpslam_amd import NN_AUTO, NN_BRUTE, NN_GRID, Context
+    from icpslam_amd import GICP, NN_AUTO, NN_BRUTE, NN_GRID, Context, sharding, synth
 
     nn_mode = {"auto": NN_AUTO, "brute": NN_BRUTE, "grid": NN_GRID}[a.nn]
-    src, tgt = make_workload(a.workload, seed=4 + rank)
+    n_s, n_t, kind = WORKLOADS[a.workload]
+    batch = kind == "batch"
     ctx = Context(local_rank)
-    ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1, nn_mode=nn_mode)
-    ctx.set_source(src)      # inputs resident in HBM before the timed region
-    ctx.set_target(tgt)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather(res):
-        """Result gather, the only inter-GPU traffic of the path: T (16 f32) + iterations + converged + n_corr + mse."""
-        rec = torch.tensor(list(res["T"].reshape(-1)) + [res["iterations"], float(res["converged"]), res["n_corr"],
-                                                          res["mse"]], dtype=torch.float64, device=coll_dev)
-        if world > 1:
-            allrec = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(allrec, rec)
+    if batch:
+        # config 4: independent pairs, seeds 1000..; pair k of the whole job lives on rank owner(k)
+        n_total = a.pairs_per_rank * world
+        mine = sharding.shard_range(n_total, rank, world)
+        pairs = [synth.make_pair(n_s, n_t, seed=1000 + k)[:2] for k in mine]
+        srcs, tgts = [p[0] for p in pairs], [p[1] for p in pairs]
+        ctx.set_params(ctx.default_params(), max_iterations=a.iters, nn_mode=nn_mode)
 
-    last = {"T": np.eye(4, dtype=np.float32), "iterations": 0, "converged": False, "n_corr": 0, "mse": 0.0}
+        def step():
+            res = ctx.align_batch(srcs, tgts, want_fitness=True)
+            local = np.stack([sharding.make_record(k, r) for k, r in zip(mine, res)])
+            sharding.gather_records(local, n_total, rank, world, coll_dev if world > 1 else None)   # the RCCL gather
+            return res
+        setup_steps = 1
+    else:
+        src, tgt = make_workload(a.workload, seed=4 + rank)
+        pairs = [(src, tgt)]
+        ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1, nn_mode=nn_mode)
+        ctx.set_source(src)      # inputs resident in HBM before the timed region
+        ctx.set_target(tgt)
+
+        def gather(res):
+            """Result gather, the only inter-GPU traffic of the path: one 184-byte record per pair."""
+            local = sharding.make_record(rank, res)[None]
+            sharding.gather_records(local, world, rank, world, coll_dev if world > 1 else None)
+
+        def step():
+            return ctx.align()
+        setup_steps = a.setup_aligns
+
     # Set-up, before the W warm-up steps: the result gather once (torch's allocator and RCCL's communicator are created
-    # lazily: milliseconds to seconds during which the GPU idles) and ~20 ms of alignments that bring the device back to
-    # its running state -- measured: with nothing but 3 warm-up steps the first timed steps ran 3 % below the steady rate.
-    gather(last)
-    for _ in range(20):
-        ctx.align()
+    # lazily: milliseconds to seconds during which the GPU idles) and --setup-aligns alignments that bring the device back
+    # to its running state -- measured: with nothing but 3 warm-up steps the first timed steps ran 3 % below the steady rate.
+    if not batch:
+        gather({"T": np.eye(4, dtype=np.float32), "iterations": 0, "converged": False, "state": 0, "n_corr": 0, "mse": 0.0,
+                "fitness": 0.0})
+    for _ in range(setup_steps):
+        step()
     for _ in range(a.warmup):
-        last = ctx.align()
+        last = step()
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        last = ctx.align()
-    gather(last)
+        last = step()
+    if not batch:
+        gather(last)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
     prof = ctx.profile()
     iters_done = int(prof.iterations)
+    pairs_done = int(prof.aligns)
+    if world > 1:
+        agg = torch.tensor([elapsed, float(iters_done), float(pairs_done)], dtype=torch.float64, device=coll_dev)
+        tmax = agg[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        elapsed, iters_all, pairs_all = float(tmax.item()), int(agg[1].item()), int(agg[2].item())
+    else:
+        iters_all, pairs_all = iters_done, pairs_done
 
-    # scan-pairs/s as the odometer runs it: align + getFitnessScore (one more NN sweep), untimed for `value`
-    t1 = time.perf_counter()
-    n_pair_runs = max(1, min(5, a.steps))
-    for _ in range(n_pair_runs):
+    extras = {}
+    if rank == 0 and not a.no_extras and kind == "pair":
+        # (1) scan pairs/s as the reference's odometer produces them, SURVEY.md 8(d) protocol: everything
+        # laserCloudCallback does per scan inside the timed region (icp_odometer.cpp:188-210) -- setInputSource from a HOST
+        # buffer (H2D copy), the per-scan index build, align, getFitnessScore, *prev_cloud_ = *curr_cloud_ -- over
+        # alternating scans A, B, A, ... so that every pair has a new source and a new target index.
+        def odometry_loop(n_pairs, **params):
+            ctx.set_params(**params)
+            clouds = (src, tgt)
+            ctx.set_source(clouds[1])
+            ctx.promote_source_to_target()
+            for k in range(2):                      # warm-up (buffers of both roles allocated)
+                ctx.set_source(clouds[k % 2]); ctx.align(want_fitness=True); ctx.promote_source_to_target()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(n_pairs):
+                ctx.set_source(clouds[k % 2])
+                ctx.align(want_fitness=True)
+                ctx.promote_source_to_target()
+            torch.cuda.synchronize()
+            return n_pairs / (time.perf_counter() - t)
+        n_e2e = max(4, min(20, a.steps))
+        e2e = odometry_loop(n_e2e, max_iterations=a.iters, force_iterations=1)
+        # ... and the resident-pair figure of round 1 (align + getFitnessScore, target index reused)
+        ctx.set_source(src); ctx.set_target(tgt)
         ctx.align(want_fitness=True)
-    torch.cuda.synchronize()
-    pair_s = (time.perf_counter() - t1) / n_pair_runs
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ctx.align(want_fitness=True)
+        torch.cuda.synchronize()
+        resident = 5 / (time.perf_counter() - t1)
+        extras["scan_pairs_per_sec_e2e"] = e2e
+        extras["scan_pairs_per_sec_resident"] = resident
+        extras["scan_pair_def"] = (
+            f"e2e: per scan set_source from a host buffer (H2D) + index build + align({a.iters} forced iterations) + "
+            "getFitnessScore + promote_source_to_target, as icp_odometer.cpp:188-210 runs per scan; resident: align + "
+            "getFitnessScore on a resident pair, target index reused")
+        # (2) the solver the reference literally instantiates (GICP, icp_odometer.cpp:188) on the same raw pair, same loop
+        gicp = odometry_loop(max(3, n_e2e // 3), method=GICP, max_iterations=a.iters, force_iterations=0)
+        extras["gicp"] = {"scan_pairs_per_sec_e2e": gicp,
+                          "def": f"the same odometry loop with method = GICP (<= {a.iters} outer iterations, BFGS inner "
+                                 "solver): what pcl::GeneralizedIterativeClosestPoint at icp_odometer.cpp:188 runs per scan"}
+        ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1, nn_mode=nn_mode)
+        ctx.set_source(src); ctx.set_target(tgt)
 
     # the brute-force kernel (north_star's design) measured in the same process for its own roofline line
     brute = None
-    if rank == 0:
+    if rank == 0 and not a.no_extras and not batch:
         ctx.profile_sampling(1)                    # 4 launches only: time every one of them
         ctx.set_params(nn_mode=NN_BRUTE, max_iterations=2)
         ctx.align()
@@ -211,29 +334,25 @@ def main():
         ctx.set_params(nn_mode=nn_mode, max_iterations=a.iters)
 
     if rank == 0:
-        n_s, n_t = src.shape[0], tgt.shape[0]
         flops = 8.0 * n_s * n_t                      # F_iter = 8 * N_s * N_t (brute force)
         alg_bytes_keys = 16.0 * (n_s + n_t) + 8.0 * n_s   # both clouds once + 8 B key per source point
         alg_bytes_fused = 16.0 * (n_s + n_t) + 64.0       # fused design lower bound
         used_grid = prof.grid_launches > 0
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(a.workload, {})
-            except Exception:
-                traffic = {}
-        b_ms = brute["avg_launch_ms"]
-        b_tf = flops / (b_ms * 1e-3) / 1e12
-        brute_roofline = {
-            "kernel": "nn_brute_kernel<0,4> (LDS-tiled brute force)", "bound": "mfma", "achieved": b_tf,
-            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": b_tf / FP32_PEAK_TFLOPS,
-            "traffic": traffic.get("nn_brute_hbm_bytes_per_launch"), "avg_launch_ms": b_ms,
-            "hbm": {"achieved": alg_bytes_keys / (b_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": alg_bytes_keys / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": alg_bytes_keys},
-            "note": "brute-force NN is FP32-compute-bound (8*Ns*Nt flop per launch); peak = f32 dense MFMA peak = f32 "
-                    "vector peak (157.3 TFLOP/s)"}
+        traffic = _load_json("pmc_traffic.json").get(a.workload, {})
+        issue_pmc = _load_json("pmc_issue.json").get(a.workload, {})
+        brute_roofline = None
+        if brute:
+            b_ms = brute["avg_launch_ms"]
+            b_tf = flops / (b_ms * 1e-3) / 1e12
+            brute_roofline = {
+                "kernel": "nn_brute_kernel (LDS-tiled brute force)", "bound": "mfma", "achieved": b_tf,
+                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": b_tf / FP32_PEAK_TFLOPS,
+                "traffic": traffic.get("nn_brute_hbm_bytes_per_launch"), "avg_launch_ms": b_ms,
+                "hbm": {"achieved": alg_bytes_keys / (b_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes_keys / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes_keys},
+                "note": "brute-force NN is FP32-compute-bound (8*Ns*Nt flop per launch); peak = f32 dense MFMA peak = f32 "
+                        "vector peak (157.3 TFLOP/s, packed FMA)"}
         if used_grid:
             g_ms = prof.grid_ms / max(1, prof.grid_timed)
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
@@ -244,17 +363,52 @@ def main():
                 "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
                 "algorithmic_bytes_per_launch": alg_bytes_fused,
                 "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
-                        "(SURVEY.md 8(d) fused lower bound); an exact NN search is bound by instruction issue and cache transactions "
-                        "(PMC: VALU 68 % of the SIMD cycles), not by HBM streaming -- DESIGN.md section 5",
-                "brute_force_kernel": brute_roofline}
+                        "(SURVEY.md 8(d) fused lower bound).  An exact NN search does not stream: what binds it is VALU "
+                        "instruction issue -- see `issue` (DESIGN.md section 5)"}
+            if issue_pmc:
+                # The binding roofline: wave-level VALU instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, mean per
+                # launch over the sweeps of an alignment, profiles/pmc_issue.json) / the live launch time, against what
+                # 1024 SIMD16s can issue (one wave64 VALU instruction per 4 cycles each).
+                valu = float(issue_pmc["valu_insts_per_launch"])
+                ginst = valu / (g_ms * 1e-3) / 1e9
+                cand = float(issue_pmc.get("candidates_per_launch", 0.0))
+                roofline["issue"] = {
+                    "bound": "valu_issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instr/s",
+                    "frac": ginst / VALU_ISSUE_PEAK_GINST, "valu_insts_per_launch": valu,
+                    "valu_insts_per_source_point": valu / n_s,
+                    "salu_insts_per_launch": issue_pmc.get("salu_insts_per_launch"),
+                    "candidates_per_launch": cand or None,
+                    "useful_tflops": (8.0 * cand / (g_ms * 1e-3) / 1e12) if cand else None,
+                    "useful_flop_frac_of_fp32_peak": (8.0 * cand / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if cand else None,
+                    "source": issue_pmc.get("_how", "profiles/pmc_issue.json")}
+            if brute_roofline:
+                roofline["brute_force_kernel"] = brute_roofline
+        elif batch:
+            roofline = {"kernel": "(batch workload: eight concurrent contexts, kernels overlap; see the pair workloads)",
+                        "bound": "hbm", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}
         else:
             nn_ms = prof.nn_ms / max(1, prof.nn_timed)
             tf = flops / (nn_ms * 1e-3) / 1e12
-            roofline = dict(brute_roofline, achieved=tf, frac=tf / FP32_PEAK_TFLOPS, avg_launch_ms=nn_ms,
-                            launches=int(prof.nn_launches))
+            roofline = dict(brute_roofline or {}, kernel="nn_brute_kernel (LDS-tiled brute force)", bound="mfma", achieved=tf,
+                            peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, avg_launch_ms=nn_ms,
+                            launches=int(prof.nn_launches), traffic=traffic.get("nn_brute_hbm_bytes_per_launch"))
+        if batch and used_grid:
+            g_ms = prof.grid_ms / max(1, prof.grid_timed)
+            gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
+            roofline = {"kernel": "nn_quad_kernel<fused> at 50k x 50k, several contexts in flight", "bound": "hbm",
+                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": g_ms, "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
+                        "algorithmic_bytes_per_launch": alg_bytes_fused}
+        if batch:
+            workload = (f"batch50k: {a.pairs_per_rank} independent 50k x 50k synthetic scan pairs per GPU and step (seeds 1000+k; "
+                        f"BASELINE config 4 = 512 pairs over 8 GPUs), <= {a.iters} point-to-point ICP iterations + getFitnessScore "
+                        "each through icpgpu_align_batch (host buffers in), then the result gather")
+        else:
+            workload = (f"{a.workload} synthetic Velodyne-shaped scan pair per GPU (seed 4+rank), "
+                        f"{a.iters} forced point-to-point ICP iterations per step, clouds resident in HBM")
         out = {
             "metric": "icp_iterations_per_sec",
-            "value": world * a.steps * a.iters / elapsed,
+            "value": iters_all / elapsed,
             "unit": "iterations/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -265,23 +419,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{a.workload} synthetic Velodyne-shaped scan pair per GPU (seed 4+rank), "
-                                   f"{a.iters} forced point-to-point ICP iterations per step, clouds resident in HBM",
-                       "n_src": n_s, "n_tgt": n_t, "iters_per_step": a.iters,
+            "config": {"workload": workload, "n_src": n_s, "n_tgt": n_t,
+                       "iters_per_step": iters_all / max(1, world * a.steps),
                        "nn": ("uniform-grid exact NN (fused reduce)" if used_grid else "brute-force LDS-tiled") + f" [--nn {a.nn}]",
-                       "parallelism": f"{world} independent scan pair(s), one per GPU; result all_gather only"},
-            "scan_pairs_per_sec": world / pair_s,
-            "scan_pair_def": f"align({a.iters} iterations) + getFitnessScore, as icp_odometer.cpp:198-201 "
-                             "(target index reused; set_target + index build are outside)",
-            "iterations_timed": iters_done,
+                       "parallelism": f"{world} rank(s), one per GPU, independent scan pairs; result all_gather only",
+                       "setup_aligns": setup_steps},
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+            "scan_pairs_per_sec": pairs_all / elapsed,
+            "scan_pairs_def": "alignments finished by all ranks / the timed region"
+                              + ("" if batch else " (resident pair, no fitness sweep: see scan_pairs_per_sec_e2e for the odometer's per-scan protocol)"),
+            "iterations_timed": iters_all,
             "roofline": roofline,
             "reduce_kernel": {"avg_ms": prof.reduce_ms / max(1, prof.reduce_timed)},
         }
+        out.update(extras)
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(src, tgt, a.iters, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pairs[: 4], a.iters, not batch, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

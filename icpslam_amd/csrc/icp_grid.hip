@@ -344,39 +344,19 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
 // 4+4 v_min_u32_dpp (no readlanes, no scalar tie logic), the winner's coordinates come back through ds_bpermute and the
 // 16 product terms of the fused reduction go one to a lane (the count is an integer, the d2 sum shares lane 0).  That
 // removes most of the per-point fixed cost of nn_wave_kernel (merge, term selection, scalar row set-up: ~70 of ~150 wave
-// instructions).
-//
-// Points the octant cannot certify (7 % of a converged 200k pair, 37 % of its first sweep) are DEFERRED: their state (slot,
-// best key and point so far -- the octant's winner or last sweep's neighbour, whichever is closer) goes to a wave-private
-// LDS list, and after the four octant passes the list is worked off by STAGE 2, again four points at a time and 16 lanes
-// each.  Stage 2 is driven by the ball, not by cubes: a target point is known at distance D, so the neighbour lies in the
-// ball of radius D, and the cell rows that can hold it are exactly those whose (y, z) slab is within D of the point.  The
-// 16 lanes of a group set up 16 such rows per batch (the window [floor(u - R), floor(u + R)]^2 of rows, each trimmed to
-// the ball's chord along x, R = D in cells, inflated like every ball of this file), then walk the non-empty ones one
-// after the other, 16 entries per step.  One level, no growth: the walk covers the whole ball, so its minimum together
-// with the seed is the exact neighbour.  Measured before it existed (200k x 200k, all ten sweeps of an alignment): the
-// wave-wide cube search of the uncertified points took 477 of the kernel's 782 us.  Only points whose window exceeds
-// s2_rows rows, or for which nothing is known yet (empty octant, no previous neighbour), still take the wave-wide cube
-// search of nn_wave_kernel, one at a time -- started at the radius the known distance asks for.
-struct DeferredPoint {
-  int ql;                 // preamble lane (row 0) of the point's slot
-  unsigned int d2, idx;   // best key so far (0xFFFFFFFF, 0xFFFFFFFF: nothing met)
-  float qx, qy, qz;       // ... and the point that has it
-};
-
+// instructions).  Points the octant cannot certify fall back to the wave-wide cube search, one at a time, as before.
 template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool PACK_SHORT_ROWS>
-__global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
+__global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_quad_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
                                                            const float4* __restrict__ sorted,
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
                                                            int* __restrict__ unmatched_count, float4* __restrict__ prev_nn,
-                                                           int use_prev, int s2_rows) {
+                                                           int use_prev, int cube_start) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp_base = lane & 48, sub = lane & 15;
   const int lb = xcd_map ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int k0 = lb * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
-  __shared__ DeferredPoint deferred[WQ_WAVES][WQ_MAX_QPW];
 
   // fused reduction: lane s of a row owns one product term (term order of accumulate_pair; s = 0 takes the d2 sum, the
   // count is kept as an integer)
@@ -387,32 +367,6 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
   else if (sub <= 3) pi = sub - 1;
   else if (sub <= 6) qi = sub - 4;
   else { qi = (sub - 7) / 3; pi = (sub - 7) % 3; }
-
-  // what happens to a point once its neighbour is settled (all 16 lanes of its group call this with the same values)
-  auto finish_point = [&](bool valid, int qi_src, bool fin, bool found, unsigned long long gkey, float qx, float qy, float qz,
-                          float px, float py, float pz) {
-    if (prev_nn && sub == 0 && valid) {
-      // the best point met, certified or not (beyond the gate it is still a target point, hence a bound for the next
-      // sweep -- getFitnessScore's ungated one in particular); NaN when nothing was met at all
-      const float bd = __uint_as_float((unsigned int)(gkey >> 32)), none = __builtin_nanf("");
-      prev_nn[qi_src] = (fin && bd == bd) ? make_float4(qx, qy, qz, 0.f) : make_float4(none, none, none, 0.f);
-    }
-    if constexpr (WRITE_KEYS) {
-      if (sub == 0 && valid) keys[qi_src] = found ? gkey : kEmptyKey;
-    }
-    if constexpr (LIST_UNMATCHED) {
-      if (sub == 0 && valid && !found) unmatched[atomicAdd(unmatched_count, 1)] = qi_src;
-    }
-    if constexpr (FUSE_REDUCE) {
-      const float d2 = __uint_as_float((unsigned int)(gkey >> 32));
-      if (valid && found && d2 <= accept_thr) {
-        const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)qx : qi == 1 ? (double)qy : qi == 2 ? (double)qz : (double)d2);
-        const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
-        acc += a * c;
-        cnt += 1;
-      }
-    }
-  };
 
   // preamble: lane -> (point lane/4, octant row lane%4), as nn_wave_kernel
   float lpx = 0.f, lpy = 0.f, lpz = 0.f, lmargin = 0.5f;
@@ -458,7 +412,6 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
   }
 
   const char* __restrict__ sorted_bytes = reinterpret_cast<const char*>(sorted);
-  int n_def = 0;  // points of this wave waiting for stage 2 (wave-uniform)
   for (int pass = 0; pass < n_pass; ++pass) {
     const int ql = 4 * lane_get_i(slot_of_rank, 4 * (4 * pass + (lane >> 4)));  // preamble lane (row 0) of this group's point
     const int qi_src = k0 + (ql >> 2) * stride;                                 // its index in the source cloud
@@ -499,7 +452,7 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
     const unsigned int imin = row16_min_u32(dbits == dmin ? idx : 0xFFFFFFFFu);
     const unsigned long long win = __ballot(dbits == dmin && idx == imin);  // >= 1 lane per row
     const int owner = grp_base + __ffs((unsigned int)(win >> grp_base) & 0xFFFFu) - 1;
-    const unsigned long long gkey = ((unsigned long long)dmin << 32) | imin;
+    unsigned long long gkey = ((unsigned long long)dmin << 32) | imin;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (FUSE_REDUCE || prev_nn) {
       const float4 w = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)(unsigned int)lane_get_i((int)bpos, owner));
@@ -507,149 +460,43 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
       qy = w.y;
       qz = w.z;
     }
-    const bool found = fin && __uint_as_float(dmin) <= lane_get_f(lsafe_sq, ql);  // an empty row has dmin = NaN bits: false
-    const float pb = lane_get_f(lbound, ql);  // last sweep's neighbour, at its distance under this sweep's transform
+    bool found = fin && __uint_as_float(dmin) <= lane_get_f(lsafe_sq, ql);  // an empty row has dmin = NaN bits: false
 
-    // not certified by the octant: deferred to stage 2 (use_prev bit 1: timing experiments only -- such points are dropped)
-    const bool defer = fin && !found && !(use_prev & 2);
-    const unsigned long long need = __ballot(defer && sub == 0);
-    if (defer && sub == 0) {
-      DeferredPoint d{ql, dmin, imin, qx, qy, qz};
-      // last sweep's neighbour seeds the search when it is closer than the octant's winner (it may lie outside the
-      // octant).  It enters with the highest index: the walk meets the point itself again, same distance bits, and its
-      // real index wins the tie.
-      if (pb < __builtin_inff() && !(__uint_as_float(dmin) <= pb)) {
-        const float4 pq = prev_nn[qi_src];  // not yet overwritten: this point has not been finished
-        d.d2 = __float_as_uint(pb);
-        d.idx = 0xFFFFFFFFu;
-        d.qx = pq.x;
-        d.qy = pq.y;
-        d.qz = pq.z;
-      }
-      deferred[wave][n_def + __popcll(need & ((1ull << lane) - 1ull))] = d;
-    }
-    n_def += __popcll(need);
-    finish_point(valid && !defer, qi_src, fin, found, gkey, qx, qy, qz, px, py, pz);
-  }
-
-  // ---- stage 2: the deferred points, four at a time ----------------------------------------------------------------------
-  // The 4 x 4 x 4 block of cells that extends the point's octant by one cell on every side: 16 cell rows, one per lane of
-  // the group, each an x run of (at most) 4 cells, trimmed to the ball of the best point known so far.  Every cell outside
-  // the block is at least 1.5 cells from the point, so a best distance <= 63/64 * 1.5 h is final.
-  __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: the list is complete)
-  const float cert2 = 1.5f * g.h * kGridSafety, cert2_sq = cert2 * cert2;
-  for (int base = 0; base < n_def; base += 4) {
-    const int e = base + (lane >> 4);
-    const bool act = e < n_def;
-    const DeferredPoint d = deferred[wave][act ? e : 0];
-    const int ql = d.ql, qi_src = k0 + (ql >> 2) * stride;
-    const float px = lane_get_f(lpx, ql), py = lane_get_f(lpy, ql), pz = lane_get_f(lpz, ql);
-    unsigned long long gkey = ((unsigned long long)d.d2 << 32) | d.idx;
-    float qx = d.qx, qy = d.qy, qz = d.qz;
-    bool found = false;
-    if (s2_rows > 0) {  // (wave-uniform; 0: straight to the cube search, as before stage 2 existed)
-      int lo = 0, len = 0;
-      // (fetched by ALL lanes: ds_bpermute returns 0 for a source lane that is masked off, and the preamble lanes of this
-      // group's point may belong to a group without a point)
-      const int cx = lane_get_i(lcx, ql), cy = lane_get_i(lcy, ql), cz = lane_get_i(lcz, ql);
-      if (act) {
-        const float ux = (px - g.ox) * g.inv_h, uy = (py - g.oy) * g.inv_h, uz = (pz - g.oz) * g.inv_h;
-        const int ax = cx + (ux - (float)cx < 0.5f ? -1 : 0), ay = cy + (uy - (float)cy < 0.5f ? -1 : 0),
-                  az = cz + (uz - (float)cz < 0.5f ? -1 : 0);  // the octant's low corner, as octant_row computes it
-        const int yy = ay - 1 + (sub & 3), zz = az - 1 + (sub >> 2);
-        int x0 = max(ax - 1, 0), x1 = min(ax + 2, g.nx - 1);
-        if (x0 <= x1 && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz) {
-          const float dy = fmaxf(fmaxf((float)yy - uy, uy - (float)(yy + 1)), 0.f);
-          const float dz = fmaxf(fmaxf((float)zz - uz, uz - (float)(zz + 1)), 0.f);
-          const float rem = ball_cells_sq(g, __uint_as_float(d.d2)) - dy * dy - dz * dz;  // +inf while nothing is known; NaN never passes
-          if (rem >= 0.f) {
-            const float w = sqrtf(rem);
-            x0 = (int)fmaxf(floorf(ux - w), (float)x0);
-            x1 = (int)fminf(floorf(ux + w), (float)x1);
-            if (x0 <= x1) {
-              const int row = zz * g.sz + yy * g.sy;
-              lo = cell_start[row + x0];
-              len = cell_start[row + x1 + 1] - lo;
-            }
-          }
-        }
-      }
-      unsigned long long bkey = kEmptyKey;
-      unsigned int bpos = 0u;
-      // phase A: every lane walks the first 16 entries of ITS OWN row, four reads in flight per round (64 rows at once:
-      // the rows of an uncertified point are short -- it sits where the target is sparse, or away from it)
-      {
-        const unsigned int rowb = (unsigned int)lo << 4;
-        const int n_a = min(len, 16), last = len - 1;
-        for (int k = 0; __ballot(k < n_a); k += 4) {
-          if (k < n_a) {
-            const unsigned int f0 = rowb + ((unsigned int)k << 4), f1 = rowb + ((unsigned int)min(k + 1, last) << 4),
-                               f2 = rowb + ((unsigned int)min(k + 2, last) << 4), f3 = rowb + ((unsigned int)min(k + 3, last) << 4);
-            const float4 q0 = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)f0);
-            const float4 q1 = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)f1);
-            const float4 q2 = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)f2);
-            const float4 q3 = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)f3);
-            const unsigned long long k0q = ((unsigned long long)__float_as_uint(dist2(q0.x, q0.y, q0.z, px, py, pz)) << 32) | __float_as_uint(q0.w);
-            const unsigned long long k1q = ((unsigned long long)__float_as_uint(dist2(q1.x, q1.y, q1.z, px, py, pz)) << 32) | __float_as_uint(q1.w);
-            const unsigned long long k2q = ((unsigned long long)__float_as_uint(dist2(q2.x, q2.y, q2.z, px, py, pz)) << 32) | __float_as_uint(q2.w);
-            const unsigned long long k3q = ((unsigned long long)__float_as_uint(dist2(q3.x, q3.y, q3.z, px, py, pz)) << 32) | __float_as_uint(q3.w);
-            if (k0q < bkey) { bkey = k0q; bpos = f0; }
-            if (k1q < bkey) { bkey = k1q; bpos = f1; }
-            if (k2q < bkey) { bkey = k2q; bpos = f2; }
-            if (k3q < bkey) { bkey = k3q; bpos = f3; }
-          }
-        }
-      }
-      // phase B: what is left of the rows longer than that, one row after the other, the 16 lanes of the group side by
-      // side (a group that has run out of rows re-reads sorted[0] meanwhile: harmless)
-      unsigned int m16 = (unsigned int)(__ballot(len > 16) >> grp_base) & 0xFFFFu;
-      while (__ballot(m16 != 0u)) {
-        const bool has = m16 != 0u;
-        const int rsel = grp_base + (has ? __ffs(m16) - 1 : 0);
-        m16 &= m16 - 1u;
-        const int rlo = has ? lane_get_i(lo, rsel) + 16 : 0, rlen = has ? lane_get_i(len, rsel) - 16 : 1;
-        const int len_max = max(max(__builtin_amdgcn_readlane(rlen, 0), __builtin_amdgcn_readlane(rlen, 16)),
-                                max(__builtin_amdgcn_readlane(rlen, 32), __builtin_amdgcn_readlane(rlen, 48)));
-        for (int k = 0; k < len_max; k += 32) {
-          const unsigned int fa = (unsigned int)(rlo + min(sub + k, rlen - 1)) << 4, fb = (unsigned int)(rlo + min(sub + k + 16, rlen - 1)) << 4;
-          const float4 qa = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)fa);
-          const float4 qb = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)fb);
-          const unsigned long long ka = ((unsigned long long)__float_as_uint(dist2(qa.x, qa.y, qa.z, px, py, pz)) << 32) | __float_as_uint(qa.w);
-          const unsigned long long kb = ((unsigned long long)__float_as_uint(dist2(qb.x, qb.y, qb.z, px, py, pz)) << 32) | __float_as_uint(qb.w);
-          if (ka < bkey) { bkey = ka; bpos = fa; }
-          if (kb < bkey) { bkey = kb; bpos = fb; }
-        }
-      }
-      // merge inside the group, then against the seed
-      const unsigned int dbits = (unsigned int)(bkey >> 32), idx = (unsigned int)bkey;
-      const unsigned int dmin = row16_min_u32(dbits);
-      const unsigned int imin = row16_min_u32(dbits == dmin ? idx : 0xFFFFFFFFu);
-      const unsigned long long win = __ballot(dbits == dmin && idx == imin);
-      const int owner = grp_base + __ffs((unsigned int)(win >> grp_base) & 0xFFFFu) - 1;
-      const unsigned long long wkey = ((unsigned long long)dmin << 32) | imin;
-      const unsigned int wpos = (unsigned int)lane_get_i((int)bpos, owner);
-      if (act && wkey < gkey) {  // (a seed met again under its real index loses the tie to it)
-        const float4 w = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)wpos);
-        gkey = wkey;
-        qx = w.x;
-        qy = w.y;
-        qz = w.z;
-      }
-      found = act && __uint_as_float((unsigned int)(gkey >> 32)) <= cert2_sq;
-    }
-
-    // still not certified: the wave-wide cube search, one point at a time, from the first radius that can still help
-    unsigned long long need = __ballot(act && !found && sub == 0);
+    // not certified by the octant: the wave-wide cube search, one point at a time
+    unsigned long long need = (use_prev & 2) ? 0ull : __ballot(fin && !found && sub == 0);  // bit 1: timing experiments only (the cube search is skipped: wrong results)
     while (need) {
       const int gl = __ffsll((long long)need) - 1, sl = __builtin_amdgcn_readlane(ql, gl);
       need &= need - 1;
-      const float vx = readlane_f(lpx, sl), vy = readlane_f(lpy, sl), vz = readlane_f(lpz, sl);
+      const float ux = readlane_f(lpx, sl), uy = readlane_f(lpy, sl), uz = readlane_f(lpz, sl);
       const int cx = __builtin_amdgcn_readlane(lcx, sl), cy = __builtin_amdgcn_readlane(lcy, sl),
                 cz = __builtin_amdgcn_readlane(lcz, sl);
+      // the octant's winner (if any) seeds the search: it bounds the ball the cubes have to cover ...
       LaneBest c{((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(gkey >> 32), gl) << 32) |
                      (unsigned int)__builtin_amdgcn_readlane((int)gkey, gl),
                  readlane_f(qx, gl), readlane_f(qy, gl), readlane_f(qz, gl)};
-      const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, vx, vy, vz, cx, cy, cz, lane, c, s2_rows > 0 ? 2 : 1);
+      // ... unless last sweep's neighbour is closer (it may lie outside the octant).  It enters with the highest index:
+      // the cubes meet the point itself again, same distance bits, and its real index wins the tie.
+      const float pb = readlane_f(lbound, sl);
+      if (pb < __builtin_inff() && !(__uint_as_float((unsigned int)(c.key >> 32)) <= pb)) {
+        const float4 pq = prev_nn[k0 + (sl >> 2) * stride];  // not yet overwritten: this point's pass is this one
+        c.key = ((unsigned long long)__float_as_uint(pb) << 32) | 0xFFFFFFFFull;
+        c.qx = pq.x;
+        c.qy = pq.y;
+        c.qz = pq.z;
+      }
+      // First cube radius.  With a previous neighbour the seed's distance D is (nearly) the neighbour's own, and the first
+      // cube that can certify anything is the one of radius ceil(D / (63/64 h)): the smaller ones would only be walked to
+      // be found insufficient (ball pruning makes the larger one cost what the ball holds) -- measured at 200k x 200k,
+      // sweeps 2..10 of an alignment: 637 -> 559 us.  In the first sweep of an alignment the seed is the octant's winner,
+      // often far from the neighbour (its ball holds several times the candidates): there the radii grow from 1 (start
+      // at the seed's radius: 175 -> 221 us).
+      int rho_first = 1;
+      if ((cube_start & 2) || ((cube_start & 1) && (use_prev & 1))) {
+        const float seed = __uint_as_float((unsigned int)(c.key >> 32));  // NaN: no seed
+        if (seed < __builtin_inff())
+          rho_first = max(1, min((int)ceilf(__builtin_amdgcn_sqrtf(seed) * g.inv_h * (1.0f / kGridSafety)), g.r_max));
+      }
+      const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, ux, uy, uz, cx, cy, cz, lane, c, rho_first);
       if (grp_base == gl) {
         gkey = c.key;
         qx = c.qx;
@@ -658,9 +505,29 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_quad_kernel(const float4* __restr
         found = f2;
       }
     }
-    finish_point(act, qi_src, true, found, gkey, qx, qy, qz, px, py, pz);
-  }
 
+    if (prev_nn && sub == 0 && valid) {
+      // the best point met, certified or not (beyond the gate it is still a target point, hence a bound for the next
+      // sweep -- getFitnessScore's ungated one in particular); NaN when nothing was met at all
+      const float bd = __uint_as_float((unsigned int)(gkey >> 32)), none = __builtin_nanf("");
+      prev_nn[qi_src] = (fin && bd == bd) ? make_float4(qx, qy, qz, 0.f) : make_float4(none, none, none, 0.f);
+    }
+    if constexpr (WRITE_KEYS) {
+      if (sub == 0 && valid) keys[qi_src] = found ? gkey : kEmptyKey;
+    }
+    if constexpr (LIST_UNMATCHED) {
+      if (sub == 0 && valid && !found) unmatched[atomicAdd(unmatched_count, 1)] = qi_src;
+    }
+    if constexpr (FUSE_REDUCE) {
+      const float d2 = __uint_as_float((unsigned int)(gkey >> 32));
+      if (found && d2 <= accept_thr) {
+        const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)qx : qi == 1 ? (double)qy : qi == 2 ? (double)qz : (double)d2);
+        const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
+        acc += a * c;
+        cnt += 1;
+      }
+    }
+  }
   if constexpr (FUSE_REDUCE) {
     __shared__ double wterm[WQ_WAVES * 4][16];
     __shared__ int wcnt[WQ_WAVES * 4];
@@ -737,16 +604,15 @@ static bool quad_enabled() {
   static const bool v = [] { const char* e = getenv("ICPGPU_QUAD"); return !e || atoi(e) != 0; }();  // 0: nn_wave_kernel
   return v;
 }
-// stage 2 of nn_quad_kernel takes windows of up to this many cell rows (ICPGPU_S2_ROWS; 0: every uncertified point goes to
-// the wave-wide cube search, as before stage 2 existed)
-static int stage2_rows() {
-  static const int v = [] { const char* e = getenv("ICPGPU_S2_ROWS"); return e ? atoi(e) : 64; }();
+// timing experiments only: ICPGPU_SKIP_UNCERT (uncertified points are dropped -- wrong results, the octant stage's time alone)
+static int quad_debug_bits() {
+  static const int v = getenv("ICPGPU_SKIP_UNCERT") ? 2 : 0;
   return v;
 }
-// timing experiments only: ICPGPU_SKIP_UNCERT (bit 1: uncertified points are dropped -- wrong results, the octant stage's
-// time alone), ICPGPU_CUBES_FROM_1 (bit 2: the cube search always starts at radius 1)
-static int quad_debug_bits() {
-  static const int v = (getenv("ICPGPU_SKIP_UNCERT") ? 2 : 0) | (getenv("ICPGPU_CUBES_FROM_1") ? 4 : 0);
+// ICPGPU_CUBE_START (experiments): 1 (default) = the cube search starts at the seed's radius in sweeps that have a previous
+// neighbour, 0 = always at radius 1, 3 = at the seed's radius in every sweep
+static int cube_start_mask() {
+  static const int v = [] { const char* e = getenv("ICPGPU_CUBE_START"); return e ? atoi(e) : 1; }();
   return v;
 }
 static bool use_quad(int n_s) { return quad_enabled() && n_s >= 4 * 8192; }
@@ -783,7 +649,7 @@ hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xf
     if (quad)                                                                                                           \
       hipLaunchKernelGGL((nn_quad_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
                          g, accept_thr, keys, partials, unmatched, unmatched_count, prev_nn,                    \
-                         ((prev_nn && use_prev) ? 1 : 0) | quad_debug_bits(), stage2_rows());                            \
+                         ((prev_nn && use_prev) ? 1 : 0) | quad_debug_bits(), cube_start_mask());                        \
     else                                                                                                                \
       hipLaunchKernelGGL((nn_wave_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
                          g, accept_thr, keys, partials, unmatched, unmatched_count);                                    \

@@ -198,8 +198,11 @@ __device__ __forceinline__ void octant_row(const int* __restrict__ cell_start, c
 __device__ __forceinline__ float grid_slack(const GridDesc& g) {
   return 0.03125f + (float)max(g.nx, max(g.ny, g.nz)) * (4.0f / 8388608.0f);
 }
+// v_sqrt_f32 / v_rcp_f32 (1 ulp) instead of the IEEE-exact expansions (14 and 10 instructions): these values only size
+// search regions, every one of them inflated by 3 % + slack -- an ulp cannot decide anything.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float ball_cells_sq(const GridDesc& g, float d2) {
-  const float ball = sqrtf(d2) * g.inv_h * 1.03125f + grid_slack(g);
+  const float ball = fast_sqrt(d2) * g.inv_h * 1.03125f + grid_slack(g);
   return d2 < __builtin_inff() ? ball * ball : __builtin_inff();
 }
 
@@ -221,7 +224,7 @@ __device__ __forceinline__ void octant_row_in_ball(const int* __restrict__ cell_
     const float dz = fmaxf(fmaxf((float)zz - uz, uz - (float)(zz + 1)), 0.f);
     const float rem = ball_sq - dy * dy - dz * dz;
     if (rem >= 0.f) {
-      const float w = sqrtf(rem);
+      const float w = fast_sqrt(rem);
       x0 = (int)fmaxf(floorf(ux - w), (float)x0);
       x1 = (int)fminf(floorf(ux + w), (float)x1);
       if (x0 <= x1) {
@@ -249,14 +252,13 @@ __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, co
                                            unsigned int lane, LaneBest& b, int rho_first = 1) {
   const float fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h;
   const float slack = grid_slack(g);
-  // rho_first > 1: the caller has already covered everything within rho_first - 1/2 cells (stage 2 of nn_quad_kernel)
-  for (int rho = min(rho_first, g.r_max);; rho = min(2 * rho, g.r_max)) {
+  for (int rho = rho_first;; rho = min(2 * rho, g.r_max)) {
     const int side = 2 * rho + 1, nrows = side * side;
     const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
-    const float inv_side = 1.0f / (float)side;
+    const float inv_side = __builtin_amdgcn_rcpf((float)side);  // (r + 1/2) / side is never within 1/(2 side) of an integer
     // radius of the ball in cells (+inf while nothing has been found: no pruning)
     const float best = __uint_as_float((unsigned int)(b.key >> 32));  // kEmptyKey reads as a NaN
-    const float ball = sqrtf(best) * g.inv_h * 1.03125f + slack;
+    const float ball = fast_sqrt(best) * g.inv_h * 1.03125f + slack;
     const float ball_sq = (ICPGPU_BALL_PRUNING && best < __builtin_inff()) ? ball * ball : __builtin_inff();
     for (int rb = 0; rb < nrows; rb += 64) {
       const int r = rb + (int)lane;  // lane -> one cell row of the cube; (y, z) by an exact float reciprocal
@@ -269,7 +271,7 @@ __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, co
         const float dz = fmaxf(fmaxf((float)zz - fz, fz - (float)(zz + 1)), 0.f);
         const float rem = ball_sq - dy * dy - dz * dz;
         if (rem >= 0.f) {
-          const float w = sqrtf(rem);
+          const float w = fast_sqrt(rem);
           const int xa = (int)fmaxf(floorf(fx - w), (float)x0), xb = (int)fminf(floorf(fx + w), (float)x1);
           if (xa <= xb) {
             const int row = zz * g.sz + yy * g.sy;

@@ -16,6 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #include <atomic>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -88,7 +91,7 @@ struct VoxelMap {
 
 constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
 constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
-constexpr double kDenseCellPopulation = 64.0;   // shrink the cells beyond this point-weighted population ...
+constexpr double kDenseCellPopulation = 44.0;   // shrink the cells beyond this point-weighted population (64 until round 2: a 200k scan at gate / 4 sits at 47; with cells for ~36 its alignment takes 620-645 instead of 668 us of search) ...
 constexpr double kTargetCellPopulation = 36.0;  // ... down to about this one (18 until the search was ball-pruned: 200k x 1M from identity 77 -> 65 us)
 constexpr double kSparseCellPopulation = 20.0;  // double the cells below this one (2.5 until then: 50k x 50k from identity 31 -> 27 us)
 constexpr size_t kOrderSourceMin = 100000;      // AUTO: order the source by cell from this size on (see ensure_source_order)
@@ -559,22 +562,37 @@ int resolve_sweep_timings(icpgpu_ctx* c, bool block = true) {
   return ICPGPU_OK;
 }
 
+// How long a result may take before the wait gives up (ICPGPU_WAIT_TIMEOUT_MS, default 30 s): a kernel that hangs without
+// faulting would otherwise keep the caller spinning for ever.  The context is unusable after a timeout (its stream still
+// holds the hung kernel); the caller gets ICPGPU_ERR_HIP instead of a dead thread.
+static double wait_timeout_ms() {
+  static const double v = [] { const char* e = std::getenv("ICPGPU_WAIT_TIMEOUT_MS"); const double x = e ? std::atof(e) : 0.0; return x > 0.0 ? x : 30000.0; }();
+  return v;
+}
+
+bool flags_ready(const volatile unsigned long long* flags, int n_flags, unsigned long long seq) {
+  bool all = true;
+  for (int k = 0; k < n_flags; ++k) all = all && (flags[k] == seq);
+  return all;
+}
+
 // Spin on the mailbox flags until every term of sweep `seq` has landed.  The stream is queried now and then so that a
-// faulted kernel turns into an error instead of an endless wait.
+// faulted kernel turns into an error instead of an endless wait, and the clock so that a hung one does.
 int wait_flags(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_flags, unsigned long long seq) {
+  std::chrono::steady_clock::time_point t0;
   for (unsigned spins = 1;; ++spins) {
-    bool all = true;
-    for (int k = 0; k < n_flags; ++k) all = all && (flags[k] == seq);
-    if (all) break;
+    if (flags_ready(flags, n_flags, seq)) break;
     if ((spins & 0x3FFu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {  // everything retired: the flags must be there on the next look
-        bool ok = true;
-        for (int k = 0; k < n_flags; ++k) ok = ok && (flags[k] == seq);
-        if (ok) break;
+        if (flags_ready(flags, n_flags, seq)) break;
         return fail(c, ICPGPU_ERR_HIP, "reduction finished without publishing its result");
       }
       if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", wait_timeout_ms());
     }
     if (spins > 8192u) std::this_thread::yield();  // a long (brute-force) sweep: stop monopolising the core
 #if defined(__x86_64__)
@@ -587,9 +605,20 @@ int wait_flags(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_fl
 
 int wait_sums(icpgpu_ctx* c, unsigned long long seq) { return wait_flags(c, c->h_flags, kReduceTerms, seq); }
 
-// One NN sweep + reduction with transform T; leaves the 17 sums in c->h_sums.  Waits for the result (by polling the
-// mailbox), not for the stream.
-int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
+// One NN sweep + reduction with transform T, in three steps so that one host thread can keep several contexts busy
+// (icpgpu_align_batch): sweep_issue queues the kernels, the 17 sums land in c->h_sums when flags_ready(c->h_flags, ...,
+// ticket.seq) -- the host polls the mailbox, it never waits for the stream -- and sweep_complete finishes the rare ungated
+// sweep whose grid stage left too many points for the few-queries kernel.
+struct SweepTicket {
+  unsigned long long seq = 0;
+  volatile int* few_host = nullptr;  // ungated grid search: number of points its grid stage left unmatched
+  const float4* red_src = nullptr;   // keys path: the array the keys index
+  int red_n = 0;
+  Xform T{};
+  float thr = 0.f;
+};
+
+int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, SweepTicket& tk) {
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   int rc = ensure(c, c->keys, (size_t)(n_s ? n_s : 1) * sizeof(unsigned long long));
   if (rc) return rc;
@@ -605,9 +634,9 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
   const bool timed = c->timing_every <= 1 || (c->sweep_counter++ % (unsigned)c->timing_every) == 0;
 #define EVREC(e) do { if (timed) HIP_TRY(c, hipEventRecord((e), c->stream)); } while (0)
   EVREC(ev[0]);
-  const float4* red_src = nullptr;  // keys path: the array the keys index
+  const float4* red_src = nullptr;
   int red_n = 0;
-  volatile int* few_host = nullptr;  // ungated grid search: number of points its grid stage left unmatched
+  volatile int* few_host = nullptr;
   if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
     const bool ordered = source_ordered(c);
@@ -664,19 +693,46 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
   }
   c->prof.reduce_launches += 1;
   c->prof.reduce_bytes += (use_grid && !open_range) ? 136ull * (uint64_t)grid_search_blocks(n_s) : 40ull * (uint64_t)n_s + 136;
-  rc = wait_sums(c, seq);
-  if (rc || !few_host) return rc;
+  tk.seq = seq;
+  tk.few_host = few_host;
+  tk.red_src = red_src;
+  tk.red_n = red_n;
+  tk.T = T;
+  tk.thr = thr;
+  return ICPGPU_OK;
+}
+
+bool sweep_ready(const icpgpu_ctx* c, const SweepTicket& tk) { return flags_ready(c->h_flags, kReduceTerms, tk.seq); }
+
+// after the sums of tk have arrived
+int sweep_complete(icpgpu_ctx* c, SweepTicket& tk) {
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (!tk.few_host) return ICPGPU_OK;
   // ungated search: the few-queries kernel completed the unmatched points unless there were too many for it (then the sums
   // just received miss them: tiled brute-force completion and a second reduction)
-  const int n_un = *few_host;
+  const int n_un = *tk.few_host;
   c->prof.grid_fallback_points += (uint64_t)(n_un > 0 ? n_un : 0);
   if (n_un <= kFewQueries) return ICPGPU_OK;
-  if ((rc = complete_deferred_keys(c, c->grid, red_src, red_n, c->tgt.data(), n_t, T, keys, n_un))) return rc;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  int rc = complete_deferred_keys(c, c->grid, tk.red_src, tk.red_n, c->tgt.data(), (int)c->tgt.n, tk.T, keys, n_un);
+  if (rc) return rc;
   const unsigned long long seq2 = ++c->sums_seq;
-  HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq2, c->stream));
+  HIP_TRY(c, launch_reduce(tk.red_src, tk.red_n, c->tgt.data(), keys, tk.T, tk.thr, static_cast<double*>(c->partials.ptr),
+                           c->h_sums_dev, c->h_flags_dev, seq2, c->stream));
   c->prof.reduce_launches += 1;
+  tk.few_host = nullptr;
+  tk.seq = seq2;
   return wait_sums(c, seq2);
 }
+
+int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
+  SweepTicket tk;
+  int rc = sweep_issue(c, T, thr, open_range, tk);
+  if (rc) return rc;
+  if ((rc = wait_sums(c, tk.seq))) return rc;
+  return sweep_complete(c, tk);
+}
+
 
 int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {
   const int n_s = (int)c->src.n;
@@ -756,8 +812,42 @@ void init_result(icpgpu_result* r) {
   r->fitness = NAN;
 }
 
-int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
-  const auto t_start = std::chrono::steady_clock::now();
+// A point-to-point alignment as a resumable run: begin() queues the first sweep, advance() -- called once the sweep's sums
+// have arrived -- does the host's share of an iteration (Umeyama / SVD, convergence test: icp_solver.cpp) and queues the
+// next sweep, the fitness sweep, or finishes.  icpgpu_align drives one run to the end; icpgpu_align_batch keeps several
+// contexts' runs in flight from one host thread.
+struct P2PRun {
+  enum Phase { Idle, Iterating, Fitness, Done } phase = Idle;
+  Mat4d final_T = mat4_identity();
+  ConvergenceCriteria crit{1, 0.0, 0.0, false};
+  float thr = 0.f;
+  int nr_iter = 0, state = ICPGPU_NOT_CONVERGED, want_fitness = 0;
+  bool converged = false;
+  unsigned n_corr = 0;
+  double mse = 0.0;
+  SweepTicket ticket;
+  icpgpu_result* res = nullptr;
+  float* out_xyzw = nullptr;
+  std::chrono::steady_clock::time_point t_start, t_issue;
+};
+
+int p2p_finish(icpgpu_ctx* c, P2PRun& r) {
+  const Xform Tf = to_xform(r.final_T);
+  int rc = write_output_cloud(c, Tf, r.out_xyzw);
+  if (rc) return rc;
+  if ((rc = resolve_sweep_timings(c, /*block=*/false))) return rc;
+  r.res->t_device_ms = c->call_timed ? c->dev_ms_accum * (double)c->call_sweeps / (double)c->call_timed : 0.0;
+  r.res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_start).count();
+  r.phase = P2PRun::Done;
+  return ICPGPU_OK;
+}
+
+int p2p_begin(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  r = P2PRun{};
+  r.t_start = std::chrono::steady_clock::now();
+  r.res = res;
+  r.out_xyzw = out_xyzw;
+  r.want_fitness = want_fitness;
   init_result(res);
   c->prof.aligns += 1;
   {
@@ -767,79 +857,83 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
     c->call_sweeps = c->call_timed = 0;
     c->prev.valid = false;  // every alignment starts cold
   }
-
-  Mat4d final_T = mat4_identity();
   if (guess)
-    for (int i = 0; i < 16; ++i) final_T[i] = (double)guess[i];
+    for (int i = 0; i < 16; ++i) r.final_T[i] = (double)guess[i];
 
   // pcl::Registration::setInputTarget refuses an empty target, initCompute() then fails and align() returns
   // with converged_ = false and final_transformation_ = identity.
   if (c->tgt.n == 0) {
-    c->final_T = mat4_identity();
+    r.final_T = mat4_identity();
+    c->final_T = r.final_T;
     c->have_final = true;
-    int rc = write_output_cloud(c, to_xform(c->final_T), out_xyzw);
-    if (rc) return rc;
-    res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    return ICPGPU_OK;
+    return p2p_finish(c, r);
   }
 
   const icpgpu_params& P = c->params;
-  ConvergenceCriteria crit(P.max_iterations, P.transformation_epsilon, P.euclidean_fitness_epsilon,
-                           P.force_iterations != 0);
-  const float thr = threshold_from(P.max_correspondence_distance * P.max_correspondence_distance);
-  {
-    int rc = ensure_grid(c, thr);
-    if (rc) return rc;
-    if ((rc = ensure_source_order(c, thr))) return rc;
-  }
-
-  int nr_iter = 0, state = ICPGPU_NOT_CONVERGED;
-  bool converged = false;
-  unsigned n_corr = 0;
-  double mse = 0.0;
-  for (;;) {
-    int rc = nn_and_reduce(c, to_xform(final_T), thr, false);
-    if (rc) return rc;
-    const double* sums = c->h_sums;
-    n_corr = (unsigned)sums[0];
-    Mat4d Tk;
-    if ((int)n_corr < P.min_correspondences || !solve_umeyama(sums, Tk)) {
-      state = ICPGPU_CONV_NO_CORRESPONDENCES;
-      converged = false;
-      break;
-    }
-    final_T = mat4_mul(Tk, final_T);
-    mse = sums[16] / sums[0];
-    ++nr_iter;
-    c->prof.iterations += 1;
-    if (crit.has_converged(nr_iter, Tk, mse)) {
-      converged = true;
-      state = crit.state();
-      break;
-    }
-  }
-
-  c->final_T = final_T;
-  c->have_final = true;
-  mat4_to_float(final_T, res->T);
-  res->converged = converged ? 1 : 0;
-  res->iterations = nr_iter;
-  res->convergence_state = state;
-  res->n_correspondences = n_corr;
-  res->mse_last = mse;
-
-  const Xform Tf = to_xform(final_T);
-  if (want_fitness) {
-    int rc = nn_and_reduce(c, Tf, FLT_MAX, true);
-    if (rc) return rc;
-    res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
-  }
-  int rc = write_output_cloud(c, Tf, out_xyzw);
+  r.crit = ConvergenceCriteria(P.max_iterations, P.transformation_epsilon, P.euclidean_fitness_epsilon, P.force_iterations != 0);
+  r.thr = threshold_from(P.max_correspondence_distance * P.max_correspondence_distance);
+  int rc = ensure_grid(c, r.thr);
   if (rc) return rc;
-  if ((rc = resolve_sweep_timings(c, /*block=*/false))) return rc;
-  res->t_device_ms = c->call_timed ? c->dev_ms_accum * (double)c->call_sweeps / (double)c->call_timed : 0.0;
-  res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-  return ICPGPU_OK;
+  if ((rc = ensure_source_order(c, r.thr))) return rc;
+  r.phase = P2PRun::Iterating;
+  r.t_issue = std::chrono::steady_clock::now();
+  return sweep_issue(c, to_xform(r.final_T), r.thr, false, r.ticket);
+}
+
+// precondition: sweep_ready(c, r.ticket)
+int p2p_advance(icpgpu_ctx* c, P2PRun& r) {
+  int rc = sweep_complete(c, r.ticket);
+  if (rc) return rc;
+  const double* sums = c->h_sums;
+  if (r.phase == P2PRun::Fitness) {
+    r.res->fitness = sums[0] > 0.0 ? sums[16] / sums[0] : DBL_MAX;
+    return p2p_finish(c, r);
+  }
+  const icpgpu_params& P = c->params;
+  bool stop = false;
+  r.n_corr = (unsigned)sums[0];
+  Mat4d Tk;
+  if ((int)r.n_corr < P.min_correspondences || !solve_umeyama(sums, Tk)) {
+    r.state = ICPGPU_CONV_NO_CORRESPONDENCES;
+    r.converged = false;
+    stop = true;
+  } else {
+    r.final_T = mat4_mul(Tk, r.final_T);
+    r.mse = sums[16] / sums[0];
+    ++r.nr_iter;
+    c->prof.iterations += 1;
+    if (r.crit.has_converged(r.nr_iter, Tk, r.mse)) {
+      r.converged = true;
+      r.state = r.crit.state();
+      stop = true;
+    }
+  }
+  r.t_issue = std::chrono::steady_clock::now();
+  if (!stop) return sweep_issue(c, to_xform(r.final_T), r.thr, false, r.ticket);
+
+  c->final_T = r.final_T;
+  c->have_final = true;
+  mat4_to_float(r.final_T, r.res->T);
+  r.res->converged = r.converged ? 1 : 0;
+  r.res->iterations = r.nr_iter;
+  r.res->convergence_state = r.state;
+  r.res->n_correspondences = r.n_corr;
+  r.res->mse_last = r.mse;
+  if (r.want_fitness) {
+    r.phase = P2PRun::Fitness;
+    return sweep_issue(c, to_xform(r.final_T), FLT_MAX, true, r.ticket);
+  }
+  return p2p_finish(c, r);
+}
+
+int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  P2PRun r;
+  int rc = p2p_begin(c, r, guess, out_xyzw, want_fitness, res);
+  while (!rc && r.phase != P2PRun::Done) {
+    if ((rc = wait_sums(c, r.ticket.seq))) break;
+    rc = p2p_advance(c, r);
+  }
+  return rc;
 }
 
 // ---- GICP mode: pcl::GeneralizedIterativeClosestPoint::computeTransformation ----------------------
@@ -1433,57 +1527,187 @@ int icpgpu_fitness(icpgpu_ctx* c, double max_range, double* out) {
   return ICPGPU_OK;
 }
 
-// Independent scan pairs: a few host worker threads, each with its own sub-context (stream, scratch, grid), pull
-// pair indices from a shared counter.  While one pair waits for its per-iteration 136-byte D2H + host SVD, the
-// kernels of the others keep the GPU busy; every pair is solved exactly as icpgpu_align would solve it.
+// ---- icpgpu_align_batch: independent scan pairs ----------------------------------------------------------------------------
+// CPUs this process may use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes grant 16 of 256 CPUs).
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+#if defined(__linux__)
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[64];
+    long long period = 0;
+    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+      n = std::min(n, std::max(1, (int)(std::atoll(q) / period)));
+    std::fclose(f);
+  } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    long long quota = -1, period = 0;
+    if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+    std::fclose(g);
+    if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(h, "%lld", &period) != 1) period = 0;
+      std::fclose(h);
+    }
+    if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)(quota / period)));
+  }
+#endif
+  return n;
+}
+
+// Host threads of a batch: every one of them spins (on mailboxes, or inside a BFGS run), so there must be no more of them
+// than CPUs -- across ALL the processes of the job: one process per GPU is the deployment (LOCAL_WORLD_SIZE, set by
+// torch.distributed.run, says how many share this host's CPUs).  ICPGPU_BATCH_THREADS overrides.
+static size_t batch_threads(size_t cap) {
+  size_t t = 0;
+  if (const char* v = std::getenv("ICPGPU_BATCH_THREADS")) t = (size_t)std::max(0, std::atoi(v));
+  else if (const char* w = std::getenv("ICPGPU_BATCH_WORKERS")) t = (size_t)std::max(0, std::atoi(w));  // round-1 name
+  if (t == 0) {
+    int local = 1;
+    if (const char* l = std::getenv("LOCAL_WORLD_SIZE")) local = std::max(1, std::atoi(l));
+    t = (size_t)std::max(1, usable_cpus() / local);
+    t = std::min(t, cap);
+  }
+  return std::max<size_t>(1, t);
+}
+
+// Point-to-point ICP: T host threads, each driving K worker contexts (own stream, scratch, grid, mailbox) ROUND-ROBIN --
+// it polls the mailboxes of its contexts and does the host's share of an iteration (3x3 SVD, convergence test, next launch)
+// for whichever has answered, so the kernels of K alignments are in flight per thread and nobody blocks on one result.
+// T x K = 8 alignments in flight (a 50k-point sweep fills less than half of the chip), T from the CPUs this process may
+// use: 4 x 2 on an unshared 16-CPU box, 2 x 4 when eight ranks share it.  GICP: one alignment per thread (its BFGS loop is
+// a blocking host loop), T threads.  Every pair is solved exactly as icpgpu_align would solve it.
 int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src,
                        const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
   ENTER(c);
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   if (n_pairs == 0) return ICPGPU_OK;
-  size_t n_workers = 8;
-  if (const char* v = std::getenv("ICPGPU_BATCH_WORKERS")) n_workers = (size_t)std::max(1, std::atoi(v));
-  n_workers = std::min(n_workers, n_pairs);
-  while (c->workers.size() < n_workers) {
+  const bool gicp = c->params.method == ICPGPU_GICP;
+  size_t n_threads = batch_threads(gicp ? 8 : 4), depth = 1;
+  if (!gicp) {
+    if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
+    else depth = std::max<size_t>(2, (8 + n_threads - 1) / n_threads);
+  }
+  n_threads = std::min(n_threads, n_pairs);
+  depth = std::min(depth, (n_pairs + n_threads - 1) / n_threads);
+  const size_t n_ctx = n_threads * depth;
+  while (c->workers.size() < n_ctx) {
     icpgpu_ctx* w = nullptr;
     const int rc = icpgpu_create(&w, c->device);
     if (rc != ICPGPU_OK) return fail(c, rc, "align_batch: worker context: %s", icpgpu_last_error(nullptr));
     c->workers.push_back(w);
   }
   std::atomic<size_t> next{0};
-  std::atomic<int> first_error{ICPGPU_OK};
-  auto work = [&](icpgpu_ctx* w) {
-    if (hipSetDevice(w->device) != hipSuccess) {
-      first_error = ICPGPU_ERR_HIP;
+  std::atomic<bool> abort{false};
+  struct ThreadError {  // one slot per host thread: nothing shared is written while the threads run
+    int code = ICPGPU_OK;
+    size_t pair = 0;
+    std::string msg;
+  };
+  std::vector<ThreadError> errors(n_threads);
+  auto load_pair = [&](icpgpu_ctx* w, size_t k) {
+    w->src_version++;
+    int rc = set_cloud_host(w, w->src, src[k], n_src[k]);
+    w->tgt_version++;
+    if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k]);
+    return rc;
+  };
+  auto work = [&](size_t t) {
+    ThreadError& err = errors[t];
+    auto failed = [&](int rc, size_t k, icpgpu_ctx* w) {
+      err.code = rc;
+      err.pair = k;
+      err.msg = w->err;
+      abort.store(true);
+    };
+    if (hipSetDevice(c->device) != hipSuccess) {
+      err.code = ICPGPU_ERR_HIP;
+      err.msg = "hipSetDevice failed in a batch thread";
+      abort.store(true);
       return;
     }
-    w->params = c->params;
-    w->nn_variant = c->nn_variant;
-    // Every worker's BFGS runs keep up to 64 workgroups resident and a host thread spinning.  8 workers fit the chip (and
-    // the box's cores) with room for everybody's searches; 16 were measured 5x SLOWER than single launches (servers wait
-    // for slots other servers hold until their 50 ms patience runs out).
-    w->gicp_server_allowed = n_workers <= kMaxServerWorkers;
-    for (;;) {
-      const size_t k = next.fetch_add(1);
-      if (k >= n_pairs || first_error.load() != ICPGPU_OK) return;
-      w->src_version++;
-      int rc = set_cloud_host(w, w->src, src[k], n_src[k]);
-      w->tgt_version++;
-      if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k]);
-      if (!rc) rc = w->params.method == ICPGPU_GICP ? align_gicp(w, nullptr, nullptr, want_fitness, &results[k])
-                                                     : align_p2p(w, nullptr, nullptr, want_fitness, &results[k]);
-      if (rc) {
-        int expected = ICPGPU_OK;
-        if (first_error.compare_exchange_strong(expected, rc)) c->err = "align_batch pair " + std::to_string(k) + ": " + w->err;
-        return;
+    icpgpu_ctx* const* ws = &c->workers[t * depth];
+    for (size_t s = 0; s < depth; ++s) {
+      ws[s]->params = c->params;
+      ws[s]->nn_variant = c->nn_variant;
+      // Every GICP worker's BFGS runs keep up to 64 workgroups resident and a host thread spinning.  8 workers fit the chip
+      // with room for everybody's searches; 16 were measured 5x SLOWER than single launches (servers wait for slots other
+      // servers hold until their 50 ms patience runs out).
+      ws[s]->gicp_server_allowed = n_threads <= kMaxServerWorkers;
+    }
+    if (gicp) {  // one blocking alignment after the other
+      icpgpu_ctx* w = ws[0];
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= n_pairs || abort.load()) return;
+        int rc = load_pair(w, k);
+        if (!rc) rc = align_gicp(w, nullptr, nullptr, want_fitness, &results[k]);
+        if (rc) return failed(rc, k, w);
       }
+    }
+    std::vector<P2PRun> runs(depth);
+    std::vector<size_t> pair_of(depth, 0);
+    bool exhausted = false;
+    const double timeout_ms = wait_timeout_ms();
+    for (unsigned idle_spins = 0;;) {
+      bool progressed = false;
+      size_t in_flight = 0;
+      for (size_t s = 0; s < depth; ++s) {
+        P2PRun& r = runs[s];
+        icpgpu_ctx* w = ws[s];
+        if (r.phase == P2PRun::Idle || r.phase == P2PRun::Done) {
+          if (exhausted || abort.load()) continue;
+          const size_t k = next.fetch_add(1);
+          if (k >= n_pairs) {
+            exhausted = true;
+            continue;
+          }
+          pair_of[s] = k;
+          int rc = load_pair(w, k);
+          if (!rc) rc = p2p_begin(w, r, nullptr, nullptr, want_fitness, &results[k]);
+          if (rc) return failed(rc, k, w);
+          progressed = true;
+          if (r.phase != P2PRun::Done) ++in_flight;
+        } else if (sweep_ready(w, r.ticket)) {
+          const int rc = p2p_advance(w, r);
+          if (rc) return failed(rc, pair_of[s], w);
+          progressed = true;
+          if (r.phase != P2PRun::Done) ++in_flight;
+        } else {
+          ++in_flight;
+        }
+      }
+      if (in_flight == 0 && (exhausted || abort.load())) return;
+      if (progressed) {
+        idle_spins = 0;
+        continue;
+      }
+      if ((++idle_spins & 0x3FFu) == 0) {  // nothing moved for a while: a faulted or hung kernel must not keep us here
+        const auto now = std::chrono::steady_clock::now();
+        for (size_t s = 0; s < depth; ++s) {
+          P2PRun& r = runs[s];
+          if (r.phase != P2PRun::Iterating && r.phase != P2PRun::Fitness) continue;
+          const hipError_t q = hipStreamQuery(ws[s]->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) {
+            fail(ws[s], ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+            return failed(ICPGPU_ERR_HIP, pair_of[s], ws[s]);
+          }
+          if (std::chrono::duration<double, std::milli>(now - r.t_issue).count() > timeout_ms) {
+            fail(ws[s], ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", timeout_ms);
+            return failed(ICPGPU_ERR_HIP, pair_of[s], ws[s]);
+          }
+        }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
     }
   };
   std::vector<std::thread> threads;
-  for (size_t i = 1; i < n_workers; ++i) threads.emplace_back(work, c->workers[i]);
-  work(c->workers[0]);
+  for (size_t t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+  work(0);
   for (auto& th : threads) th.join();
-  for (size_t i = 0; i < n_workers; ++i) {  // fold the workers' kernel accounting into the parent's profile
+  for (size_t i = 0; i < n_ctx; ++i) {  // fold the workers' kernel accounting into the parent's profile
     icpgpu_profile& p = c->workers[i]->prof;
     c->prof.nn_launches += p.nn_launches; c->prof.nn_ms += p.nn_ms; c->prof.nn_pairs += p.nn_pairs; c->prof.nn_bytes += p.nn_bytes;
     c->prof.reduce_launches += p.reduce_launches; c->prof.reduce_ms += p.reduce_ms; c->prof.reduce_bytes += p.reduce_bytes;
@@ -1497,7 +1721,12 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;
     std::memset(&p, 0, sizeof(p));
   }
-  return first_error.load();
+  for (const ThreadError& e : errors)  // the first failure in thread order (each thread stops at its first)
+    if (e.code != ICPGPU_OK) {
+      c->err = "align_batch pair " + std::to_string(e.pair) + ": " + e.msg;
+      return e.code;
+    }
+  return ICPGPU_OK;
 }
 
 int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {

@@ -27,6 +27,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(d["value"] - 1e3 * d["config"]["iters_per_step"] / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert d["scan_pairs_per_sec_e2e"] > 0 and d["gicp"]["scan_pairs_per_sec_e2e"] > 0   # the odometer's per-scan protocol
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
@@ -51,3 +52,37 @@ def test_bench_two_ranks_through_torchrun():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
     # whole-job aggregate: both ranks' iterations over the slowest rank's time
     assert abs(d["value"] - 2 * 1e3 * d["config"]["iters_per_step"] / d["ms_per_step"]) <= 1e-6 * d["value"]
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it must become two ranks by itself (it re-executes under
+    torch.distributed.run on 127.0.0.1) and say so in the JSON line; gloo so that both ranks can share this box's GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ICPGPU_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "50kx50k"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["scaling"] == "weak"
+    assert d["iterations_timed"] == 2 * 3 * 10
+
+
+def test_bench_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_bench_batch50k_workload_small():
+    """BASELINE config 4's shape (independent 50k pairs through icpgpu_align_batch + the record gather), 6 pairs per rank."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--workload", "batch50k", "--pairs-per-rank", "6", "--cpu-seconds", "1"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["metric"] == "icp_iterations_per_sec" and "batch50k" in d["config"]["workload"]
+    assert d["scan_pairs_per_sec"] > 0 and abs(d["scan_pairs_per_sec"] - 6 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["scan_pairs_per_sec"]
+    assert d["cpu_baseline"]["pairs_per_sec"] > 0

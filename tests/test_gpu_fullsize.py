@@ -119,3 +119,58 @@ def test_config2_50k_30_iterations(ctx):
     r = ctx.align()
     assert r["iterations"] == ref["iterations"] == 30 and r["n_corr"] == ref["n_corr"]
     assert _close(r["T"], ref["T"])
+
+
+# ---- the HIP path against the oracle's PCL-float / FLANN-ordered flavour at every BASELINE size -------------------------
+# PCL's IterativeClosestPoint accumulates the Umeyama sums, the solve and the transform chain in float32, transforms a
+# working copy in place by each incremental T_k, and FLANN measures (dx*dx + dy*dy) + dz*dz without an FMA; the contract of
+# DESIGN.md section 3 fixes float64 sums, the accumulated transform applied to the original cloud and an FMA distance.  These
+# are the choices a PCL / compiler version could flip: the GPU result must stay within the BASELINE tolerance of the oracle
+# run with ALL of them flipped to PCL's side (precision = PCL_F32, arith = FLANN), at the sizes BASELINE.json names.
+def _pcl_flavour(**kw):
+    return oracle.default_params(precision=oracle.PREC_PCL_F32, arith=oracle.ARITH_FLANN, **kw)
+
+
+def _assert_close_to_pcl_flavour(r, ref, what):
+    dR = float(np.abs(r["T"][:3, :3].astype(np.float64) - ref["T"][:3, :3]).max())
+    dt = float(np.linalg.norm(r["T"][:3, 3].astype(np.float64) - ref["T"][:3, 3]))
+    print(f"{what}: GPU vs PCL-float/FLANN flavour dR {dR:.2e} dt {dt:.2e} m, iterations {r['iterations']} / {ref['iterations']}, "
+          f"n_corr {r['n_corr']} / {ref['n_corr']}")
+    assert dR <= R_TOL and dt <= T_TOL, (what, dR, dt)
+    assert abs(r["n_corr"] - ref["n_corr"]) <= 1e-3 * max(1, ref["n_corr"])
+
+
+def test_pcl_flavour_config1_5k(ctx):
+    src, tgt, _ = synth.make_pair(5000, 5000, seed=1)
+    ref = oracle.icp_align(src, tgt, _pcl_flavour(max_iterations=10))
+    ctx.set_params(ctx.default_params(), max_iterations=10)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    _assert_close_to_pcl_flavour(ctx.align(), ref, "config 1, 5k x 5k")
+
+
+def test_pcl_flavour_config2_50k_30_iterations(ctx):
+    src, tgt, _ = synth.make_pair(50000, 50000, seed=2)
+    ref = oracle.icp_align(src, tgt, _pcl_flavour(max_iterations=30, force_iterations=1, transformation_epsilon=0.0))
+    ctx.set_params(ctx.default_params(), max_iterations=30, force_iterations=1, transformation_epsilon=0.0)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    _assert_close_to_pcl_flavour(ctx.align(), ref, "config 2, 50k x 50k x 30")
+
+
+def test_pcl_flavour_headline_200k(ctx, pair200k):
+    src, tgt, _ = pair200k
+    ref = oracle.icp_align(src, tgt, _pcl_flavour(max_iterations=10))
+    ctx.set_params(ctx.default_params(), max_iterations=10)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    _assert_close_to_pcl_flavour(ctx.align(), ref, "headline, 200k x 200k")
+
+
+def test_pcl_flavour_config3_200k_vs_1m(ctx, scan_vs_submap):
+    src, tgt, _ = scan_vs_submap
+    ref = oracle.icp_align(src, tgt, _pcl_flavour(max_iterations=30))
+    ctx.set_params(ctx.default_params(), max_iterations=30)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    _assert_close_to_pcl_flavour(ctx.align(), ref, "config 3, 200k x 1M")

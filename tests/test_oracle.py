@@ -126,6 +126,20 @@ def test_c_oracle_matches_numpy_restatement(seed, n):
         assert abs(a["fitness"] - b["fitness"]) <= 1e-6 * max(1.0, b["fitness"])
 
 
+def test_c_oracle_matches_numpy_restatement_50k():
+    """The same at BASELINE config 2's size (50k x 50k); and the PCL-float / FLANN-ordered flavour of the C oracle stays
+    within the BASELINE tolerance of the contract there too."""
+    src, tgt, _ = synth.make_pair(50000, 50000, seed=2)
+    a = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=10), want_fitness=True, want_trace=True)
+    b = onp.icp_align(src, tgt, max_iterations=10, want_fitness=True)
+    assert a["iterations"] == b["iterations"] and a["state"] == b["state"] and a["n_corr"] == b["n_corr"]
+    assert dR(a["T"], b["T"]) <= 1e-6 and dt(a["T"], b["T"]) <= 1e-6
+    assert [t["n_corr"] for t in a["trace"]] == [t["n_corr"] for t in b["trace"]]
+    assert abs(a["fitness"] - b["fitness"]) <= 1e-6 * max(1.0, b["fitness"])
+    c = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=10, precision=oracle.PREC_PCL_F32, arith=oracle.ARITH_FLANN))
+    assert dR(a["T"], c["T"]) <= 1e-4 and dt(a["T"], c["T"]) <= 1e-3
+
+
 def test_known_answer_recovers_ground_truth():
     src, tgt, T_gt = synth.make_known_answer_pair(5000, seed=21)
     r = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=50))
