@@ -60,7 +60,7 @@ EXPORTS = [
     "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
     "icpgpu_posegraph_get_keyframe", "icpgpu_posegraph_get_edge", "icpgpu_posegraph_write_g2o",
     "icpgpu_map_reset", "icpgpu_map_add_points", "icpgpu_map_add_source", "icpgpu_map_size", "icpgpu_map_get_points",
-    "icpgpu_map_nn_target",
+    "icpgpu_map_nn_target", "icpgpu_count_candidates", "icpgpu_count_candidates_read",
 ]
 
 _lib = None
@@ -139,6 +139,8 @@ def load():
     L.icpgpu_profile_set_sampling.argtypes = [vp, C.c_int]
     L.icpgpu_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.icpgpu_synchronize.argtypes = [vp]
+    L.icpgpu_count_candidates.argtypes = [vp, C.c_int]
+    L.icpgpu_count_candidates_read.argtypes = [vp, C.POINTER(C.c_uint64)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name in ("icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes"):

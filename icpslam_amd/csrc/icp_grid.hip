@@ -352,9 +352,13 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                            unsigned long long* __restrict__ keys,
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
                                                            int* __restrict__ unmatched_count, float4* __restrict__ prev_nn,
-                                                           int use_prev, int cube_start) {
+                                                           int use_prev, int cube_start,
+                                                           unsigned long long* __restrict__ count_candidates) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp_base = lane & 48, sub = lane & 15;
+  // counting runs (bench.py's useful-flop figure, ICPGPU_COUNT_CANDIDATES): target points this wave evaluates, octant lists
+  // + cube rows, without the padding re-reads.  nullptr otherwise: the additions below are scalar and skipped.
+  unsigned int n_cand = 0;
   const int lb = xcd_map ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int k0 = lb * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
 
@@ -430,6 +434,9 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     const unsigned int lastb = (unsigned int)max(L - 1, 0) << 4;
     const int l_max = max(max(__builtin_amdgcn_readlane(L, 0), __builtin_amdgcn_readlane(L, 16)),
                           max(__builtin_amdgcn_readlane(L, 32), __builtin_amdgcn_readlane(L, 48)));
+    if (count_candidates)
+      n_cand += (unsigned int)(__builtin_amdgcn_readlane(L, 0) + __builtin_amdgcn_readlane(L, 16) + __builtin_amdgcn_readlane(L, 32) +
+                               __builtin_amdgcn_readlane(L, 48));
     // per lane: the best (d2, original index) key and where that entry sits (its coordinates are fetched once, after the merge)
     unsigned long long bkey = kEmptyKey;
     unsigned int bpos = 0u;
@@ -488,15 +495,17 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
       // cube that can certify anything is the one of radius ceil(D / (63/64 h)): the smaller ones would only be walked to
       // be found insufficient (ball pruning makes the larger one cost what the ball holds) -- measured at 200k x 200k,
       // sweeps 2..10 of an alignment: 637 -> 559 us.  In the first sweep of an alignment the seed is the octant's winner,
-      // often far from the neighbour (its ball holds several times the candidates): there the radii grow from 1 (start
-      // at the seed's radius: 175 -> 221 us).
+      // often far from the neighbour (its ball holds several times the candidates; starting at its radius: 175 -> 221 us):
+      // there the start is capped (cube_start >> 8: 1 = the radii grow from 1 as before).
       int rho_first = 1;
-      if ((cube_start & 2) || ((cube_start & 1) && (use_prev & 1))) {
+      {
         const float seed = __uint_as_float((unsigned int)(c.key >> 32));  // NaN: no seed
-        if (seed < __builtin_inff())
-          rho_first = max(1, min((int)ceilf(__builtin_amdgcn_sqrtf(seed) * g.inv_h * (1.0f / kGridSafety)), g.r_max));
+        const int cap = (use_prev & 1) ? ((cube_start & 1) ? g.r_max : 1) : min((cube_start >> 8) & 0xFF, g.r_max);
+        if (seed < __builtin_inff() && cap > 1)
+          rho_first = max(1, min((int)ceilf(__builtin_amdgcn_sqrtf(seed) * g.inv_h * (1.0f / kGridSafety)), cap));
       }
-      const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, ux, uy, uz, cx, cy, cz, lane, c, rho_first);
+      const bool f2 = grow_cubes<PACK_SHORT_ROWS>(sorted, cell_start, g, ux, uy, uz, cx, cy, cz, lane, c, rho_first,
+                                                  count_candidates ? &n_cand : nullptr);
       if (grp_base == gl) {
         gkey = c.key;
         qx = c.qx;
@@ -521,13 +530,16 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
     if constexpr (FUSE_REDUCE) {
       const float d2 = __uint_as_float((unsigned int)(gkey >> 32));
       if (found && d2 <= accept_thr) {
-        const double a = qi < 0 ? 1.0 : (qi == 0 ? (double)qx : qi == 1 ? (double)qy : qi == 2 ? (double)qz : (double)d2);
-        const double c = pi < 0 ? 1.0 : (pi == 0 ? (double)px : pi == 1 ? (double)py : (double)pz);
-        acc += a * c;
+        // the lane's two factors are picked as FLOATS (selects on loop-invariant lane masks), then widened: the double-
+        // precision ternaries compiled into a ladder of divergent branches (~40 instructions per pass)
+        const float af = qi == 0 ? qx : qi == 1 ? qy : qi == 2 ? qz : qi == 3 ? d2 : 1.0f;
+        const float cf = pi == 0 ? px : pi == 1 ? py : pi == 2 ? pz : 1.0f;
+        acc += (double)af * (double)cf;
         cnt += 1;
       }
     }
   }
+  if (count_candidates && lane == 0) atomicAdd(count_candidates, (unsigned long long)n_cand);
   if constexpr (FUSE_REDUCE) {
     __shared__ double wterm[WQ_WAVES * 4][16];
     __shared__ int wcnt[WQ_WAVES * 4];
@@ -604,15 +616,22 @@ static bool quad_enabled() {
   static const bool v = [] { const char* e = getenv("ICPGPU_QUAD"); return !e || atoi(e) != 0; }();  // 0: nn_wave_kernel
   return v;
 }
+// counting runs: a device counter every nn_quad_kernel launch adds its evaluated target points to (grid_count_candidates)
+static unsigned long long* g_count_candidates = nullptr;
 // timing experiments only: ICPGPU_SKIP_UNCERT (uncertified points are dropped -- wrong results, the octant stage's time alone)
 static int quad_debug_bits() {
   static const int v = getenv("ICPGPU_SKIP_UNCERT") ? 2 : 0;
   return v;
 }
-// ICPGPU_CUBE_START (experiments): 1 (default) = the cube search starts at the seed's radius in sweeps that have a previous
-// neighbour, 0 = always at radius 1, 3 = at the seed's radius in every sweep
+// First radius of the cube search (see nn_quad_kernel).  Bit 0: sweeps with a previous neighbour start at the seed's radius
+// (ICPGPU_CUBE_START=0: at 1); bits 8..15: cap of the start radius in sweeps without one (ICPGPU_CUBE_COLD_CAP, default 1).
 static int cube_start_mask() {
-  static const int v = [] { const char* e = getenv("ICPGPU_CUBE_START"); return e ? atoi(e) : 1; }();
+  static const int v = [] {
+    const char* e = getenv("ICPGPU_CUBE_START");
+    const char* c = getenv("ICPGPU_CUBE_COLD_CAP");
+    const int warm = e ? (atoi(e) & 1) : 1, cold = c ? atoi(c) : 1;
+    return warm | ((cold < 1 ? 1 : cold > 255 ? 255 : cold) << 8);
+  }();
   return v;
 }
 static bool use_quad(int n_s) { return quad_enabled() && n_s >= 4 * 8192; }
@@ -625,6 +644,8 @@ static int queries_per_wave(int n_s) {
   if (q > WQ_MAX_QPW) q = WQ_MAX_QPW;
   return q;
 }
+
+void grid_count_candidates(unsigned long long* device_counter) { g_count_candidates = device_counter; }
 
 bool grid_search_keeps_prev(int n_s, int flags) { return use_quad(n_s) && !(flags & kGridOver4GiB); }
 
@@ -649,7 +670,7 @@ hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xf
     if (quad)                                                                                                           \
       hipLaunchKernelGGL((nn_quad_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
                          g, accept_thr, keys, partials, unmatched, unmatched_count, prev_nn,                    \
-                         ((prev_nn && use_prev) ? 1 : 0) | quad_debug_bits(), cube_start_mask());                        \
+                         ((prev_nn && use_prev) ? 1 : 0) | quad_debug_bits(), cube_start_mask(), g_count_candidates);     \
     else                                                                                                                \
       hipLaunchKernelGGL((nn_wave_kernel<K, F, U, P>), grid, block, 0, stream, src, n_s, qpw, xm, T, sorted, cell_start, \
                          g, accept_thr, keys, partials, unmatched, unmatched_count);                                    \

@@ -112,7 +112,8 @@ __device__ __forceinline__ bool merge_lanes(LaneBest& b) {
 // instead of being masked: evaluating a target point twice cannot change an exact minimum, so there is no per-lane
 // bounds test, and both loads of a step are in flight together.
 __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, int lo, int len, unsigned long long mask,
-                                           unsigned int lane, float px, float py, float pz, LaneBest& b) {
+                                           unsigned int lane, float px, float py, float pz, LaneBest& b,
+                                           unsigned int* n_cand = nullptr) {
   while (mask) {
     const int ra = __ffsll((long long)mask) - 1;
     mask &= mask - 1;
@@ -124,6 +125,7 @@ __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, in
       blo = __builtin_amdgcn_readlane(lo, rb);
       blen = __builtin_amdgcn_readlane(len, rb);
     }
+    if (n_cand) *n_cand += (unsigned int)(alen + (blo != alo || blen != 1 ? blen : 0));  // (counting runs only; wave-uniform)
     const float4* __restrict__ pa = sorted + alo;
     const float4* __restrict__ pb = sorted + blo;
     const float4 qa = pa[min(lane, (unsigned int)(alen - 1))];
@@ -142,7 +144,8 @@ __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, in
 // 200k x 200k, so it is a template switch (the mere presence of this code in the
 // kernel costs the dense case 3 %) that the host picks by the target's cell population.
 __device__ __forceinline__ void sweep_rows_packed(const float4* __restrict__ sorted, int lo, int len, unsigned long long mask,
-                                                  unsigned int lane, float px, float py, float pz, LaneBest& b) {
+                                                  unsigned int lane, float px, float py, float pz, LaneBest& b,
+                                                  unsigned int* n_cand = nullptr) {
   unsigned long long shortm = mask & __ballot(len <= 16);
   const unsigned long long longm = mask & ~shortm;
   const unsigned int seg = lane >> 4, sub = lane & 15u;
@@ -166,11 +169,12 @@ __device__ __forceinline__ void sweep_rows_packed(const float4* __restrict__ sor
               lo2 = __builtin_amdgcn_readlane(lo, r2), lo3 = __builtin_amdgcn_readlane(lo, r3);
     const int n0 = __builtin_amdgcn_readlane(len, r0), n1 = __builtin_amdgcn_readlane(len, r1),
               n2 = __builtin_amdgcn_readlane(len, r2), n3 = __builtin_amdgcn_readlane(len, r3);
+    if (n_cand) *n_cand += (unsigned int)(n0 + (r1 != r0 ? n1 : 0) + (r2 != r0 ? n2 : 0) + (r3 != r0 ? n3 : 0));
     const int mylo = seg == 0 ? lo0 : seg == 1 ? lo1 : seg == 2 ? lo2 : lo3;
     const int mylen = seg == 0 ? n0 : seg == 1 ? n1 : seg == 2 ? n2 : n3;
     consider(sorted[mylo + (int)min(sub, (unsigned int)(mylen - 1))], px, py, pz, b);
   }
-  sweep_rows(sorted, lo, len, longm, lane, px, py, pz, b);
+  sweep_rows(sorted, lo, len, longm, lane, px, py, pz, b, n_cand);
 }
 
 // The 2x2x2 octant of cells a point leans towards: lane `sel` in 0..3 gets one of its four cell rows.  Along each axis
@@ -249,7 +253,7 @@ __device__ __forceinline__ void octant_row_in_ball(const int* __restrict__ cell_
 template <bool PACK_SHORT_ROWS>
 __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                            const GridDesc& g, float px, float py, float pz, int cx, int cy, int cz,
-                                           unsigned int lane, LaneBest& b, int rho_first = 1) {
+                                           unsigned int lane, LaneBest& b, int rho_first = 1, unsigned int* n_cand = nullptr) {
   const float fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h;
   const float slack = grid_slack(g);
   for (int rho = rho_first;; rho = min(2 * rho, g.r_max)) {
@@ -280,8 +284,8 @@ __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, co
           }
         }
       }
-      if constexpr (PACK_SHORT_ROWS) sweep_rows_packed(sorted, lo, len, __ballot(len > 0), lane, px, py, pz, b);
-      else sweep_rows(sorted, lo, len, __ballot(len > 0), lane, px, py, pz, b);
+      if constexpr (PACK_SHORT_ROWS) sweep_rows_packed(sorted, lo, len, __ballot(len > 0), lane, px, py, pz, b, n_cand);
+      else sweep_rows(sorted, lo, len, __ballot(len > 0), lane, px, py, pz, b, n_cand);
     }
     const bool any = merge_lanes(b);
     const float safe = (float)rho * g.h * kGridSafety;

@@ -104,6 +104,9 @@ hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xf
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream,
                                  float4* prev_nn = nullptr, bool use_prev = false);
 int grid_search_blocks(int n_s);
+// Counting runs only (process-wide, not thread-safe): every nn_quad_kernel launch adds the number of target points it
+// evaluates to *device_counter; nullptr switches the counting off again.
+void grid_count_candidates(unsigned long long* device_counter);
 // prev_nn (optional, n_s float4): the neighbour each point found, written by every sweep of nn_quad_kernel and, with
 // use_prev, read back by the next one as an upper bound that prunes its search (valid for ANY transform, but only against
 // the same target points and the same src array).  True when launch_nn_grid_search would use it for this size.

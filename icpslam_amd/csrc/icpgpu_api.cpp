@@ -118,7 +118,7 @@ struct icpgpu_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   icpgpu_params params{};
   Cloud src, tgt;
-  DeviceBuf keys, partials, sums, out, idx, d2;
+  DeviceBuf keys, partials, sums, out, idx, d2, cand_counter;
   GridIndex grid;            // acceleration structure over the current target
   GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
   PrevNeighbours prev;       // last sweep's neighbours (search bound of the next sweep)
@@ -1414,6 +1414,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->vox_ints);
   release(c->idx);
   release(c->d2);
+  if (c->cand_counter.ptr) grid_count_candidates(nullptr);
+  release(c->cand_counter);
   for (DeviceBuf* b : {&c->map.pts.buf, &c->map.keys, &c->map.vals, &c->map.first, &c->map.staged, &c->map.moved, &c->map.slot_of,
                        &c->map.flags, &c->map.rank, &c->map.temp, &c->map.counter, &c->map.nn_keys, &c->map.first_user,
                        &c->map.uflags, &c->map.urank, &c->map.uniq_index, &c->map.uniq.buf})
@@ -2143,6 +2145,33 @@ int icpgpu_get_stream(icpgpu_ctx* c, void** out_stream) {
 int icpgpu_synchronize(icpgpu_ctx* c) {
   ENTER(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ICPGPU_OK;
+}
+
+int icpgpu_count_candidates(icpgpu_ctx* c, int enable) {
+  ENTER(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (enable) {
+    int rc = ensure(c, c->cand_counter, sizeof(unsigned long long));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->cand_counter.ptr, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    grid_count_candidates(static_cast<unsigned long long*>(c->cand_counter.ptr));
+  } else {
+    grid_count_candidates(nullptr);
+  }
+  return ICPGPU_OK;
+}
+
+int icpgpu_count_candidates_read(icpgpu_ctx* c, uint64_t* out) {
+  ENTER(c);
+  if (!out) return fail(c, ICPGPU_ERR_INVALID_ARG, "out is null");
+  if (!c->cand_counter.ptr) return fail(c, ICPGPU_ERR_NO_INPUT, "count_candidates_read: counting was never enabled on this context");
+  unsigned long long v = 0;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(&v, c->cand_counter.ptr, sizeof(v), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemset(c->cand_counter.ptr, 0, sizeof(v)));
+  *out = (uint64_t)v;
   return ICPGPU_OK;
 }
 

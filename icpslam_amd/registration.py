@@ -255,6 +255,15 @@ class Context:
     def synchronize(self):
         self._check(self._L.icpgpu_synchronize(self._h))
 
+    def count_candidates(self, enable: bool = True):
+        """Counting runs: target points evaluated by the grid sweeps (see icpgpu_count_candidates)."""
+        self._check(self._L.icpgpu_count_candidates(self._h, int(enable)))
+
+    def candidates(self) -> int:
+        v = C.c_uint64()
+        self._check(self._L.icpgpu_count_candidates_read(self._h, C.byref(v)))
+        return int(v.value)
+
 
 def result_dict(res: Result, cloud):
     return dict(T=np.array(res.T, dtype=np.float32).reshape(4, 4).T.copy(), converged=bool(res.converged),
@@ -264,11 +273,15 @@ def result_dict(res: Result, cloud):
 
 
 class IterativeClosestPoint:
-    """pcl::IterativeClosestPoint<PointXYZ, PointXYZ>-shaped front end (same method names as the reference uses)."""
+    """pcl::IterativeClosestPoint<PointXYZ, PointXYZ>-shaped front end (same method names as the reference uses):
+    point-to-point ICP, the solver BASELINE.json's north_star specifies.  The class the reference literally instantiates
+    is GeneralizedIterativeClosestPoint below; each mirror keeps the semantics of the PCL class it is named after."""
 
     _shared_ctx: dict = {}
+    METHOD = _lib.P2P_SVD
 
-    def __init__(self, device_id: int = 0, method: int = _lib.P2P_SVD):
+    def __init__(self, device_id: int = 0, method: int | None = None):
+        method = self.METHOD if method is None else method
         # the reference builds a fresh registration object per scan (icp_odometer.cpp:188); the GPU context is
         # cached per device so that doing the same here costs nothing
         ctx = IterativeClosestPoint._shared_ctx.get(device_id)
@@ -314,7 +327,7 @@ class IterativeClosestPoint:
         self._ctx.set_source(self._source)
         self._ctx.set_target(self._target)
         self._result = self._ctx.align(guess=guess, want_cloud=True)
-        self._fitness = None
+        self._ctx._last_user = self          # objects of one device share the cached context (see getFitnessScore)
         return self._result["cloud"]
 
     def getFinalTransformation(self) -> np.ndarray:   # icp_odometer.cpp:199
@@ -326,8 +339,25 @@ class IterativeClosestPoint:
     def getFitnessScore(self, max_range: float = float(np.finfo(np.float64).max)) -> float:   # icp_odometer.cpp:201
         if self._result is None:
             raise IcpGpuError(_lib.ERR_NO_INPUT, "getFitnessScore before align")
+        if getattr(self._ctx, "_last_user", None) is not self:
+            # another registration object used the shared context since this one's align: put this object's clouds back
+            # and evaluate under ITS transform (kernel-level entry points), not under whatever the context did last
+            self._ctx.set_params(self._params)
+            self._ctx.set_source(self._source)
+            self._ctx.set_target(self._target)
+            self._ctx.nn(self._result["T"])
+            s = self._ctx.reduce(self._result["T"], 1e18 if max_range >= 1e36 else float(np.sqrt(max_range)))
+            self._ctx._last_user = None
+            return float(s[16] / s[0]) if s[0] > 0 else float(np.finfo(np.float64).max)
         return self._ctx.fitness(max_range)
 
     @property
     def result(self):
         return self._result
+
+
+class GeneralizedIterativeClosestPoint(IterativeClosestPoint):
+    """pcl::GeneralizedIterativeClosestPoint<PointXYZ, PointXYZ>-shaped front end: the class the reference instantiates at
+    icp_odometer.cpp:188 and octree_mapper.cpp:104 (plane-to-plane cost, BFGS inner solver, PCL's constructor defaults)."""
+
+    METHOD = _lib.GICP

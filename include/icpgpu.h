@@ -283,6 +283,12 @@ int icpgpu_profile_get(icpgpu_ctx* ctx, icpgpu_profile* out);
 /* stream handle (hipStream_t as void*) so a host can order its own work against the context. */
 int icpgpu_get_stream(icpgpu_ctx* ctx, void** out_stream);
 int icpgpu_synchronize(icpgpu_ctx* ctx);
+/* Counting runs (bench.py's useful-flop figure; process-wide, one context at a time): with enable != 0 every grid
+ * correspondence sweep (nn_quad_kernel) adds the number of target points it evaluates to a device counter;
+ * icpgpu_count_candidates_read waits for the stream and returns the count since it was enabled (or last read), then
+ * zeroes it.  Not for production: one atomic per wave. */
+int icpgpu_count_candidates(icpgpu_ctx* ctx, int enable);
+int icpgpu_count_candidates_read(icpgpu_ctx* ctx, uint64_t* out);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,10 @@
 // so switching it to the MI355X path is a one-type-name change:
 //
 //   - pcl::GeneralizedIterativeClosestPoint<pcl::PointXYZ, pcl::PointXYZ> icp;
-//   + icpgpu::IterativeClosestPoint<pcl::PointCloud<pcl::PointXYZ>> icp;
+//   + icpgpu::GeneralizedIterativeClosestPoint<pcl::PointCloud<pcl::PointXYZ>> icp;   // the same solver (GICP)
+//
+// icpgpu::IterativeClosestPoint<Cloud> is pcl::IterativeClosestPoint's counterpart (point-to-point, SVD): the solver
+// BASELINE.json's north_star specifies kernel by kernel.  Each class keeps the semantics of the PCL class it is named after.
 //
 // CloudT is any type with a contiguous `points` container of 16-byte {x, y, z, pad} structs, `size()` and
 // `resize()`: pcl::PointCloud<pcl::PointXYZ> qualifies (PointXYZ is 16 B, 16-byte aligned).
@@ -18,8 +21,11 @@
 #pragma once
 
 #include <cfloat>
+#include <cmath>
 #include <cstddef>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -60,34 +66,50 @@ inline Matrix4 make_matrix4(const float* colmajor) {
 
 namespace detail {
 // The reference constructs its registration object on the stack for every scan (icp_odometer.cpp:188); the device
-// context (stream, scratch, HBM buffers) is therefore cached per thread and device, not per object.
-struct CachedContext {
-  icpgpu_ctx* ctx = nullptr;
-  int device = -1;
-  ~CachedContext() {
-    if (ctx) icpgpu_destroy(ctx);
+// context (stream, scratch, HBM buffers) is therefore cached per (thread, device), not per object.  Objects hold it by
+// shared_ptr: a context lives as long as anything uses it (an OctreeMap member keeps its map alive even if the thread
+// later works on another device), and the objects of one thread on one device share it on purpose -- that is how
+// setInputTargetFromMap() finds the nn cloud OctreeMap::approxNearestNeighbors left in HBM.
+using ContextPtr = std::shared_ptr<icpgpu_ctx>;
+inline ContextPtr thread_context(int device) {
+  static thread_local std::map<int, ContextPtr> cache;
+  ContextPtr& slot = cache[device];
+  if (!slot) {
+    icpgpu_ctx* raw = nullptr;
+    const int rc = icpgpu_create(&raw, device);
+    if (rc != ICPGPU_OK)
+      throw std::runtime_error(std::string("icpgpu_create failed: ") + icpgpu_last_error(nullptr));
+    slot = ContextPtr(raw, [](icpgpu_ctx* c) { icpgpu_destroy(c); });
   }
-};
-inline icpgpu_ctx* thread_context(int device) {
-  static thread_local CachedContext cache;
-  if (cache.ctx && cache.device == device) return cache.ctx;
-  if (cache.ctx) {
-    icpgpu_destroy(cache.ctx);
-    cache.ctx = nullptr;
-  }
-  const int rc = icpgpu_create(&cache.ctx, device);
-  if (rc != ICPGPU_OK)
-    throw std::runtime_error(std::string("icpgpu_create failed: ") + icpgpu_last_error(nullptr));
-  cache.device = device;
-  return cache.ctx;
+  return slot;
 }
+// every align() through a context gets a number: a registration object knows whether it was the last to use the context
+inline unsigned long long next_generation() {
+  static thread_local unsigned long long g = 0;
+  return ++g;
+}
+inline unsigned long long& context_generation(icpgpu_ctx* c) {
+  static thread_local std::map<icpgpu_ctx*, unsigned long long> gen;
+  return gen[c];
+}
+
+// pcl::PointCloud keeps width / height / is_dense beside `points` (pcl::toROSMsg asserts width * height == size): set
+// them when the cloud type has them
+template <class C>
+auto set_cloud_shape(C& c, std::size_t n, int) -> decltype(c.width = 0, c.height = 0, c.is_dense = true, void()) {
+  c.width = static_cast<decltype(c.width)>(n);
+  c.height = 1;
+  c.is_dense = true;
+}
+template <class C>
+void set_cloud_shape(C&, std::size_t, long) {}
 }  // namespace detail
 
 template <class CloudT>
 class IterativeClosestPoint {
  public:
   explicit IterativeClosestPoint(int device = 0, icpgpu_method method = ICPGPU_P2P_SVD)
-      : ctx_(detail::thread_context(device)) {
+      : ctx_holder_(detail::thread_context(device)), ctx_(ctx_holder_.get()) {
     icpgpu_default_params(&params_);
     params_.method = method;
     std::memset(&result_, 0, sizeof(result_));
@@ -122,7 +144,19 @@ class IterativeClosestPoint {
   bool hasConverged() const { return result_.converged != 0; }                // icp_odometer.cpp:201
   double getFitnessScore(double max_range = DBL_MAX) {                        // icp_odometer.cpp:201
     double f = DBL_MAX;
-    if (!aligned_ || icpgpu_fitness(ctx_, max_range, &f) != ICPGPU_OK) return DBL_MAX;
+    if (!aligned_) return DBL_MAX;
+    // Another object of this thread may have used the shared context since (the mapper's ICP between the odometer's
+    // align and its getFitnessScore): put this object's clouds and transform back first.
+    if (detail::context_generation(ctx_) != generation_) {
+      if (target_from_map_ || !source_ || !target_ || !upload()) return DBL_MAX;
+      double sums[17];
+      std::size_t n = source_->points.size();
+      if (n == 0) return DBL_MAX;
+      // mean squared distance of the neighbours within max_range under THIS object's transform (kernel-level entry points)
+      if (fitness_sums_at(result_.T, max_range, sums) != ICPGPU_OK) return DBL_MAX;
+      return sums[0] > 0.0 ? sums[16] / sums[0] : DBL_MAX;
+    }
+    if (icpgpu_fitness(ctx_, max_range, &f) != ICPGPU_OK) return DBL_MAX;
     return f;
   }
   const icpgpu_result& getResult() const { return result_; }
@@ -132,19 +166,39 @@ class IterativeClosestPoint {
   using PointT = typename std::remove_reference<decltype(std::declval<CloudT>().points[0])>::type;
   static_assert(sizeof(PointT) == 16, "point type must be the 16-byte pcl::PointXYZ layout");
 
+  bool upload() {
+    if (icpgpu_set_params(ctx_, &params_) != ICPGPU_OK) return false;
+    const std::size_t ns = source_->points.size();
+    if (icpgpu_set_source(ctx_, ns ? reinterpret_cast<const float*>(&source_->points[0]) : nullptr, ns) != ICPGPU_OK) return false;
+    if (!target_from_map_) {
+      const std::size_t nt = target_->points.size();
+      if (icpgpu_set_target(ctx_, nt ? reinterpret_cast<const float*>(&target_->points[0]) : nullptr, nt) != ICPGPU_OK) return false;
+    }
+    return true;
+  }
+
+  // fitness through the kernel-level entry points, for a transform that is not the context's last one
+  int fitness_sums_at(const float* T, double max_range, double sums[17]) {
+    const std::size_t n = source_->points.size();
+    std::unique_ptr<int32_t[]> idx(new int32_t[n]);
+    std::unique_ptr<float[]> d2(new float[n]);
+    int rc = icpgpu_nn(ctx_, T, idx.get(), d2.get());
+    if (rc != ICPGPU_OK) return rc;
+    // PCL compares SQUARED distances with max_range; icpgpu_reduce takes the distance
+    return icpgpu_reduce(ctx_, T, max_range >= 1e36 ? 1e18 : std::sqrt(max_range), sums);
+  }
+
   void align_impl(CloudT& output, const float* guess) {
     aligned_ = false;
     result_.converged = 0;
     if (!source_ || (!target_ && !target_from_map_)) return;  // PCL: initCompute() fails, align returns, converged_ stays false
-    if (icpgpu_set_params(ctx_, &params_) != ICPGPU_OK) return;
+    if (!upload()) return;
     const std::size_t ns = source_->points.size();
-    if (icpgpu_set_source(ctx_, ns ? reinterpret_cast<const float*>(&source_->points[0]) : nullptr, ns) != ICPGPU_OK) return;
-    if (!target_from_map_) {
-      const std::size_t nt = target_->points.size();
-      if (icpgpu_set_target(ctx_, nt ? reinterpret_cast<const float*>(&target_->points[0]) : nullptr, nt) != ICPGPU_OK) return;
-    }
     output.points.resize(ns);
+    detail::set_cloud_shape(output, ns, 0);
     float* out = ns ? reinterpret_cast<float*>(&output.points[0]) : nullptr;
+    generation_ = detail::next_generation();
+    detail::context_generation(ctx_) = generation_;
     if (icpgpu_align(ctx_, guess, out, 0, &result_) != ICPGPU_OK) {
       result_.converged = 0;
       return;
@@ -152,7 +206,9 @@ class IterativeClosestPoint {
     aligned_ = true;
   }
 
+  detail::ContextPtr ctx_holder_;
   icpgpu_ctx* ctx_;
+  unsigned long long generation_ = 0;
   icpgpu_params params_;
   icpgpu_result result_;
   const CloudT* source_ = nullptr;
@@ -162,6 +218,15 @@ class IterativeClosestPoint {
   bool target_from_map_ = false;
 };
 
+// pcl::GeneralizedIterativeClosestPoint<PointXYZ, PointXYZ>'s counterpart -- the class the reference instantiates at
+// icp_odometer.cpp:188 and octree_mapper.cpp:104: same protocol, method = ICPGPU_GICP (plane-to-plane cost, BFGS inner solver,
+// PCL's constructor defaults: 20 neighbours, gicp_epsilon 1e-3, rotation_epsilon 2e-3, 20 inner iterations).
+template <class CloudT>
+class GeneralizedIterativeClosestPoint : public IterativeClosestPoint<CloudT> {
+ public:
+  explicit GeneralizedIterativeClosestPoint(int device = 0) : IterativeClosestPoint<CloudT>(device, ICPGPU_GICP) {}
+};
+
 // pcl::VoxelGrid<PointT>-shaped front end for the odometer's pre-step
 // (/root/reference/src/icpslam/icp_odometer.cpp:96-101):
 //   pcl::VoxelGrid<pcl::PointXYZ> voxel_filter;  ->  icpgpu::VoxelGrid<pcl::PointCloud<pcl::PointXYZ>> voxel_filter;
@@ -169,7 +234,7 @@ class IterativeClosestPoint {
 template <class CloudT>
 class VoxelGrid {
  public:
-  explicit VoxelGrid(int device = 0) : ctx_(detail::thread_context(device)) {}
+  explicit VoxelGrid(int device = 0) : ctx_holder_(detail::thread_context(device)), ctx_(ctx_holder_.get()) {}
   template <class CloudPtr>
   void setInputCloud(const CloudPtr& cloud) { input_ = &*cloud; }
   void setLeafSize(float lx, float ly, float lz) {
@@ -184,9 +249,11 @@ class VoxelGrid {
     const int rc = icpgpu_voxel_grid(ctx_, n ? reinterpret_cast<const float*>(&input_->points[0]) : nullptr, n, leaf_,
                                      n ? reinterpret_cast<float*>(&output.points[0]) : nullptr, &m);
     output.points.resize(rc == ICPGPU_OK ? m : 0);
+    detail::set_cloud_shape(output, output.points.size(), 0);
   }
 
  private:
+  detail::ContextPtr ctx_holder_;
   icpgpu_ctx* ctx_;
   const CloudT* input_ = nullptr;
   float leaf_ = 0.1f;
@@ -199,7 +266,8 @@ class VoxelGrid {
 template <class CloudT>
 class OctreeMap {
  public:
-  explicit OctreeMap(double resolution, int device = 0) : ctx_(detail::thread_context(device)), resolution_(resolution) { resetMap(); }
+  explicit OctreeMap(double resolution, int device = 0)
+      : ctx_holder_(detail::thread_context(device)), ctx_(ctx_holder_.get()), resolution_(resolution) { resetMap(); }
   void resetMap() { icpgpu_map_reset(ctx_, resolution_); }                                     // :55-59
   std::size_t addPointsToMap(const CloudT& cloud, const Matrix4& pose) {                         // :62-69 (+ :135, :152)
     std::size_t added = 0;
@@ -218,6 +286,8 @@ class OctreeMap {
                              &m) != ICPGPU_OK)
       m = 0;
     nearest_neighbors.points.resize(m);
+    detail::set_cloud_shape(nearest_neighbors, m, 0);
+    detail::context_generation(ctx_) = detail::next_generation();  // the context's source / target are the map's now
     return m > 0;
   }
   std::size_t size() const {
@@ -229,9 +299,11 @@ class OctreeMap {
     std::size_t n = size(), m = 0;
     out.points.resize(n);
     if (icpgpu_map_get_points(ctx_, n ? reinterpret_cast<float*>(&out.points[0]) : nullptr, n, &m) != ICPGPU_OK) out.points.resize(0);
+    detail::set_cloud_shape(out, out.points.size(), 0);
   }
 
  private:
+  detail::ContextPtr ctx_holder_;
   icpgpu_ctx* ctx_;
   double resolution_;
 };

@@ -55,6 +55,37 @@ def test_shim_matches_oracle(built, tmp_path):
     assert abs(float(vals[19]) - (c[:, 0] + 2 * c[:, 1] + 3 * c[:, 2] + c[:, 3]).sum()) <= 1e-2
 
 
+def test_gicp_shim_compiles_and_fails_loudly_without_gpu(built, tmp_path):
+    import torch
+    exe = _build_demo(tmp_path, "gicp_shim_demo")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    src, tgt, _ = synth.make_pair(100, 100, seed=1)
+    r = _run(exe, tmp_path, src, tgt, 10)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gicp_shim_matches_oracle_and_objects_do_not_disturb_each_other(built, tmp_path):
+    """icpgpu::GeneralizedIterativeClosestPoint -- the type the reference's call site swaps to (INTEGRATION.md) -- runs
+    GICP; align() leaves width = size, height = 1, is_dense on clouds that have those members; a second registration object
+    on the same thread (shared cached context) does not change what the first one's getFitnessScore() returns."""
+    exe = _build_demo(tmp_path, "gicp_shim_demo")
+    src, tgt, _ = synth.make_pair(5000, 5000, seed=1)
+    r = _run(exe, tmp_path, src, tgt, 10)
+    assert r.returncode == 0, r.stderr
+    l1, l2 = [ln.split() for ln in r.stdout.strip().splitlines()]
+    ref = oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_iterations=10), want_fitness=True)
+    T = np.array([float(v) for v in l1[3:19]]).reshape(4, 4).T
+    assert int(l1[0]) == int(ref["converged"]) and int(l1[1]) == ref["iterations"]
+    assert np.abs(T[:3, :3] - ref["T"][:3, :3]).max() <= 1e-4 and np.linalg.norm(T[:3, 3] - ref["T"][:3, 3]) <= 1e-3
+    assert abs(float(l1[2]) - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+    assert (int(l1[19]), int(l1[20]), int(l1[21])) == (src.shape[0], 1, 1)
+    assert abs(float(l2[0]) - float(l1[2])) <= 1e-9 * max(1.0, float(l1[2]))          # A's fitness, after B used the context
+    other = oracle.icp_align(tgt, src, oracle.default_params(max_iterations=3), want_fitness=True)
+    assert abs(float(l2[1]) - other["fitness"]) <= 1e-9 * max(1.0, other["fitness"])
+
+
 def _run_map(exe, tmp_path, scan0, scan1, pose, pose_inv):
     a, b = tmp_path / "s0.bin", tmp_path / "s1.bin"
     scan0.tofile(a)

@@ -239,3 +239,94 @@ def test_align_batch_matches_single_aligns(ctx):
         assert got["fitness"] == one["fitness"] or (np.isnan(got["fitness"]) and np.isnan(one["fitness"]))
     ref = oracle.icp_align(pairs[3][0], pairs[3][1], oracle.default_params(max_iterations=10))
     assert _dR(batch[3]["T"], ref["T"]) <= R_TOL and _dt(batch[3]["T"], ref["T"]) <= T_TOL
+
+
+# ---- BASELINE config 4 at its workload: icpgpu_align_batch on 50k-point pairs -------------------------------------------------
+def _oracle_many(pairs, params):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as ex:   # the oracle releases the GIL (ctypes)
+        return list(ex.map(lambda p: oracle.icp_align(p[0], p[1], params, want_fitness=True), pairs))
+
+
+@pytest.fixture(scope="module")
+def pairs50k():
+    return [synth.make_pair(50000, 50000, seed=1000 + k)[:2] for k in range(16)]   # seeds of SURVEY.md 8(d) C4
+
+
+def test_align_batch_16_pairs_of_50k_match_oracle(ctx, pairs50k):
+    """16 of config 4's 512 pairs: 50k points -> nn_quad_kernel with the previous-neighbour bound, several worker contexts in
+    flight per host thread (the round-robin scheduler of icpgpu_align_batch), against the oracle pair by pair."""
+    ctx.set_params(ctx.default_params(), max_iterations=10)
+    got = ctx.align_batch([p[0] for p in pairs50k], [p[1] for p in pairs50k], want_fitness=True)
+    ref = _oracle_many(pairs50k, oracle.default_params(max_iterations=10))
+    for g, r in zip(got, ref):
+        assert (g["converged"], g["iterations"], g["state"], g["n_corr"]) == (r["converged"], r["iterations"], r["state"], r["n_corr"])
+        assert _dR(g["T"], r["T"]) <= R_TOL and _dt(g["T"], r["T"]) <= T_TOL
+        assert abs(g["fitness"] - r["fitness"]) <= 1e-9 * max(1.0, r["fitness"])
+    # every scheduler shape gives the same bits (threads x contexts per thread: 1 x 8, 2 x 4, 8 x 1)
+    import os
+    for t, k in ((1, 8), (2, 4), (8, 1)):
+        os.environ["ICPGPU_BATCH_THREADS"], os.environ["ICPGPU_BATCH_DEPTH"] = str(t), str(k)
+        try:
+            again = ctx.align_batch([p[0] for p in pairs50k], [p[1] for p in pairs50k], want_fitness=True)
+        finally:
+            del os.environ["ICPGPU_BATCH_THREADS"], os.environ["ICPGPU_BATCH_DEPTH"]
+        for a, b in zip(again, got):
+            assert np.array_equal(a["T"], b["T"]) and a["iterations"] == b["iterations"] and a["fitness"] == b["fitness"]
+
+
+def test_align_batch_gicp_8_pairs_of_50k_match_oracle(ctx, pairs50k):
+    """The same through the solver the reference instantiates (GICP): bit-identical to the exact-sum oracle, pair by pair."""
+    from icpslam_amd import GICP
+    pairs = pairs50k[:8]
+    ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10)
+    got = ctx.align_batch([p[0] for p in pairs], [p[1] for p in pairs], want_fitness=True)
+    ref = _oracle_many(pairs, oracle.default_params(method=oracle.GICP, max_iterations=10))
+    for g, r in zip(got, ref):
+        assert (g["converged"], g["iterations"], g["n_corr"]) == (r["converged"], r["iterations"], r["n_corr"])
+        assert np.array_equal(g["T"].view(np.uint32), np.asarray(r["T"], np.float32).view(np.uint32))
+        assert abs(g["fitness"] - r["fitness"]) <= 1e-9 * max(1.0, r["fitness"])
+    ctx.set_params(ctx.default_params())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_align_campaign_slice(ctx, seed):
+    """A 10-pair slice of scripts/align_campaign.py (300 pairs in round 1): random sizes 33k-60k x 20k-80k, gates 0.3-2 m,
+    5-30 iterations; iterations, correspondences and state equal to the oracle's, transform within the BASELINE tolerance."""
+    rng = np.random.default_rng(50_000 + seed)
+    n_s, n_t = int(rng.integers(33_000, 60_000)), int(rng.integers(20_000, 80_000))
+    gate = float(rng.choice([0.3, 1.0, 2.0]))
+    iters = int(rng.choice([5, 10, 30]))
+    src, tgt, _ = synth.make_pair(n_s, n_t, seed=seed)
+    ctx.set_params(ctx.default_params(), max_iterations=iters, max_correspondence_distance=gate)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    got = ctx.align(want_fitness=True)
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=iters, max_correspondence_distance=gate), want_fitness=True)
+    assert (got["converged"], got["iterations"], got["state"], got["n_corr"]) == (ref["converged"], ref["iterations"], ref["state"], ref["n_corr"])
+    assert _dR(got["T"], ref["T"]) <= R_TOL and _dt(got["T"], ref["T"]) <= T_TOL
+    assert abs(got["fitness"] - ref["fitness"]) <= 1e-6 * max(1.0, ref["fitness"])
+    ctx.set_params(ctx.default_params())
+
+
+def test_registration_mirrors_keep_their_pcl_semantics(built):
+    """icpslam_amd.GeneralizedIterativeClosestPoint (what the reference instantiates) runs GICP, IterativeClosestPoint runs
+    point-to-point ICP, and two objects sharing the cached context do not disturb each other's getFitnessScore()."""
+    from icpslam_amd import GeneralizedIterativeClosestPoint, IterativeClosestPoint
+    curr, prev, _ = synth.make_pair(6000, 6000, seed=61)
+    a = GeneralizedIterativeClosestPoint()
+    a.setMaximumIterations(10); a.setTransformationEpsilon(1e-6); a.setMaxCorrespondenceDistance(1.0); a.setRANSACIterations(0)
+    a.setInputSource(curr); a.setInputTarget(prev)
+    a.align()
+    fit_a = a.getFitnessScore()
+    ref = oracle.icp_align(curr, prev, oracle.default_params(method=oracle.GICP, max_iterations=10), want_fitness=True)
+    assert a.hasConverged() == ref["converged"] and a.result["iterations"] == ref["iterations"]
+    assert np.array_equal(a.getFinalTransformation().view(np.uint32), np.asarray(ref["T"], np.float32).view(np.uint32))
+    assert abs(fit_a - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+    b = IterativeClosestPoint()                       # same device: the same cached context
+    b.setMaximumIterations(3); b.setInputSource(prev); b.setInputTarget(curr)
+    b.align()
+    refb = oracle.icp_align(prev, curr, oracle.default_params(max_iterations=3), want_fitness=True)
+    assert b.result["iterations"] == refb["iterations"] and _dt(b.getFinalTransformation(), refb["T"]) <= T_TOL
+    assert abs(a.getFitnessScore() - fit_a) <= 1e-9 * max(1.0, fit_a)          # still A's, after B used the context
+    assert abs(b.getFitnessScore() - refb["fitness"]) <= 1e-9 * max(1.0, refb["fitness"])

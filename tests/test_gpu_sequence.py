@@ -74,3 +74,24 @@ def test_rejected_scan_keeps_older_target(ctx):
         assert rec[2]["n_corr"] == ref["n_corr"] and np.abs(rec[2]["T"] - ref["T"]).max() <= 1e-4
     for i in range(g1.num_poses):
         np.testing.assert_allclose(g1.pose(i)[0], g2.pose(i)[0], atol=1e-9)
+
+
+def test_batched_odometry_21_scans_of_50k_match_oracle_chain(ctx):
+    """BASELINE config 5 at its scan size: 21 scans of 50k points (20 consecutive pairs) through run_odometry_batched
+    (icpgpu_align_batch, gather, host chain) and through the online loop, against the oracle's chain."""
+    scans, _ = _drive(n_scans=21, n_pts=50000, seed=8)
+    ctx.set_params(ctx.default_params())
+    g1, rec1 = sequence.run_odometry(ctx, scans)
+    g2, rec2 = sequence.run_odometry_batched(ctx, scans)
+    ref = _oracle_chain(scans)
+    assert [r["accepted"] for r in rec1] == [r["accepted"] for r in rec2] == [o[0] for o in ref]
+    for a, b in zip(rec1, rec2):
+        assert a["iterations"] == b["iterations"] and a["n_corr"] == b["n_corr"] and np.array_equal(a["T"], b["T"])
+    acc = [o for o in ref if o[0]]
+    assert g1.num_poses == g2.num_poses == len(acc) and len(acc) >= 18
+    for i, o in enumerate(acc):
+        for g in (g1, g2):
+            pos, q = g.pose(i)
+            assert np.linalg.norm(pos - o[1]) <= 1e-3 * (i + 1)
+            rq = o[2].as_quat()
+            assert min(np.abs(q - rq).max(), np.abs(q + rq).max()) <= 1e-4 * (i + 1)
