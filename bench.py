@@ -320,18 +320,21 @@ def main():
         ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1, nn_mode=nn_mode)
         ctx.set_source(src); ctx.set_target(tgt)
 
-    # the brute-force kernel (north_star's design) measured in the same process for its own roofline line
+    # the brute-force search (north_star's design) measured in the same process for its own roofline line: the matrix-core
+    # kernel (default for large clouds) and the plain-VALU kernel
     brute = None
     if rank == 0 and not a.no_extras and not batch:
-        ctx.profile_sampling(1)                    # 4 launches only: time every one of them
-        ctx.set_params(nn_mode=NN_BRUTE, max_iterations=2)
-        ctx.align()
-        ctx.profile_reset()
-        ctx.align()
-        pb = ctx.profile()
-        brute = {"avg_launch_ms": pb.nn_ms / max(1, pb.nn_timed), "launches": int(pb.nn_launches)}
+        ctx.profile_sampling(1)                    # a handful of launches: time every one of them
+        brute = {}
+        for name, variant in (("mfma", 0), ("valu", 1)):
+            ctx.set_params(nn_mode=NN_BRUTE, max_iterations=2, brute_variant=variant)
+            ctx.align()
+            ctx.profile_reset()
+            ctx.align()
+            pb = ctx.profile()
+            brute[name] = {"avg_launch_ms": pb.nn_ms / max(1, pb.nn_timed), "launches": int(pb.nn_launches)}
         ctx.profile_sampling(7)
-        ctx.set_params(nn_mode=nn_mode, max_iterations=a.iters)
+        ctx.set_params(nn_mode=nn_mode, max_iterations=a.iters, brute_variant=0)
 
     if rank == 0:
         flops = 8.0 * n_s * n_t                      # F_iter = 8 * N_s * N_t (brute force)
@@ -342,17 +345,24 @@ def main():
         issue_pmc = _load_json("pmc_issue.json").get(a.workload, {})
         brute_roofline = None
         if brute:
-            b_ms = brute["avg_launch_ms"]
-            b_tf = flops / (b_ms * 1e-3) / 1e12
-            brute_roofline = {
-                "kernel": "nn_brute_kernel (LDS-tiled brute force)", "bound": "mfma", "achieved": b_tf,
-                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": b_tf / FP32_PEAK_TFLOPS,
-                "traffic": traffic.get("nn_brute_hbm_bytes_per_launch"), "avg_launch_ms": b_ms,
-                "hbm": {"achieved": alg_bytes_keys / (b_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg_bytes_keys / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "algorithmic_bytes_per_launch": alg_bytes_keys},
-                "note": "brute-force NN is FP32-compute-bound (8*Ns*Nt flop per launch); peak = f32 dense MFMA peak = f32 "
-                        "vector peak (157.3 TFLOP/s, packed FMA)"}
+            def brute_entry(kernel, ms, note):
+                tf = flops / (ms * 1e-3) / 1e12
+                return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tf / FP32_PEAK_TFLOPS, "avg_launch_ms": ms,
+                        "hbm": {"achieved": alg_bytes_keys / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": alg_bytes_keys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": alg_bytes_keys}, "note": note}
+            small = min(n_s, n_t) < 8192
+            brute_roofline = brute_entry(
+                "nn_brute_kernel (plain VALU; below 8192 points the matrix-core kernel is not used)" if small else
+                "nn_brute_mfma_kernel (LDS-tiled brute force on the matrix cores: f32 MFMA lower bound + exact re-check)",
+                brute["mfma"]["avg_launch_ms"],
+                "flops = 8*Ns*Nt per launch (SURVEY.md 8(d) convention: 3 sub + 1 mul + 2 fma per pair); peak = f32 dense MFMA "
+                "peak = packed-f32 vector peak (157.3 TFLOP/s); sweeps seeded with the previous sweep's neighbours")
+            brute_roofline["traffic"] = traffic.get("nn_brute_hbm_bytes_per_launch")
+            brute_roofline["valu_kernel"] = brute_entry(
+                "nn_brute_kernel<0,4> (plain VALU, 7 instructions per pair)", brute["valu"]["avg_launch_ms"],
+                "the round-1 kernel: 79-84 % of what the vector ALUs issue unpacked (78.6 TFLOP/s); v_pk_*_f32 issues at half rate")
         if used_grid:
             g_ms = prof.grid_ms / max(1, prof.grid_timed)
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
@@ -389,7 +399,7 @@ def main():
         else:
             nn_ms = prof.nn_ms / max(1, prof.nn_timed)
             tf = flops / (nn_ms * 1e-3) / 1e12
-            roofline = dict(brute_roofline or {}, kernel="nn_brute_kernel (LDS-tiled brute force)", bound="mfma", achieved=tf,
+            roofline = dict(brute_roofline or {}, kernel=(brute_roofline or {}).get("kernel", "nn_brute_kernel (LDS-tiled brute force)"), bound="mfma", achieved=tf,
                             peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, avg_launch_ms=nn_ms,
                             launches=int(prof.nn_launches), traffic=traffic.get("nn_brute_hbm_bytes_per_launch"))
         if batch and used_grid:

@@ -19,7 +19,7 @@ class Params(C.Structure):
     _fields_ = [("method", C.c_int32), ("max_iterations", C.c_int32), ("transformation_epsilon", C.c_double),
                 ("max_correspondence_distance", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
                 ("min_correspondences", C.c_int32), ("force_iterations", C.c_int32), ("nn_mode", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("brute_variant", C.c_int32)]
 
 
 class Result(C.Structure):

@@ -42,6 +42,13 @@ hipError_t launch_nn_brute(const float4* src, int n_s, const float4* tgt, int n_
                            unsigned long long* keys, hipStream_t stream);
 
 // partials: [blocks][17] doubles, sums_out: 17 doubles (device). Deterministic (fixed order) two-stage reduction.
+// The same keys from the matrix cores (icp_brute_mfma.hip).  src_sorted: the source in cell order, ORIGINAL index in .w (a
+// grid's sorted copy); keys are written at the original indices and must be pre-filled with kEmptyKey.
+// seed (nullable): n_s keys of an earlier sweep of the same source over the SAME target array -- each source's old neighbour
+// bounds its search from the first tile on.
+hipError_t launch_nn_brute_mfma(const float4* src_sorted, int n_q, const float4* tgt, int n_t, const Xform& T, int num_cus,
+                                unsigned long long* keys, const unsigned long long* seed, hipStream_t stream);
+
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
                          float d2_threshold, double* partials, double* sums_out, unsigned long long* flags,
                          unsigned long long seq, hipStream_t stream);

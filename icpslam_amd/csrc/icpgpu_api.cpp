@@ -74,6 +74,16 @@ struct PrevNeighbours {
   uint64_t grid_version = 0, src_version = 0;
 };
 
+// Keys of the last matrix-core brute-force sweep (icp_brute_mfma.hip): every source's neighbour, a bound for the next sweep
+// of the same source over the same target.
+struct BruteSeed {
+  DeviceBuf keys;
+  bool valid = false;
+  uint64_t src_version = 0, tgt_version = 0;
+  const void* tgt = nullptr;
+  int n_s = 0, n_t = 0;
+};
+
 // The mapper's one-point-per-voxel map (icp_map.hip; octree_mapper.cpp:55-90).
 struct VoxelMap {
   bool defined = false;   // resolution set by icpgpu_map_reset
@@ -122,6 +132,7 @@ struct icpgpu_ctx {
   GridIndex grid;            // acceleration structure over the current target
   GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
   PrevNeighbours prev;       // last sweep's neighbours (search bound of the next sweep)
+  BruteSeed brute_seed;      // the same for the matrix-core brute-force kernel
   VoxelMap map;              // the mapper's map
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
   uint64_t src_version = 1;  // bumped whenever the source cloud changes
@@ -158,7 +169,7 @@ struct icpgpu_ctx {
   bool have_final = false;
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
-  int nn_variant = 0;
+  int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   std::string err;
@@ -525,6 +536,51 @@ bool source_ordered(const icpgpu_ctx* c) {
   return c->src_grid.built && c->src_grid.usable && c->src_grid.version == c->src_version && c->src_grid.n_binned > 0;
 }
 
+// Brute-force keys of every source point against tgt_pts (exact NN).  Large problems go to the matrix
+// cores (icp_brute_mfma.hip: an MFMA lower bound settles all but a handful of pairs, those are evaluated exactly); that
+// kernel wants its sources as neighbours in space, so the source is binned with the grid machinery first (cached per source
+// cloud; promote_source_to_target hands the same structure on as the next target's grid).  brute_variant: 0 = this choice,
+// 1 = the plain-VALU kernel whatever the size (A/B measurements; ICPGPU_NN_VARIANT picks among its variants).
+constexpr int kMfmaMinPoints = 8192;
+
+int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T, unsigned long long* keys, bool* used_mfma = nullptr) {
+  const int n_s = (int)c->src.n;
+  if (used_mfma) *used_mfma = false;
+  if (n_s <= 0) return ICPGPU_OK;
+  if (c->params.brute_variant == 0 && c->nn_variant < 0 && n_s >= kMfmaMinPoints && n_t >= kMfmaMinPoints) {
+    double cut = c->params.max_correspondence_distance;
+    if (!(cut > 1e-3) || !std::isfinite(cut) || cut > 1e6) cut = 1.0;
+    const float thr = threshold_from(cut * cut);
+    int rc = build_grid(c, c->src, c->src_version, std::sqrt((double)thr) * (1.0 + 1e-6), /*adapt=*/true, c->src_grid);
+    if (rc) return rc;
+    if (c->src_grid.usable && c->src_grid.n_binned > 0) {
+      // the keys of the last matrix-core sweep of this source over this target seed the next one (a private copy: c->keys
+      // has other writers); results do not depend on the seed, only the time does
+      BruteSeed& S = c->brute_seed;
+      const bool seeded = S.valid && S.src_version == c->src_version && S.tgt_version == c->tgt_version && S.tgt == tgt_pts &&
+                          S.n_s == n_s && S.n_t == n_t;
+      if ((rc = ensure(c, S.keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+      HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+      HIP_TRY(c, launch_nn_brute_mfma(static_cast<const float4*>(c->src_grid.sorted.ptr), c->src_grid.n_binned, tgt_pts, n_t, T,
+                                      c->num_cus, keys, seeded ? static_cast<const unsigned long long*>(S.keys.ptr) : nullptr,
+                                      c->stream));
+      HIP_TRY(c, hipMemcpyAsync(S.keys.ptr, keys, (size_t)n_s * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+      S.valid = true;
+      S.src_version = c->src_version;
+      S.tgt_version = c->tgt_version;
+      S.tgt = tgt_pts;
+      S.n_s = n_s;
+      S.n_t = n_t;
+      if (used_mfma) *used_mfma = true;
+      return ICPGPU_OK;
+    }
+  }
+  const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant < 0 ? 0 : c->nn_variant, c->num_cus);
+  if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+  HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, tgt_pts, n_t, T, plan, keys, c->stream));
+  return ICPGPU_OK;
+}
+
 // Read back the kernel timings of the sweeps issued since the last call (one stream synchronisation for all of them).
 // With block = false nothing waits: the events of the last sweep are normally complete a few microseconds after its
 // result reached the mailbox (a short poll of hipEventQuery); if they are not, the timings stay pending and are read by
@@ -668,10 +724,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
       if ((rc = nn_keys_grid(c, c->grid, red_src, red_n, c->tgt.data(), n_t, T, keys, reinterpret_cast<int*>(c->h_sums_dev + 20))))
         return rc;
     } else {
-      const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
-      if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-      EVREC(ev[0]);
-      HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, T, plan, keys, c->stream));
+      if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, T, keys))) return rc;
     }
     EVREC(ev[1]);
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
@@ -1137,9 +1190,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
                                        static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, keys, nullptr, nullptr,
                                        nullptr, c->stream, prev, use_prev));
     } else {
-      const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
-      if (plan.splits > 1) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-      HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, Tq, plan, keys, c->stream));
+      if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
     }
     HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
                                        static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
@@ -1296,6 +1347,7 @@ void icpgpu_default_params(icpgpu_params* p) {
   p->min_correspondences = 3;                // PCL default
   p->force_iterations = 0;
   p->nn_mode = ICPGPU_NN_AUTO;
+  p->brute_variant = 0;
 }
 
 int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
@@ -1414,6 +1466,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->vox_ints);
   release(c->idx);
   release(c->d2);
+  release(c->brute_seed.keys);
   if (c->cand_counter.ptr) grid_count_candidates(nullptr);
   release(c->cand_counter);
   for (DeviceBuf* b : {&c->map.pts.buf, &c->map.keys, &c->map.vals, &c->map.first, &c->map.staged, &c->map.moved, &c->map.slot_of,
@@ -1449,6 +1502,7 @@ int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* p) {
   if (!c || !p) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   if (p->method != ICPGPU_P2P_SVD && p->method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad method");
   if (p->nn_mode < ICPGPU_NN_AUTO || p->nn_mode > ICPGPU_NN_GRID) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad nn_mode");
+  if (p->brute_variant < 0 || p->brute_variant > 1) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad brute_variant");
   c->params = *p;
   return ICPGPU_OK;
 }
@@ -1750,10 +1804,7 @@ int icpgpu_nn(icpgpu_ctx* c, const float* T, int32_t* idx, float* d2) {
   if (use_grid) {
     if ((rc = nn_keys_grid(c, X, keys))) return rc;
   } else {
-    const NnPlan plan = plan_nn_brute(n_s, n_t, c->nn_variant, c->num_cus);
-    if (plan.splits > 1 && n_t > 0) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, c->tgt.data(), n_t, X, plan, keys, c->stream));
+    if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, X, keys))) return rc;
   }
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
   HIP_TRY(c, launch_unpack_keys(keys, n_s, static_cast<int32_t*>(c->idx.ptr), static_cast<float*>(c->d2.ptr), c->stream));
@@ -2054,9 +2105,7 @@ int icpgpu_map_nn_target(icpgpu_ctx* c, const float* pose, const float* pose_inv
   if (M.grid.usable) {
     if ((rc = nn_keys_grid(c, M.grid, c->src.data(), n_s, M.pts.data(), M.n, T, keys))) return rc;
   } else {
-    const NnPlan plan = plan_nn_brute(n_s, M.n, c->nn_variant, c->num_cus);
-    if (plan.splits > 1) HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-    HIP_TRY(c, launch_nn_brute(c->src.data(), n_s, M.pts.data(), M.n, T, plan, keys, c->stream));
+    if ((rc = nn_keys_brute(c, M.pts.data(), M.n, T, keys))) return rc;
   }
   if ((rc = ensure(c, c->tgt.buf, (size_t)n_s * sizeof(float4)))) return rc;
   if ((rc = ensure(c, M.flags, (size_t)n_s * sizeof(int)))) return rc;

@@ -82,7 +82,7 @@ typedef struct {
   int32_t min_correspondences;        /* PCL default 3 (P2P) / 4 (GICP) */
   int32_t force_iterations;           /* != 0: run exactly max_iterations (benchmarking; no PCL equivalent) */
   int32_t nn_mode;                    /* icpgpu_nn_mode */
-  int32_t reserved;
+  int32_t brute_variant;              /* brute-force search: 0 = matrix-core kernel for large clouds (default), 1 = plain-VALU kernel always */
 } icpgpu_params;
 
 typedef struct {
