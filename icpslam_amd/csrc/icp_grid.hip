@@ -638,6 +638,8 @@ static bool use_quad(int n_s) { return quad_enabled() && n_s >= 4 * 8192; }
 
 // points per wave: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
 static int queries_per_wave(int n_s) {
+  static const int forced = [] { const char* e = getenv("ICPGPU_QPW"); return e ? atoi(e) : 0; }();  // experiments: 4, 8, 12, 16
+  if (forced >= 4 && forced <= WQ_MAX_QPW && use_quad(n_s)) return forced & ~3;
   int q = n_s / 8192;
   if (use_quad(n_s)) q = (q + 3) & ~3;  // four points per pass
   if (q < 1) q = 1;

@@ -280,12 +280,16 @@ static double sparse_population() {  // ICPGPU_SPARSE_POP overrides (tuning expe
   return v;
 }
 
-// cells per cutoff; 4 unless ICPGPU_GRID_DIV overrides it (tuning experiments only)
+// cells per cutoff; 4.5 unless ICPGPU_GRID_DIV overrides it (tuning experiments only).  4 until the dense-population rule
+// moved to 44: a raw 200k scan (population 47 at gate / 4) then paid a second count pass (table memset, count, scan, host
+// round trip: ~80 us of a 0.25 ms build) for every scan; at gate / 4.5 it lands on ~36 at once.  (A hint from the previous
+// cloud would save the same, but an alignment's cell size -- hence its summation order, hence its last bits -- would then
+// depend on what the context did before.)
 static double grid_divisor() {
   static const double d = [] {
     const char* v = std::getenv("ICPGPU_GRID_DIV");
     const double x = v ? std::atof(v) : 0.0;
-    return (x >= 1.0 && x <= 64.0) ? x : 4.0;
+    return (x >= 1.0 && x <= 64.0) ? x : 4.5;
   }();
   return d;
 }
