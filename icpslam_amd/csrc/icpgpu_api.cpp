@@ -171,6 +171,9 @@ struct icpgpu_ctx {
   icpgpu_profile prof{};
   int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
+  DeviceBuf vox_bins, vox_tmp;   // ... of the direct (no library sort) path; vox_bins starts with its self-cleaning histogram
+  void* vox_bins_zeroed = nullptr;  // the allocation (address, size) whose histogram is known to be zero
+  size_t vox_bins_zeroed_cap = 0;
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   std::string err;
 };
@@ -816,7 +819,7 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   *passthrough = false;
   if (!(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel filter: leaf size must be positive");
   if (n <= 0) return ICPGPU_OK;
-  int rc = ensure(c, c->vox_ints, 8 * sizeof(int));
+  int rc = ensure(c, c->vox_ints, 16 * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(c->vox_ints.ptr);
   HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream));
@@ -841,21 +844,57 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
     *passthrough = true;
     return ICPGPU_OK;
   }
-  const size_t tb = voxel_temp_bytes(n);
   if ((rc = ensure(c, c->vox_keys, (size_t)2 * n * sizeof(int)))) return rc;
   if ((rc = ensure(c, c->vox_vals, (size_t)2 * n * sizeof(int)))) return rc;
-  if ((rc = ensure(c, c->vox_flags, (size_t)n * sizeof(int)))) return rc;
-  if ((rc = ensure(c, c->vox_slots, (size_t)n * sizeof(int)))) return rc;
-  if ((rc = ensure(c, c->vox_temp, tb))) return rc;
-  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  HIP_TRY(c, launch_voxel_grid(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_vals.ptr),
-                               static_cast<int*>(c->vox_flags.ptr), static_cast<int*>(c->vox_slots.ptr), c->vox_temp.ptr, tb,
-                               static_cast<float4*>(out.ptr), d_ints + 6, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
   float ms = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  // the direct path (one distribution pass + a sort in LDS): every cloud up to 2M points; it reports the rare cloud it cannot
+  // take (thousands of points in one voxel) through `status`, and the library-sort path runs instead
+  static const bool force_sort = [] { const char* e = std::getenv("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
+  bool done = false;
+  if (!force_sort && n <= (1 << 21)) {
+    if ((rc = ensure(c, c->vox_bins, voxel_direct_scratch_ints(n) * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->vox_tmp, (size_t)n * sizeof(float4)))) return rc;
+    if (c->vox_bins_zeroed != c->vox_bins.ptr || c->vox_bins_zeroed_cap != c->vox_bins.cap) {
+      HIP_TRY(c, hipMemsetAsync(c->vox_bins.ptr, 0, c->vox_bins.cap, c->stream));
+      c->vox_bins_zeroed = c->vox_bins.ptr;
+      c->vox_bins_zeroed_cap = c->vox_bins.cap;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
+                                             static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
+                                             static_cast<unsigned long long*>(c->vox_vals.ptr),
+                                             static_cast<float4*>(c->vox_tmp.ptr), static_cast<float4*>(out.ptr), d_ints + 6,
+                                             d_ints + 8, c->stream);
+    if (le != hipSuccess) {
+      c->vox_bins_zeroed = nullptr;
+      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (se != hipSuccess) {
+      c->vox_bins_zeroed = nullptr;
+      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(se));
+    }
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    done = c->h_ints[8] == 0;
+  }
+  if (!done) {
+    const size_t tb = voxel_temp_bytes(n);
+    if ((rc = ensure(c, c->vox_flags, (size_t)n * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->vox_slots, (size_t)n * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->vox_temp, tb))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, launch_voxel_grid(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_vals.ptr),
+                                 static_cast<int*>(c->vox_flags.ptr), static_cast<int*>(c->vox_slots.ptr), c->vox_temp.ptr, tb,
+                                 static_cast<float4*>(out.ptr), d_ints + 6, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms2 = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms2, c->ev[0], c->ev[1]));
+    ms += ms2;
+  }
   *n_out = c->h_ints[6] + c->h_ints[7];
   c->prof.voxel_launches += 1;
   c->prof.voxel_ms += ms;
@@ -1468,6 +1507,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->vox_slots);
   release(c->vox_temp);
   release(c->vox_ints);
+  release(c->vox_bins);
+  release(c->vox_tmp);
   release(c->idx);
   release(c->d2);
   release(c->brute_seed.keys);

@@ -70,3 +70,49 @@ def test_fuzz_voxel_filter_against_oracle(ctx, seed):
     out = ctx.voxel_grid(cloud, leaf)
     ref = oracle.voxel_grid(cloud, leaf)                          # returns the input unchanged on index overflow, like PCL
     assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("leaf", [0.2, 0.5, 2.0])
+def test_raw_scan_dense_voxels_bit_exact(ctx, leaf):
+    """A raw scan's near-field voxels hold hundreds of points: the direct path's in-LDS sort must keep PCL's input order
+    inside every voxel (float sums), and groups of several buckets / one bucket filling a group must both work."""
+    scene = synth.make_scene(31)
+    for n in (5000, 70000, 200000):
+        cloud = synth.scan(scene, np.eye(4), n, seed=n)
+        got, ref = ctx.voxel_grid(cloud, leaf), oracle.voxel_grid(cloud, leaf)
+        assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), (n, leaf)
+
+
+def test_voxel_over_capacity_falls_back_to_the_sort_path(ctx):
+    """Thousands of points in ONE voxel exceed what a workgroup sorts in LDS: the direct path reports it and the library-sort
+    path produces the result -- same bits as the oracle either way."""
+    rng = np.random.default_rng(5)
+    cloud = np.ones((30000, 4), np.float32)
+    cloud[:, :3] = rng.uniform(-20, 20, (30000, 3)).astype(np.float32)
+    cloud[1000:9000, :3] = rng.uniform(0.01, 0.19, (8000, 3)).astype(np.float32)   # 8000 points in the voxel at the origin
+    got, ref = ctx.voxel_grid(cloud, 0.2), oracle.voxel_grid(cloud, 0.2)
+    assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
+    # exactly at / around the capacity of one group (4096) and of one bucket (3072)
+    for m in (3071, 3072, 3073, 4095, 4096, 4097):
+        c = np.ones((m + 500, 4), np.float32)
+        c[:m, :3] = rng.uniform(0.01, 0.19, (m, 3)).astype(np.float32)
+        c[m:, :3] = rng.uniform(-5, 5, (500, 3)).astype(np.float32)
+        got, ref = ctx.voxel_grid(c, 0.2), oracle.voxel_grid(c, 0.2)
+        assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), m
+    # and a later ordinary cloud on the same context is unaffected (the self-cleaning histogram stayed clean)
+    cloud2, _, _ = synth.make_pair(20000, 10, seed=3)
+    assert np.array_equal(_bits(ctx.voxel_grid(cloud2, 0.2)), _bits(oracle.voxel_grid(cloud2, 0.2)))
+
+
+def test_voxel_sizes_around_the_group_quantum(ctx):
+    rng = np.random.default_rng(9)
+    for n in (2, 63, 64, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 8191):
+        c = np.ones((n, 4), np.float32)
+        c[:, :3] = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
+        for leaf in (0.1, 1.5):
+            got, ref = ctx.voxel_grid(c, leaf), oracle.voxel_grid(c, leaf)
+            assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), (n, leaf)
