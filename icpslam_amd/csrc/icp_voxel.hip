@@ -201,7 +201,7 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int* wsum /* 16 
 
 __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const int* __restrict__ keys, const int* __restrict__ relpos,
                                                                  int n, unsigned int cpb, int nbins, const int* __restrict__ hist,
-                                                                 int n_groups, int2* __restrict__ group_range,
+                                                                 int n_groups, int4* __restrict__ group_range,
                                                                  int* __restrict__ status,
                                                                  unsigned long long* __restrict__ comp) {
   __shared__ int st[VX_BINS + 1];  // first item of every bucket
@@ -253,8 +253,15 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const int* __re
         if (st[mid] >= want) b = mid; else a = mid + 1;
       }
       const int first = st[a] >= want ? st[a] : total;
-      if (g < n_groups) group_range[g].x = first;
-      if (g > 0) group_range[g - 1].y = first;
+      const int first_key = (int)min((unsigned long long)a * cpb, 0x7FFFFFFFull);  // bucket a begins at cell a * cpb
+      if (g < n_groups) {
+        group_range[g].x = first;
+        group_range[g].z = first_key;
+      }
+      if (g > 0) {
+        group_range[g - 1].y = first;
+        group_range[g - 1].w = first_key;
+      }
     }
   }
 }
@@ -269,42 +276,45 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const int* __re
 // every step through LDS -- two round trips of LDS latency per step, 12 us for 1024 elements, 33 us for 4096: 80 % of
 // the filter's time.)
 typedef unsigned long long vx_u64;
-__device__ __forceinline__ void vx_ce(vx_u64& a, vx_u64& b) {
+typedef unsigned int vx_u32;
+template <typename T>
+__device__ __forceinline__ void vx_ce(T& a, T& b) {
   const bool lt = a < b;
-  const vx_u64 lo = lt ? a : b, hi = lt ? b : a;
+  const T lo = lt ? a : b, hi = lt ? b : a;
   a = lo;
   b = hi;
 }
 // the value lane (l ^ MASK) holds: DPP moves where the pattern has one (1, 2, 3, 4, 7, 8, 15: plain VALU instructions),
 // ds_swizzle inside 32 lanes (16, 31), ds_bpermute beyond (32, 63)
 template <int MASK>
-__device__ __forceinline__ unsigned int vx_lane_xor_u32(unsigned int x, int lane) {
+__device__ __forceinline__ vx_u32 vx_lane_xor(vx_u32 x, int lane) {
   const int v = (int)x;
-  if constexpr (MASK == 1) return (unsigned int)__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-  else if constexpr (MASK == 2) return (unsigned int)__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  else if constexpr (MASK == 3) return (unsigned int)__builtin_amdgcn_update_dpp(v, v, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+  if constexpr (MASK == 1) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (MASK == 2) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (MASK == 3) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
   else if constexpr (MASK == 4) {
-    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                                      // row_shl:4 into banks 0, 2
-    return (unsigned int)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                               // row_shr:4 into banks 1, 3
-  } else if constexpr (MASK == 7) return (unsigned int)__builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-  else if constexpr (MASK == 8) return (unsigned int)__builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);  // row_ror:8
-  else if constexpr (MASK == 15) return (unsigned int)__builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); // row_mirror
-  else if constexpr (MASK == 16) return (unsigned int)__builtin_amdgcn_ds_swizzle(v, 0x401F);
-  else if constexpr (MASK == 31) return (unsigned int)__builtin_amdgcn_ds_swizzle(v, 0x7C1F);
-  else return (unsigned int)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, v);
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                                // row_shl:4 into banks 0, 2
+    return (vx_u32)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                               // row_shr:4 into banks 1, 3
+  } else if constexpr (MASK == 7) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  else if constexpr (MASK == 8) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  else if constexpr (MASK == 15) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); // row_mirror
+  else if constexpr (MASK == 16) return (vx_u32)__builtin_amdgcn_ds_swizzle(v, 0x401F);
+  else if constexpr (MASK == 31) return (vx_u32)__builtin_amdgcn_ds_swizzle(v, 0x7C1F);
+  else return (vx_u32)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, v);
 }
 template <int MASK>
 __device__ __forceinline__ vx_u64 vx_lane_xor(vx_u64 v, int lane) {
-  const unsigned int lo = vx_lane_xor_u32<MASK>((unsigned int)v, lane);
-  const unsigned int hi = vx_lane_xor_u32<MASK>((unsigned int)(v >> 32), lane);
+  const vx_u32 lo = vx_lane_xor<MASK>((vx_u32)v, lane);
+  const vx_u32 hi = vx_lane_xor<MASK>((vx_u32)(v >> 32), lane);
   return ((vx_u64)hi << 32) | lo;
 }
 // keep the smaller (low side) or the larger (high side) of mine and the partner's
-__device__ __forceinline__ vx_u64 vx_keep(vx_u64 mine, vx_u64 other, bool low) { return ((mine < other) == low) ? mine : other; }
+template <typename T>
+__device__ __forceinline__ T vx_keep(T mine, T other, bool low) { return ((mine < other) == low) ? mine : other; }
 
-// strides J_FIRST .. 4 across lanes (J_FIRST <= 128), then 2 and 1 inside the lane
-template <int J>
-__device__ __forceinline__ void vx_strides_in_wave(vx_u64 v[4], int lane) {
+// strides J .. 4 across lanes (J <= 128), then 2 and 1 inside the lane
+template <int J, typename T>
+__device__ __forceinline__ void vx_strides_in_wave(T v[4], int lane) {
   if constexpr (J >= 4) {
     const bool low = (lane & (J >> 2)) == 0;
 #pragma unroll
@@ -317,17 +327,18 @@ __device__ __forceinline__ void vx_strides_in_wave(vx_u64 v[4], int lane) {
     vx_ce(v[2], v[3]);
   }
 }
-template <int K>
-__device__ __forceinline__ void vx_merge_in_wave(vx_u64 v[4], int lane) {  // 8 <= K <= 256
+template <int K, typename T>
+__device__ __forceinline__ void vx_merge_in_wave(T v[4], int lane) {  // 8 <= K <= 256
   const bool low = (lane & (K >> 3)) == 0;
-  vx_u64 o[4];
+  T o[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) o[c] = vx_lane_xor<(K >> 2) - 1>(v[3 - c], lane);
 #pragma unroll
   for (int c = 0; c < 4; ++c) v[c] = vx_keep(v[c], o[c], low);
   vx_strides_in_wave<(K >> 2)>(v, lane);
 }
-__device__ __forceinline__ void vx_sort_chunk(vx_u64 v[4], int lane) {
+template <typename T>
+__device__ __forceinline__ void vx_sort_chunk(T v[4], int lane) {
   vx_ce(v[0], v[1]);
   vx_ce(v[2], v[3]);
   vx_ce(v[0], v[3]);
@@ -341,27 +352,91 @@ __device__ __forceinline__ void vx_sort_chunk(vx_u64 v[4], int lane) {
   vx_merge_in_wave<128>(v, lane);
   vx_merge_in_wave<256>(v, lane);
 }
+// a lane's four consecutive elements to / from LDS, 16 bytes at a time
+__device__ __forceinline__ void vx_store4(vx_u32* p, const vx_u32 v[4]) {
+  typedef vx_u32 u32x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<u32x4*>(p) = u32x4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void vx_load4(const vx_u32* p, vx_u32 o[4]) {
+  typedef vx_u32 u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+  o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+__device__ __forceinline__ void vx_store4(vx_u64* p, const vx_u64 v[4]) {
+  typedef vx_u64 u64x2 __attribute__((ext_vector_type(2)));
+  reinterpret_cast<u64x2*>(p)[0] = u64x2{v[0], v[1]};
+  reinterpret_cast<u64x2*>(p)[1] = u64x2{v[2], v[3]};
+}
+__device__ __forceinline__ void vx_load4(const vx_u64* p, vx_u64 o[4]) {
+  typedef vx_u64 u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2 a = reinterpret_cast<const u64x2*>(p)[0], b = reinterpret_cast<const u64x2*>(p)[1];
+  o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y;
+}
 
-__global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __restrict__ pts,
+// The whole group in ascending order into arr[0 .. m) (LDS); v = the lane's four elements (padding = all ones).
+template <typename T>
+__device__ __forceinline__ void vx_sort_group(T v[4], T* arr, int m, int m_pad) {
+  const int lane = threadIdx.x & 63, chunk = threadIdx.x >> 6, chunk_base = chunk * VX_CHUNK;
+  const bool live = chunk_base < m;  // (a chunk of nothing but padding takes no part)
+  if (live) vx_sort_chunk(v, lane);
+  for (int k = 2 * VX_CHUNK; k <= m_pad; k <<= 1) {
+    // the flip across chunks: chunk c against c ^ (k/256 - 1), lane l against 63 - l, the four elements reversed
+    {
+      const int pc = chunk ^ ((k >> 8) - 1);
+      const bool both = live && pc * VX_CHUNK < m;
+      if (both) vx_store4(arr + chunk_base + 4 * lane, v);
+      __syncthreads();
+      if (both) {
+        T t[4];
+        vx_load4(arr + pc * VX_CHUNK + 4 * (63 - lane), t);
+        const bool low = (chunk & (k >> 9)) == 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = vx_keep(v[c], t[3 - c], low);
+      }
+      __syncthreads();
+    }
+    for (int j = k >> 2; j >= VX_CHUNK; j >>= 1) {
+      const int pc = chunk ^ (j >> 8);
+      const bool both = live && pc * VX_CHUNK < m;
+      if (both) vx_store4(arr + chunk_base + 4 * lane, v);
+      __syncthreads();
+      if (both) {
+        T t[4];
+        vx_load4(arr + pc * VX_CHUNK + 4 * lane, t);
+        const bool low = (chunk & (j >> 8)) == 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = vx_keep(v[c], t[c], low);
+      }
+      __syncthreads();
+    }
+    if (live) vx_strides_in_wave<128>(v, lane);
+  }
+  if (live) vx_store4(arr + chunk_base + 4 * lane, v);
+  __syncthreads();
+}
+
+// number of bits of x (0 for 0)
+__device__ __forceinline__ int vx_bits(unsigned int x) { return 32 - __clz(x); }
+
+__global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __restrict__ pts, int n,
                                                                const unsigned long long* __restrict__ comp,
-                                                               const int2* __restrict__ group_range,
+                                                               const int4* __restrict__ group_range,
                                                                float4* __restrict__ tmp, int* __restrict__ group_count,
                                                                int* __restrict__ group_start, int* __restrict__ status,
                                                                long long* __restrict__ dbg) {
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #define VX_STAMP(k) do { if (dbg && threadIdx.x == 0) stamp[k] = (long long)wall_clock64(); } while (0)
   VX_STAMP(0);
-  // 45 KiB: the composites while they are sorted (32 KiB), then x / y / z of the gathered points (rows one word apart in
-  // bank so that the three axis lanes of a voxel do not collide)
+  // 45 KiB: the composites while they are sorted (<= 32 KiB), then x / y / z of the gathered points (rows one word apart
+  // in bank so that the three axis lanes of a voxel do not collide)
   constexpr int ROW = VX_CAP + 1;
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * ROW * 4];
   __shared__ unsigned short head_pos[VX_CAP + 2];  // element index of the voxel with local rank r; [heads] = m
   __shared__ int wsum[VX_BLOCK / 64];
   static_assert(3 * ROW * 4 >= VX_SORT * 8, "the sort array aliases the coordinate rows");
-  unsigned long long* arr = reinterpret_cast<unsigned long long*>(lds);
   float* coord = reinterpret_cast<float*>(lds);
   const int g = blockIdx.x, tid = threadIdx.x;
-  const int2 rg = group_range[g];
+  const int4 rg = group_range[g];  // items [x, y), cell keys [z, w)
   const int gs = rg.x, m = rg.y - rg.x;
   if (m <= 0 || m > VX_CAP) {
     if (tid == 0) {
@@ -373,78 +448,66 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
   }
   int m_pad = VX_CHUNK;
   while (m_pad < m) m_pad <<= 1;
-  const int lane = tid & 63, chunk = tid >> 6, chunk_base = chunk * VX_CHUNK;
-  const bool live = chunk_base < m;  // (a chunk of nothing but padding takes no part)
-  vx_u64 v[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int e = chunk_base + 4 * lane + c;
-    v[c] = e < m ? comp[gs + e] : ~0ull;
-  }
-  VX_STAMP(1);
-  if (live) vx_sort_chunk(v, lane);
-  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-  u64x2* arr2 = reinterpret_cast<u64x2*>(arr);
-  for (int k = 2 * VX_CHUNK; k <= m_pad; k <<= 1) {
-    // the flip across chunks: chunk c against c ^ (k/256 - 1), lane l against 63 - l, the four elements reversed
-    {
-      const int pc = chunk ^ ((k >> 8) - 1);
-      const bool both = live && pc * VX_CHUNK < m;
-      if (both) {
-        arr2[(chunk_base >> 1) + 2 * lane] = u64x2{v[0], v[1]};
-        arr2[(chunk_base >> 1) + 2 * lane + 1] = u64x2{v[2], v[3]};
-      }
-      __syncthreads();
-      if (both) {
-        const u64x2 a = arr2[(pc * VX_CHUNK >> 1) + 2 * (63 - lane)], b = arr2[(pc * VX_CHUNK >> 1) + 2 * (63 - lane) + 1];
-        const vx_u64 o[4] = {b.y, b.x, a.y, a.x};
-        const bool low = (chunk & (k >> 9)) == 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = vx_keep(v[c], o[c], low);
-      }
-      __syncthreads();
-    }
-    for (int j = k >> 2; j >= VX_CHUNK; j >>= 1) {
-      const int pc = chunk ^ (j >> 8);
-      const bool both = live && pc * VX_CHUNK < m;
-      if (both) {
-        arr2[(chunk_base >> 1) + 2 * lane] = u64x2{v[0], v[1]};
-        arr2[(chunk_base >> 1) + 2 * lane + 1] = u64x2{v[2], v[3]};
-      }
-      __syncthreads();
-      if (both) {
-        const u64x2 a = arr2[(pc * VX_CHUNK >> 1) + 2 * lane], b = arr2[(pc * VX_CHUNK >> 1) + 2 * lane + 1];
-        const vx_u64 o[4] = {a.x, a.y, b.x, b.y};
-        const bool low = (chunk & (j >> 8)) == 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = vx_keep(v[c], o[c], low);
-      }
-      __syncthreads();
-    }
-    if (live) vx_strides_in_wave<128>(v, lane);
-  }
-  if (live) {
-    arr2[(chunk_base >> 1) + 2 * lane] = u64x2{v[0], v[1]};
-    arr2[(chunk_base >> 1) + 2 * lane + 1] = u64x2{v[2], v[3]};
-  }
-  __syncthreads();
-  VX_STAMP(2);
-  // each thread owns four consecutive sorted elements: voxel heads, gather
+  // A group of few buckets (all the crowded ones are) sorts 32-bit words -- (key - first key of the group) above the point
+  // index -- when the two fit: half the exchanges, single-instruction compares; the others sort (key << 32 | index).
+  const int idx_bits = vx_bits((unsigned int)(n - 1)) > 0 ? vx_bits((unsigned int)(n - 1)) : 1;
+  const bool narrow = vx_bits((unsigned int)(rg.w - rg.z - 1)) + idx_bits <= 31;
   constexpr int OWN = VX_SORT / VX_BLOCK;
   bool head[OWN];
+  unsigned int pidx[OWN];
+  {
+    vx_u64 c64[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = tid * 4 + c;  // (= chunk_base + 4 lane + c)
+      c64[c] = e < m ? comp[gs + e] : ~0ull;
+    }
+    VX_STAMP(1);
+    if (narrow) {
+      vx_u32* arr = reinterpret_cast<vx_u32*>(lds);
+      vx_u32 v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        v[c] = c64[c] == ~0ull ? ~0u : ((((vx_u32)(c64[c] >> 32) - (vx_u32)rg.z) << idx_bits) | (vx_u32)c64[c]);
+      vx_sort_group(v, arr, m, m_pad);
+      const vx_u32 mask = (1u << idx_bits) - 1u;
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        const int e = tid * OWN + k;
+        head[k] = false;
+        pidx[k] = 0;
+        if (e < m) {
+          const vx_u32 x = arr[e];
+          head[k] = e == 0 || (arr[e - 1] >> idx_bits) != (x >> idx_bits);
+          pidx[k] = x & mask;
+        }
+      }
+    } else {
+      vx_u64* arr = reinterpret_cast<vx_u64*>(lds);
+      vx_sort_group(c64, arr, m, m_pad);
+#pragma unroll
+      for (int k = 0; k < OWN; ++k) {
+        const int e = tid * OWN + k;
+        head[k] = false;
+        pidx[k] = 0;
+        if (e < m) {
+          const vx_u64 x = arr[e];
+          head[k] = e == 0 || (vx_u32)(arr[e - 1] >> 32) != (vx_u32)(x >> 32);
+          pidx[k] = (vx_u32)x;
+        }
+      }
+    }
+  }
+  VX_STAMP(2);
+  // each thread owns four consecutive sorted elements: gather, voxel ranks
   float4 p[OWN];
   int n_heads = 0;
 #pragma unroll
   for (int k = 0; k < OWN; ++k) {
     const int e = tid * OWN + k;
-    head[k] = false;
     p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < m) {
-      const unsigned long long c = arr[e];
-      head[k] = e == 0 || (unsigned int)(arr[e - 1] >> 32) != (unsigned int)(c >> 32);
-      p[k] = pts[(unsigned int)c];
-      n_heads += head[k] ? 1 : 0;
-    }
+    if (e < m) p[k] = pts[pidx[k]];
+    n_heads += head[k] ? 1 : 0;
   }
   int heads = 0;
   int rank = block_exclusive_scan_1024(n_heads, wsum, &heads);  // (its barriers: the composites are dead from here on)
@@ -461,7 +524,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
   if (tid == 0) head_pos[heads] = (unsigned short)m;
   __syncthreads();
   VX_STAMP(3);
-  // one lane per (voxel, axis): the members in sorted order = input order, loads eight ahead of the dependent additions
+  // one lane per (voxel, axis): the members in sorted order = input order
   for (int q = tid; q < 3 * heads; q += VX_BLOCK) {
     const int r = q / 3, axis = q - 3 * r;
     const int e = head_pos[r], len = (int)head_pos[r + 1] - e;
@@ -502,7 +565,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
       for (int k = 0; k < 5; ++k) dbg[g * 8 + k] = stamp[k];
       dbg[g * 8 + 5] = m;
       dbg[g * 8 + 6] = heads;
-      dbg[g * 8 + 7] = m_pad;
+      dbg[g * 8 + 7] = narrow ? -m_pad : m_pad;
     }
   }
 #undef VX_STAMP
@@ -533,7 +596,7 @@ __global__ __launch_bounds__(256) void voxel_compact_kernel(const float4* __rest
 }  // namespace
 
 int voxel_direct_groups(int n) { return (n + VX_QUANTUM - 1) / VX_QUANTUM; }
-size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 4 * (size_t)voxel_direct_groups(n); }
+size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 6 * (size_t)voxel_direct_groups(n); }
 
 // bins: voxel_direct_scratch_ints(n) ints, ALL zero before the first call (the histogram is left zero); keys: n ints; relpos: n
 // ints; comp: n 64-bit words; tmp: n points; d_n_out: 2 ints (sum = cells written); status: 1 int, 1 = not done, use the sort path.
@@ -547,8 +610,8 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   const int nbins = (int)((ncells - 1) / cpb) + 1;
   const int groups = voxel_direct_groups(n);
   int* hist = bins;
-  int2* group_range = reinterpret_cast<int2*>(bins + VX_BINS + 8);
-  int* group_count = bins + VX_BINS + 8 + 2 * groups;
+  int4* group_range = reinterpret_cast<int4*>(bins + VX_BINS + 8);
+  int* group_count = bins + VX_BINS + 8 + 4 * groups;
   int* group_start = group_count + groups;
   const int blocks = (n + VX_BLOCK * VX_PPT - 1) / (VX_BLOCK * VX_PPT);
   hipLaunchKernelGGL(voxel_hist_kernel, dim3(blocks), dim3(VX_BLOCK), 0, stream, pts, n, inv_leaf, minb[0], minb[1], minb[2],
@@ -560,7 +623,7 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   long long* dbg = nullptr;
   if (debug && hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)groups * 8 * sizeof(long long)) == hipSuccess)
     (void)hipMemsetAsync(dbg, 0, (size_t)groups * 8 * sizeof(long long), stream);
-  hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, comp, group_range, tmp, group_count,
+  hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, tmp, group_count,
                      group_start, status, dbg);
   if (dbg) {
     std::vector<long long> h((size_t)groups * 8);
@@ -579,7 +642,7 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
     std::fprintf(stderr, "[voxel] %d live groups, first start -> last end %.2f us (100 MHz clock)\n", (int)order.size(), (last - first) * 0.01);
     for (size_t k = 0; k < order.size() && k < 4; ++k) {
       const long long* r = &h[(size_t)order[k] * 8];
-      std::fprintf(stderr, "[voxel]   group %d: m %lld pad %lld heads %lld | starts at %.2f | load %.2f sort %.2f gather+scan %.2f sums %.2f us\n",
+      std::fprintf(stderr, "[voxel]   group %d: m %lld pad %lld (< 0: 32-bit words) heads %lld | starts at %.2f | load %.2f sort %.2f gather+scan %.2f sums %.2f us\n",
                    order[k], r[5], r[7], r[6], (r[0] - first) * 0.01, (r[1] - r[0]) * 0.01, (r[2] - r[1]) * 0.01, (r[3] - r[2]) * 0.01, (r[4] - r[3]) * 0.01);
     }
   }
