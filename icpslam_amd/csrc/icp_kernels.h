@@ -193,11 +193,11 @@ hipError_t launch_voxel_grid(const float4* pts, int n, float inv_leaf, const int
                              hipStream_t stream);
 
 // The same filter without the library sort (one distribution pass + a sort in LDS; icp_voxel.hip): bins =
-// voxel_direct_scratch_ints(n) ints, all zero before the first call; keys, relpos n ints each; comp n 64-bit words; tmp n points;
-// *status = 1 when a voxel bucket exceeded the LDS capacity -- nothing usable was written, run launch_voxel_grid instead.
+// voxel_direct_scratch_ints(n) ints, all zero before the first call; keys, relpos n ints each; comp n 64-bit words;
+// *status != 0 when a voxel bucket exceeded the LDS capacity -- nothing usable was written, run launch_voxel_grid instead.
 size_t voxel_direct_scratch_ints(int n);
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
-                                    int* keys, int* relpos, unsigned long long* comp, float4* tmp, float4* out, int* d_n_out,
-                                    int* status, hipStream_t stream);
+                                    int* keys, int* relpos, unsigned long long* comp, float4* out, int* d_n_out, int* status,
+                                    hipStream_t stream);
 
 }  // namespace icpgpu

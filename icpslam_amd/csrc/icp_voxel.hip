@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(VC_BLOCK) void voxel_centroid_kernel(const float4* 
 
 // ---- round 2: the filter without the library sort -------------------------------------------------------------------
 // VERDICT round 1, item 9.  The radix sort (7-8 launches of ~7 us each for a 200k scan, whatever the key width) is replaced by
-// ONE distribution pass on the high bits of the cell key and a sort in LDS -- four launches:
+// ONE distribution pass on the high bits of the cell key and a sort in LDS -- three launches:
 //   voxel_hist_kernel     cell key of every point (kept), histogram of key / cells-per-bucket over <= 8192 buckets (privatised in LDS:
 //                         a raw scan's near-field buckets take thousands of points, global atomics on them serialise)
 //   voxel_scatter_kernel  every workgroup scans the histogram for itself (32 KiB, cheaper than a launch), then writes
@@ -122,9 +123,8 @@ __global__ __launch_bounds__(VC_BLOCK) void voxel_centroid_kernel(const float4* 
 //                         <= 3840 composites in LDS -- ascending key, and inside a key ascending input index, which is
 //                         the order PCL adds a voxel's points in and the reason a sort is needed at all --, gathers the
 //                         points, and adds every voxel's members in that order: one LANE per (voxel, axis), a float
-//                         addition chain cannot be split any further
-//   voxel_compact_kernel  every group copies its centroids behind those of the groups before it (ascending cell order);
-//                         zeroes the histogram and the cursors for the next call
+//                         addition chain cannot be split any further; the centroids go straight behind those of the groups
+//                         before it (ascending cell order): every group publishes its voxel count, none waits long
 // A group that would exceed the LDS capacity (a bucket of > 3328 points: thousands of points in ONE voxel, or a leaf far
 // larger than the point spacing) raises `status`; the host then runs the library-sort path above instead.
 constexpr int VX_BINS_LOG2 = 13;
@@ -288,16 +288,18 @@ __device__ __forceinline__ void vx_ce(T& a, T& b) {
 // ds_swizzle inside 32 lanes (16, 31), ds_bpermute beyond (32, 63)
 template <int MASK>
 __device__ __forceinline__ vx_u32 vx_lane_xor(vx_u32 x, int lane) {
+  // (mov_dpp, not update_dpp: every lane is written, so there is no "old" value to copy first, and a plain DPP move with
+  // full masks is what the compiler folds into the min / max / compare that consumes it)
   const int v = (int)x;
-  if constexpr (MASK == 1) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
-  else if constexpr (MASK == 2) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
-  else if constexpr (MASK == 3) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x1B, 0xF, 0xF, false);   // quad_perm [3,2,1,0]
+  if constexpr (MASK == 1) return (vx_u32)__builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+  else if constexpr (MASK == 2) return (vx_u32)__builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  else if constexpr (MASK == 3) return (vx_u32)__builtin_amdgcn_mov_dpp(v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
   else if constexpr (MASK == 4) {
-    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                                // row_shl:4 into banks 0, 2
-    return (vx_u32)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                               // row_shr:4 into banks 1, 3
-  } else if constexpr (MASK == 7) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
-  else if constexpr (MASK == 8) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);  // row_ror:8
-  else if constexpr (MASK == 15) return (vx_u32)__builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); // row_mirror
+    const int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                          // row_shl:4 into banks 0, 2
+    return (vx_u32)__builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                         // row_shr:4 into banks 1, 3
+  } else if constexpr (MASK == 7) return (vx_u32)__builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  else if constexpr (MASK == 8) return (vx_u32)__builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  else if constexpr (MASK == 15) return (vx_u32)__builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true); // row_mirror
   else if constexpr (MASK == 16) return (vx_u32)__builtin_amdgcn_ds_swizzle(v, 0x401F);
   else if constexpr (MASK == 31) return (vx_u32)__builtin_amdgcn_ds_swizzle(v, 0x7C1F);
   else return (vx_u32)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, v);
@@ -309,8 +311,11 @@ __device__ __forceinline__ vx_u64 vx_lane_xor(vx_u64 v, int lane) {
   return ((vx_u64)hi << 32) | lo;
 }
 // keep the smaller (low side) or the larger (high side) of mine and the partner's
-template <typename T>
-__device__ __forceinline__ T vx_keep(T mine, T other, bool low) { return ((mine < other) == low) ? mine : other; }
+__device__ __forceinline__ vx_u64 vx_keep(vx_u64 mine, vx_u64 other, bool low) { return ((mine < other) == low) ? mine : other; }
+__device__ __forceinline__ vx_u32 vx_keep(vx_u32 mine, vx_u32 other, bool low) {
+  const vx_u32 lo = min(mine, other), hi = max(mine, other);  // (v_min_u32 / v_max_u32 take the DPP operand directly)
+  return low ? lo : hi;
+}
 
 // strides J .. 4 across lanes (J <= 128), then 2 and 1 inside the lane
 template <int J, typename T>
@@ -421,9 +426,10 @@ __device__ __forceinline__ int vx_bits(unsigned int x) { return 32 - __clz(x); }
 __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __restrict__ pts, int n,
                                                                const unsigned long long* __restrict__ comp,
                                                                const int4* __restrict__ group_range,
-                                                               float4* __restrict__ tmp, int* __restrict__ group_count,
-                                                               int* __restrict__ group_start, int* __restrict__ status,
-                                                               long long* __restrict__ dbg) {
+                                                               unsigned long long* __restrict__ published,
+                                                               unsigned int epoch, float4* __restrict__ out,
+                                                               int* __restrict__ d_n_out, int* __restrict__ hist, int nbins,
+                                                               int* __restrict__ status, long long* __restrict__ dbg) {
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #define VX_STAMP(k) do { if (dbg && threadIdx.x == 0) stamp[k] = (long long)wall_clock64(); } while (0)
   VX_STAMP(0);
@@ -438,11 +444,47 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
   const int g = blockIdx.x, tid = threadIdx.x;
   const int4 rg = group_range[g];  // items [x, y), cell keys [z, w)
   const int gs = rg.x, m = rg.y - rg.x;
+  // leave the histogram zero for the next call (nothing reads it any more)
+  for (int b = g * VX_BLOCK + tid; b < nbins; b += gridDim.x * VX_BLOCK) hist[b] = 0;
+  // Where the group's centroids go: behind those of all the groups before it (ascending cell order).  Every group
+  // PUBLISHES its number of voxels as soon as it knows it -- (epoch << 32 | count), the epoch telling this call's word from
+  // an older one -- and adds up its predecessors' words once it needs the offset; by then they have been out for
+  // microseconds.  Workgroups start in index order and none waits for a later one, so the wait cannot deadlock; 20 ms
+  // without an answer gives up (status 2: the host runs the sort path).
+  auto publish = [&](int count) {
+    if (tid == 0)
+      __hip_atomic_store(&published[g], ((unsigned long long)epoch << 32) | (unsigned int)count, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto voxels_before = [&]() -> int {
+    int part = 0;
+    bool ok = true;
+    for (int i = tid; i < g; i += VX_BLOCK) {
+      unsigned long long w;
+      const long long t0 = (long long)wall_clock64();
+      while ((unsigned int)((w = __hip_atomic_load(&published[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((long long)wall_clock64() - t0 > 2000000) {
+          ok = false;
+          break;
+        }
+      }
+      part += (int)(unsigned int)w;
+    }
+    if (!ok) *status = 2;
+    int total = 0;
+    (void)block_exclusive_scan_1024(part, wsum, &total);
+    return total;
+  };
   if (m <= 0 || m > VX_CAP) {
-    if (tid == 0) {
-      group_count[g] = 0;
-      group_start[g] = gs;
-      if (m > VX_CAP) *status = 1;
+    publish(0);
+    if (m > VX_CAP && tid == 0) *status = 1;
+    if (g == (int)gridDim.x - 1) {  // the last group reports the number of cells
+      const int before = voxels_before();
+      if (tid == 0) {
+        d_n_out[0] = before;
+        d_n_out[1] = 0;
+      }
     }
     return;
   }
@@ -511,6 +553,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
   }
   int heads = 0;
   int rank = block_exclusive_scan_1024(n_heads, wsum, &heads);  // (its barriers: the composites are dead from here on)
+  publish(heads);
 #pragma unroll
   for (int k = 0; k < OWN; ++k) {
     const int e = tid * OWN + k;
@@ -522,7 +565,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
     }
   }
   if (tid == 0) head_pos[heads] = (unsigned short)m;
-  __syncthreads();
+  const int before = voxels_before();  // (its barriers publish coord / head_pos)
   VX_STAMP(3);
   // one lane per (voxel, axis): the members in sorted order = input order
   for (int q = tid; q < 3 * heads; q += VX_BLOCK) {
@@ -552,15 +595,17 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
       s += b.x; s += b.y; s += b.z; s += b.w;
     }
     for (; j < len; ++j) s += c[j];
-    float* o = reinterpret_cast<float*>(tmp + gs + r);
+    float* o = reinterpret_cast<float*>(out + before + r);
     o[axis] = s / (float)len;
     if (axis == 0) o[3] = 1.0f;
   }
   if (dbg) __syncthreads();
   VX_STAMP(4);
   if (tid == 0) {
-    group_count[g] = heads;
-    group_start[g] = gs;
+    if (g == (int)gridDim.x - 1) {
+      d_n_out[0] = before + heads;
+      d_n_out[1] = 0;
+    }
     if (dbg) {
       for (int k = 0; k < 5; ++k) dbg[g * 8 + k] = stamp[k];
       dbg[g * 8 + 5] = m;
@@ -571,38 +616,16 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
 #undef VX_STAMP
 }
 
-__global__ __launch_bounds__(256) void voxel_compact_kernel(const float4* __restrict__ tmp, const int* __restrict__ group_count,
-                                                            const int* __restrict__ group_start, float4* __restrict__ out,
-                                                            int* __restrict__ d_n_out, int* __restrict__ hist, int nbins) {
-  __shared__ int wsum[4];
-  const int g = blockIdx.x;
-  int s = 0;
-  for (int i = threadIdx.x; i < g; i += 256) s += group_count[i];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
-  __syncthreads();
-  const int before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  const int mine = group_count[g], from = group_start[g];
-  for (int r = threadIdx.x; r < mine; r += 256) out[before + r] = tmp[from + r];
-  if (g == (int)gridDim.x - 1 && threadIdx.x == 0) {
-    d_n_out[0] = before + mine;
-    d_n_out[1] = 0;
-  }
-  // leave the histogram zero for the next call
-  for (int b = g * 256 + threadIdx.x; b < nbins; b += gridDim.x * 256) hist[b] = 0;
-}
-
 }  // namespace
 
 int voxel_direct_groups(int n) { return (n + VX_QUANTUM - 1) / VX_QUANTUM; }
 size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 6 * (size_t)voxel_direct_groups(n); }
 
 // bins: voxel_direct_scratch_ints(n) ints, ALL zero before the first call (the histogram is left zero); keys: n ints; relpos: n
-// ints; comp: n 64-bit words; tmp: n points; d_n_out: 2 ints (sum = cells written); status: 1 int, 1 = not done, use the sort path.
+// ints; comp: n 64-bit words; d_n_out: 2 ints (sum = cells written); status: 1 int, non-zero = not done, use the sort path.
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
-                                    int* keys, int* relpos, unsigned long long* comp, float4* tmp, float4* out, int* d_n_out,
-                                    int* status, hipStream_t stream) {
+                                    int* keys, int* relpos, unsigned long long* comp, float4* out, int* d_n_out, int* status,
+                                    hipStream_t stream) {
   const long long ncells = (long long)divb[0] * divb[1] * divb[2];
   // buckets of cpb consecutive cells, as many of the 8192 as the index space fills (a power-of-two bucket would leave up to
   // half of them unused -- 4350 for a raw scan at 0.2 m -- and the near-field buckets twice as full)
@@ -611,8 +634,10 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   const int groups = voxel_direct_groups(n);
   int* hist = bins;
   int4* group_range = reinterpret_cast<int4*>(bins + VX_BINS + 8);
-  int* group_count = bins + VX_BINS + 8 + 4 * groups;
-  int* group_start = group_count + groups;
+  unsigned long long* published = reinterpret_cast<unsigned long long*>(bins + VX_BINS + 8 + 4 * groups);
+  static std::atomic<unsigned int> call_counter{0};
+  unsigned int epoch = ++call_counter;
+  if (epoch == 0u) epoch = ++call_counter;  // (zero is what a fresh buffer holds)
   const int blocks = (n + VX_BLOCK * VX_PPT - 1) / (VX_BLOCK * VX_PPT);
   hipLaunchKernelGGL(voxel_hist_kernel, dim3(blocks), dim3(VX_BLOCK), 0, stream, pts, n, inv_leaf, minb[0], minb[1], minb[2],
                      divb[0], divb[0] * divb[1], cpb, nbins, keys, relpos, hist);
@@ -623,8 +648,8 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   long long* dbg = nullptr;
   if (debug && hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)groups * 8 * sizeof(long long)) == hipSuccess)
     (void)hipMemsetAsync(dbg, 0, (size_t)groups * 8 * sizeof(long long), stream);
-  hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, tmp, group_count,
-                     group_start, status, dbg);
+  hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, published, epoch, out,
+                     d_n_out, hist, nbins, status, dbg);
   if (dbg) {
     std::vector<long long> h((size_t)groups * 8);
     (void)hipStreamSynchronize(stream);
@@ -642,12 +667,10 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
     std::fprintf(stderr, "[voxel] %d live groups, first start -> last end %.2f us (100 MHz clock)\n", (int)order.size(), (last - first) * 0.01);
     for (size_t k = 0; k < order.size() && k < 4; ++k) {
       const long long* r = &h[(size_t)order[k] * 8];
-      std::fprintf(stderr, "[voxel]   group %d: m %lld pad %lld (< 0: 32-bit words) heads %lld | starts at %.2f | load %.2f sort %.2f gather+scan %.2f sums %.2f us\n",
+      std::fprintf(stderr, "[voxel]   group %d: m %lld pad %lld (< 0: 32-bit words) heads %lld | starts at %.2f | load %.2f sort %.2f gather+scan+offset %.2f sums %.2f us\n",
                    order[k], r[5], r[7], r[6], (r[0] - first) * 0.01, (r[1] - r[0]) * 0.01, (r[2] - r[1]) * 0.01, (r[3] - r[2]) * 0.01, (r[4] - r[3]) * 0.01);
     }
   }
-  hipLaunchKernelGGL(voxel_compact_kernel, dim3(groups), dim3(256), 0, stream, tmp, group_count, group_start, out, d_n_out, hist,
-                     nbins);
   return hipGetLastError();
 }
 

@@ -171,7 +171,7 @@ struct icpgpu_ctx {
   icpgpu_profile prof{};
   int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
-  DeviceBuf vox_bins, vox_tmp;   // ... of the direct (no library sort) path; vox_bins starts with its self-cleaning histogram
+  DeviceBuf vox_bins;   // ... of the direct (no library sort) path; starts with its self-cleaning histogram
   void* vox_bins_zeroed = nullptr;  // the allocation (address, size) whose histogram is known to be zero
   size_t vox_bins_zeroed_cap = 0;
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
@@ -853,7 +853,6 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   bool done = false;
   if (!force_sort && n <= (1 << 21)) {
     if ((rc = ensure(c, c->vox_bins, voxel_direct_scratch_ints(n) * sizeof(int)))) return rc;
-    if ((rc = ensure(c, c->vox_tmp, (size_t)n * sizeof(float4)))) return rc;
     if (c->vox_bins_zeroed != c->vox_bins.ptr || c->vox_bins_zeroed_cap != c->vox_bins.cap) {
       HIP_TRY(c, hipMemsetAsync(c->vox_bins.ptr, 0, c->vox_bins.cap, c->stream));
       c->vox_bins_zeroed = c->vox_bins.ptr;
@@ -862,9 +861,8 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
                                              static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
-                                             static_cast<unsigned long long*>(c->vox_vals.ptr),
-                                             static_cast<float4*>(c->vox_tmp.ptr), static_cast<float4*>(out.ptr), d_ints + 6,
-                                             d_ints + 8, c->stream);
+                                             static_cast<unsigned long long*>(c->vox_vals.ptr), static_cast<float4*>(out.ptr),
+                                             d_ints + 6, d_ints + 8, c->stream);
     if (le != hipSuccess) {
       c->vox_bins_zeroed = nullptr;
       return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
@@ -1508,7 +1506,6 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->vox_temp);
   release(c->vox_ints);
   release(c->vox_bins);
-  release(c->vox_tmp);
   release(c->idx);
   release(c->d2);
   release(c->brute_seed.keys);

@@ -96,8 +96,8 @@ def test_voxel_over_capacity_falls_back_to_the_sort_path(ctx):
     cloud[1000:9000, :3] = rng.uniform(0.01, 0.19, (8000, 3)).astype(np.float32)   # 8000 points in the voxel at the origin
     got, ref = ctx.voxel_grid(cloud, 0.2), oracle.voxel_grid(cloud, 0.2)
     assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
-    # exactly at / around the capacity of one group (4096) and of one bucket (3072)
-    for m in (3071, 3072, 3073, 4095, 4096, 4097):
+    # around the capacity of one group (3840 elements) and of one bucket (3840 - 512), and the sort's padding (4096)
+    for m in (3327, 3328, 3329, 3839, 3840, 3841, 4095, 4096, 4097):
         c = np.ones((m + 500, 4), np.float32)
         c[:m, :3] = rng.uniform(0.01, 0.19, (m, 3)).astype(np.float32)
         c[m:, :3] = rng.uniform(-5, 5, (500, 3)).astype(np.float32)
@@ -110,9 +110,40 @@ def test_voxel_over_capacity_falls_back_to_the_sort_path(ctx):
 
 def test_voxel_sizes_around_the_group_quantum(ctx):
     rng = np.random.default_rng(9)
-    for n in (2, 63, 64, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 8191):
+    for n in (2, 63, 64, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 8191):
         c = np.ones((n, 4), np.float32)
         c[:, :3] = rng.uniform(-8, 8, (n, 3)).astype(np.float32)
         for leaf in (0.1, 1.5):
             got, ref = ctx.voxel_grid(c, leaf), oracle.voxel_grid(c, leaf)
             assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), (n, leaf)
+
+
+def test_voxel_narrow_and_wide_sort_words(ctx):
+    """Groups of few buckets sort 32-bit words (cell key relative to the group above the point index), the others 64-bit
+    ones: both against the oracle, on clouds that force each -- a tight cluster (narrow everywhere), the same cluster inside a
+    huge sparse volume (wide groups next to narrow ones), and duplicates of one point (equal keys, order by index only)."""
+    rng = np.random.default_rng(21)
+    tight = np.ones((60000, 4), np.float32)
+    tight[:, :3] = rng.normal(0, 1.5, (60000, 3)).astype(np.float32)
+    mixed = tight.copy()
+    mixed[::7, :3] = rng.uniform(-400, 400, (len(mixed[::7]), 3)).astype(np.float32)
+    dup = np.ones((3000, 4), np.float32)
+    dup[:, :3] = np.float32(0.123)
+    dup[1500:, :3] = rng.uniform(-3, 3, (1500, 3)).astype(np.float32)
+    for cloud in (tight, mixed, dup):
+        for leaf in (0.2, 0.35):
+            got, ref = ctx.voxel_grid(cloud, leaf), oracle.voxel_grid(cloud, leaf)
+            assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
+
+
+def test_voxel_filter_is_repeatable_across_calls_and_sizes(ctx):
+    """The direct path keeps state between calls (a self-cleaning histogram, an epoch for the published group counts): many
+    calls of changing size on one context, each against the oracle."""
+    rng = np.random.default_rng(33)
+    scene = synth.make_scene(5)
+    for rep in range(12):
+        n = int(rng.integers(100, 90000))
+        cloud = synth.scan(scene, np.eye(4), n, seed=rep) if rep % 2 else synth.make_pair(n, 10, seed=rep)[0]
+        leaf = float(rng.choice([0.1, 0.2, 0.4]))
+        got, ref = ctx.voxel_grid(cloud, leaf), oracle.voxel_grid(cloud, leaf)
+        assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), (rep, n, leaf)
