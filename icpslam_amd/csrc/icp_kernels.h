@@ -193,11 +193,13 @@ hipError_t launch_voxel_grid(const float4* pts, int n, float inv_leaf, const int
                              hipStream_t stream);
 
 // The same filter without the library sort (one distribution pass + a sort in LDS; icp_voxel.hip): bins =
-// voxel_direct_scratch_ints(n) ints, all zero before the first call; keys, relpos n ints each; comp n 64-bit words;
+// voxel_direct_scratch_ints(n) ints, all zero before the first call; published = voxel_direct_groups(n) 64-bit words used for
+// nothing else, zero before the first call; keys, relpos n ints each; comp n 64-bit words;
 // *status != 0 when a voxel bucket exceeded the LDS capacity -- nothing usable was written, run launch_voxel_grid instead.
 size_t voxel_direct_scratch_ints(int n);
+int voxel_direct_groups(int n);
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
-                                    int* keys, int* relpos, unsigned long long* comp, float4* out, int* d_n_out, int* status,
-                                    hipStream_t stream);
+                                    unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
+                                    int* d_n_out, int* status, hipStream_t stream);
 
 }  // namespace icpgpu

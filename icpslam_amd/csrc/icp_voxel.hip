@@ -619,13 +619,16 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
 }  // namespace
 
 int voxel_direct_groups(int n) { return (n + VX_QUANTUM - 1) / VX_QUANTUM; }
-size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 6 * (size_t)voxel_direct_groups(n); }
+size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 4 * (size_t)voxel_direct_groups(n); }
 
-// bins: voxel_direct_scratch_ints(n) ints, ALL zero before the first call (the histogram is left zero); keys: n ints; relpos: n
-// ints; comp: n 64-bit words; d_n_out: 2 ints (sum = cells written); status: 1 int, non-zero = not done, use the sort path.
+// bins: voxel_direct_scratch_ints(n) ints, ALL zero before the first call (the histogram is left zero); published:
+// voxel_direct_groups(n) 64-bit words that NOTHING else ever writes, zero before the first call (a word counts as this
+// call's when its upper half is this call's number: memory that once held anything else could pass for one); keys: n ints;
+// relpos: n ints; comp: n 64-bit words; d_n_out: 2 ints (sum = cells written); status: 1 int, non-zero = not done, use the
+// sort path.
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
-                                    int* keys, int* relpos, unsigned long long* comp, float4* out, int* d_n_out, int* status,
-                                    hipStream_t stream) {
+                                    unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
+                                    int* d_n_out, int* status, hipStream_t stream) {
   const long long ncells = (long long)divb[0] * divb[1] * divb[2];
   // buckets of cpb consecutive cells, as many of the 8192 as the index space fills (a power-of-two bucket would leave up to
   // half of them unused -- 4350 for a raw scan at 0.2 m -- and the near-field buckets twice as full)
@@ -634,7 +637,6 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   const int groups = voxel_direct_groups(n);
   int* hist = bins;
   int4* group_range = reinterpret_cast<int4*>(bins + VX_BINS + 8);
-  unsigned long long* published = reinterpret_cast<unsigned long long*>(bins + VX_BINS + 8 + 4 * groups);
   static std::atomic<unsigned int> call_counter{0};
   unsigned int epoch = ++call_counter;
   if (epoch == 0u) epoch = ++call_counter;  // (zero is what a fresh buffer holds)
@@ -677,7 +679,7 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
 size_t voxel_temp_bytes(int n) {
   size_t a = 0, b = 0;
   int* ip = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, a, ip, ip, ip, ip, (size_t)n, 0, 31, (hipStream_t) nullptr);
+  (void)rocprim::radix_sort_pairs(nullptr, a, ip, ip, ip, ip, (size_t)n, 0, 32, (hipStream_t) nullptr);
   (void)rocprim::exclusive_scan(nullptr, b, ip, ip, 0, (size_t)n, rocprim::plus<int>(), (hipStream_t) nullptr);
   return (a > b ? a : b) + 256;
 }
@@ -696,6 +698,9 @@ hipError_t launch_voxel_grid(const float4* pts, int n, float inv_leaf, const int
   const long long ncells = (long long)divb[0] * divb[1] * divb[2];
   while (end_bit < 31 && (1ll << end_bit) < ncells) ++end_bit;
   end_bit = end_bit < 31 ? end_bit + 1 : 31;
+  // PCL tests the float extents for overflow and indexes with the integer ones: when those are a cell wider the topmost
+  // cells' index wraps negative, and PCL's sort (signed) puts them first -- the sign bit must take part then
+  if (ncells > 0x7FFFFFFFll) end_bit = 32;
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys + n, vals, vals + n, (size_t)n, 0, end_bit, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(256), 0, stream, keys + n, n, flags);

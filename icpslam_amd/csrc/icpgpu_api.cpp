@@ -171,9 +171,11 @@ struct icpgpu_ctx {
   icpgpu_profile prof{};
   int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
-  DeviceBuf vox_bins;   // ... of the direct (no library sort) path; starts with its self-cleaning histogram
+  DeviceBuf vox_bins, vox_pub;   // ... of the direct (no library sort) path: self-cleaning histogram + group ranges; published counts
   void* vox_bins_zeroed = nullptr;  // the allocation (address, size) whose histogram is known to be zero
   size_t vox_bins_zeroed_cap = 0;
+  void* vox_pub_zeroed = nullptr;
+  size_t vox_pub_zeroed_cap = 0;
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   std::string err;
 };
@@ -851,15 +853,26 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   // take (thousands of points in one voxel) through `status`, and the library-sort path runs instead
   static const bool force_sort = [] { const char* e = std::getenv("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
   bool done = false;
-  if (!force_sort && n <= (1 << 21)) {
+  // (PCL's overflow test uses the float extents, its cell index the integer ones: when these are one cell wider the index of
+  // the topmost cells can wrap in int32 and PCL -- and the sort path, on signed keys -- puts them first.  The direct path's
+  // buckets assume keys in [0, number of cells): leave that corner to the sort path.)
+  const bool keys_may_wrap = (long long)divb[0] * divb[1] * divb[2] > (long long)INT32_MAX;
+  if (!force_sort && !keys_may_wrap && n <= (1 << 21)) {
     if ((rc = ensure(c, c->vox_bins, voxel_direct_scratch_ints(n) * sizeof(int)))) return rc;
     if (c->vox_bins_zeroed != c->vox_bins.ptr || c->vox_bins_zeroed_cap != c->vox_bins.cap) {
       HIP_TRY(c, hipMemsetAsync(c->vox_bins.ptr, 0, c->vox_bins.cap, c->stream));
       c->vox_bins_zeroed = c->vox_bins.ptr;
       c->vox_bins_zeroed_cap = c->vox_bins.cap;
     }
+    if ((rc = ensure(c, c->vox_pub, (size_t)voxel_direct_groups(n) * sizeof(unsigned long long)))) return rc;
+    if (c->vox_pub_zeroed != c->vox_pub.ptr || c->vox_pub_zeroed_cap != c->vox_pub.cap) {
+      HIP_TRY(c, hipMemsetAsync(c->vox_pub.ptr, 0, c->vox_pub.cap, c->stream));
+      c->vox_pub_zeroed = c->vox_pub.ptr;
+      c->vox_pub_zeroed_cap = c->vox_pub.cap;
+    }
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
+                                             static_cast<unsigned long long*>(c->vox_pub.ptr),
                                              static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
                                              static_cast<unsigned long long*>(c->vox_vals.ptr), static_cast<float4*>(out.ptr),
                                              d_ints + 6, d_ints + 8, c->stream);
@@ -894,6 +907,11 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
     ms += ms2;
   }
   *n_out = c->h_ints[6] + c->h_ints[7];
+  if (*n_out < 0 || *n_out > n) {
+    const int got = *n_out;
+    *n_out = 0;
+    return fail(c, ICPGPU_ERR_HIP, "voxel filter: %d cells from %d points (internal error)", got, n);
+  }
   c->prof.voxel_launches += 1;
   c->prof.voxel_ms += ms;
   c->prof.voxel_bytes += 16ull * (uint64_t)n + 16ull * (uint64_t)*n_out;
@@ -1506,6 +1524,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->vox_temp);
   release(c->vox_ints);
   release(c->vox_bins);
+  release(c->vox_pub);
   release(c->idx);
   release(c->d2);
   release(c->brute_seed.keys);

@@ -147,3 +147,18 @@ def test_voxel_filter_is_repeatable_across_calls_and_sizes(ctx):
         leaf = float(rng.choice([0.1, 0.2, 0.4]))
         got, ref = ctx.voxel_grid(cloud, leaf), oracle.voxel_grid(cloud, leaf)
         assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), (rep, n, leaf)
+
+
+def test_voxel_index_wraps_like_pcl(ctx):
+    """PCL tests the FLOAT extents for overflow but indexes with the integer ones, which can be a cell wider: the topmost
+    cells' int32 index then wraps negative and those voxels come first.  Found by scripts/voxel_campaign.py (seed 2864); the
+    oracle and the sort path reproduce it, the direct path hands such clouds over."""
+    rng = np.random.default_rng(9000 + 2864)
+    n = int(rng.integers(1, 120000))
+    leaf = float(rng.choice([0.03, 0.1, 0.2, 0.35, 0.77, 2.0, 5.0]))
+    c = np.ones((n, 4), np.float32)
+    c[:, :3] = rng.normal(0, float(rng.choice([2.0, 30.0, 300.0])), (n, 3)).astype(np.float32)
+    got, ref = ctx.voxel_grid(c, leaf), oracle.voxel_grid(c, leaf)
+    assert 0 < len(ref) < n                       # filtered, not passed through
+    assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
+    assert ref[0, 2] > ref[1, 2] + 100            # the wrapped voxel: highest z, first in the output
