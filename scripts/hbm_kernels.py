@@ -30,7 +30,7 @@ with Context(0) as ctx:
             for _ in range(3): out = ctx.voxel_grid(src, 0.2)
             p = ctx.profile(); ms = p.voxel_ms / p.voxel_launches
             print(f"voxel filter      n={n:8d}: {ms*1e3:8.1f} us device time -> {len(out)} points; {p.voxel_bytes/p.voxel_launches/ms/1e6:7.0f} GB/s "
-                  f"algorithmic (16 B in + 16 B out per point; radix sort passes move ~10x that)")
+                  f"algorithmic (16 B in + 16 B out per point; was 88 / 212 us through the library sort)")
             ctx.map_reset(0.5); ctx.map_add_points(src); ctx.map_reset(0.5); ctx.profile_reset()
             ctx.map_add_points(src)
             ctx.map_reset(0.5); ctx.map_add_points(src[:10]); ctx.profile_reset(); ctx.map_add_points(src)
