@@ -554,25 +554,36 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
   return hipGetLastError();
 }
 
-int gicp_direct_blocks(int n_s) {
+int gicp_direct_blocks(int n_s, int most) {
+  // ICPGPU_GICP_BLOCKS (tuning): the most workgroups an evaluation may use.  64 until round 2; with one workgroup per 1024
+  // points up to 256 a 200k x 200k registration takes 3.9 instead of 4.45 ms (12 instead of 15 us per evaluation: the
+  // workgroups' share shrinks faster than the host's merge of their partial sums grows).  Keeping each lane's
+  // correspondences in registers for the whole run of the server was measured too (no memory reads per evaluation):
+  // slower -- 298 registers, one wave per SIMD; the reads come from the Infinity Cache and were not what an evaluation waits for.
+  static const int cap = [] {
+    const char* e = std::getenv("ICPGPU_GICP_BLOCKS");
+    const int v = e ? std::atoi(e) : kGicpDirectBlocks;
+    return v < 1 ? 1 : (v > kGicpDirectBlocks ? kGicpDirectBlocks : v);
+  }();
   int blocks = (n_s + 1023) / 1024;  // >= 4 points per thread: the grid-stride loop keeps the few workgroups busy
-  if (blocks > kGicpDirectBlocks) blocks = kGicpDirectBlocks;
+  if (blocks > cap) blocks = cap;
+  if (blocks > most) blocks = most;  // (the caller's share of the chip: several contexts' servers must all be resident)
   if (blocks < 1) blocks = 1;
   return blocks;
 }
 
-hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                                    const Xform& T, const Xform& base, const double* maha6, double* host_partials,
                                    unsigned long long* host_flags, unsigned long long seq, hipStream_t stream) {
-  hipLaunchKernelGGL(gicp_cost_kernel, dim3(gicp_direct_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base,
+  hipLaunchKernelGGL(gicp_cost_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, T, base,
                      maha6, host_partials, host_flags, seq);
   return hipGetLastError();
 }
 
-hipError_t launch_gicp_server(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
                               unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream) {
-  hipLaunchKernelGGL(gicp_server_kernel, dim3(gicp_direct_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base,
+  hipLaunchKernelGGL(gicp_server_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base,
                      maha6, host_partials, host_flags, cmd, first_seq, seq_hi);
   return hipGetLastError();
 }

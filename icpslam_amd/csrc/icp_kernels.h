@@ -143,11 +143,11 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
 // One BFGS function/gradient evaluation: at most kGicpDirectBlocks workgroups, each stores its partial sums straight into
 // host-mapped memory (host_partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = high parts of sum r^T M r, sum M r
 // (3), sum (base p)(M r)^T (9), [14] = sum d2, [16..28] = the 13 low parts -- the sums are double-double, see icp_gicp.hip)
-// followed by host_flags[block] = seq; the host adds the partials in block order.  gicp_direct_blocks(n_s) = workgroups.
+// followed by host_flags[block] = seq; the host adds the partials in block order.  blocks = gicp_direct_blocks(n_s, share).
 static constexpr int kGicpPartialStride = 32;
-static constexpr int kGicpDirectBlocks = 64;
-int gicp_direct_blocks(int n_s);
-hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+static constexpr int kGicpDirectBlocks = 256;  // capacity of the mailbox; gicp_direct_blocks() may use fewer
+int gicp_direct_blocks(int n_s, int most = kGicpDirectBlocks);
+hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                                    const Xform& T, const Xform& base, const double* maha6, double* host_partials,
                                    unsigned long long* host_flags, unsigned long long seq, hipStream_t stream);
 
@@ -156,7 +156,7 @@ hipError_t launch_gicp_cost_direct(const float4* src, int n_s, const float4* tgt
 // host_partials / host_flags like the direct kernel (flag = seq_hi << 32 | sequence number) and leaves on sequence number
 // kGicpServerExit (acknowledged by host_flags[0] = ~0) or after 50 ms without a command.
 static constexpr unsigned int kGicpServerExit = 0xFFFFFFFFu;
-hipError_t launch_gicp_server(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
                               unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream);
 

@@ -157,6 +157,7 @@ struct icpgpu_ctx {
   unsigned int* gicp_cmd = nullptr;
   bool gicp_server_on = false;
   bool gicp_server_allowed = true;  // align_batch with more than kMaxServerWorkers threads: single launches (below)
+  int gicp_blocks_most = kGicpDirectBlocks;  // workgroups per cost evaluation: the whole chip, or this worker's share of it
   // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
   std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
   struct PendingSweep { int slot; bool grid; };
@@ -1134,7 +1135,7 @@ static int gicp_server_start(icpgpu_ctx* c, int n_s, const unsigned long long* k
   }
   Xform none{};
   gicp_server_command(c, next - 1u, none);  // a number the server does not wait for: the line may still hold an old exit
-  HIP_TRY(c, launch_gicp_server(c->src.data(), n_s, c->tgt.data(), keys, thr, base, maha, c->h_gicp_dev, c->h_gicp_flags_dev,
+  HIP_TRY(c, launch_gicp_server(gicp_direct_blocks(n_s, c->gicp_blocks_most), c->src.data(), n_s, c->tgt.data(), keys, thr, base, maha, c->h_gicp_dev, c->h_gicp_flags_dev,
                                 c->gicp_cmd, next, (unsigned int)((c->sums_seq + 1) >> 32), c->stream));
   c->gicp_server_on = true;
   return ICPGPU_OK;
@@ -1265,7 +1266,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       // polled host mailbox; the host adds them in workgroup order (deterministic)
       unsigned long long seq = ++c->sums_seq;
       if ((unsigned int)seq == kGicpServerExit) seq = (c->sums_seq += 2);  // (never a command number; the server skips it too)
-      const int nblk = gicp_direct_blocks(n_s);
+      const int nblk = gicp_direct_blocks(n_s, c->gicp_blocks_most);
       bool have = false;
       if (c->gicp_server_on) {  // the resident server evaluates; no launch
         gicp_server_command(c, (unsigned int)seq, xform_from_f16(T));
@@ -1276,7 +1277,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         if (!have && std::getenv("ICPGPU_DEBUG")) fprintf(stderr, "[icpgpu] gicp server gave up at evaluation %llu\n", seq);
       }
       if (!have) {
-        if (launch_gicp_cost_direct(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
+        if (launch_gicp_cost_direct(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
                                     c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
           return false;
         if (wait_flags(c, c->h_gicp_flags, nblk, seq) != ICPGPU_OK) return false;
@@ -1747,10 +1748,13 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     for (size_t s = 0; s < depth; ++s) {
       ws[s]->params = c->params;
       ws[s]->nn_variant = c->nn_variant;
-      // Every GICP worker's BFGS runs keep up to 64 workgroups resident and a host thread spinning.  8 workers fit the chip
+      // Every GICP worker's BFGS runs keep its workgroups resident and a host thread spinning.  8 workers fit the chip
       // with room for everybody's searches; 16 were measured 5x SLOWER than single launches (servers wait for slots other
       // servers hold until their 50 ms patience runs out).
       ws[s]->gicp_server_allowed = n_threads <= kMaxServerWorkers;
+      // ... and each worker's evaluations get their share of the ~512 workgroups of that size the chip holds at once (64
+      // apiece for 8 workers, as measured in round 1; a lone alignment uses up to 256)
+      ws[s]->gicp_blocks_most = std::max(16, std::min(kGicpDirectBlocks, 512 / (int)std::max<size_t>(1, n_threads)));
     }
     if (gicp) {  // one blocking alignment after the other
       icpgpu_ctx* w = ws[0];
