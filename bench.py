@@ -281,17 +281,19 @@ def main():
         # laserCloudCallback does per scan inside the timed region (icp_odometer.cpp:188-210) -- setInputSource from a HOST
         # buffer (H2D copy), the per-scan index build, align, getFitnessScore, *prev_cloud_ = *curr_cloud_ -- over
         # alternating scans A, B, A, ... so that every pair has a new source and a new target index.
-        def odometry_loop(n_pairs, **params):
+        def odometry_loop(n_pairs, voxel_leaf=None, **params):
             ctx.set_params(**params)
             clouds = (src, tgt)
-            ctx.set_source(clouds[1])
+            # voxel_leaf: the scan goes through the voxel filter on its way in (icp_odometer.cpp:96-101,177), on the device
+            put = (lambda cl: ctx.set_source_voxel_filtered(cl, voxel_leaf)) if voxel_leaf else ctx.set_source
+            put(clouds[1])
             ctx.promote_source_to_target()
             for k in range(2):                      # warm-up (buffers of both roles allocated)
-                ctx.set_source(clouds[k % 2]); ctx.align(want_fitness=True); ctx.promote_source_to_target()
+                put(clouds[k % 2]); ctx.align(want_fitness=True); ctx.promote_source_to_target()
             torch.cuda.synchronize()
             t = time.perf_counter()
             for k in range(n_pairs):
-                ctx.set_source(clouds[k % 2])
+                put(clouds[k % 2])
                 ctx.align(want_fitness=True)
                 ctx.promote_source_to_target()
             torch.cuda.synchronize()
@@ -314,9 +316,16 @@ def main():
             "getFitnessScore on a resident pair, target index reused")
         # (2) the solver the reference literally instantiates (GICP, icp_odometer.cpp:188) on the same raw pair, same loop
         gicp = odometry_loop(max(3, n_e2e // 3), method=GICP, max_iterations=a.iters, force_iterations=0)
+        # (3) ... and the reference's whole per-scan pipeline: VoxelGrid at icpslam.yaml's 0.2 m in front of it
+        leaf = 0.2
+        pipeline = odometry_loop(max(4, n_e2e // 2), voxel_leaf=leaf, method=GICP, max_iterations=a.iters, force_iterations=0)
         extras["gicp"] = {"scan_pairs_per_sec_e2e": gicp,
                           "def": f"the same odometry loop with method = GICP (<= {a.iters} outer iterations, BFGS inner "
-                                 "solver): what pcl::GeneralizedIterativeClosestPoint at icp_odometer.cpp:188 runs per scan"}
+                                 "solver): what pcl::GeneralizedIterativeClosestPoint at icp_odometer.cpp:188 runs per scan",
+                          "reference_pipeline_scans_per_sec": pipeline,
+                          "reference_pipeline_def": f"per scan: VoxelGrid({leaf} m) of the raw {n_s}-point scan on the device "
+                                                    f"(-> {ctx.n_target} points), then the GICP loop above on the filtered clouds: "
+                                                    "laserCloudCallback's registration work (icp_odometer.cpp:96-101,177-210)"}
         ctx.set_params(ctx.default_params(), max_iterations=a.iters, force_iterations=1, nn_mode=nn_mode)
         ctx.set_source(src); ctx.set_target(tgt)
 

@@ -28,6 +28,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(d["value"] - 1e3 * d["config"]["iters_per_step"] / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert d["scan_pairs_per_sec_e2e"] > 0 and d["gicp"]["scan_pairs_per_sec_e2e"] > 0   # the odometer's per-scan protocol
+    assert d["gicp"]["reference_pipeline_scans_per_sec"] > 0          # ... with VoxelGrid 0.2 m in front of it
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
