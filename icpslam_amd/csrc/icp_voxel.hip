@@ -429,7 +429,8 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
                                                                unsigned long long* __restrict__ published,
                                                                unsigned int epoch, float4* __restrict__ out,
                                                                int* __restrict__ d_n_out, int* __restrict__ hist, int nbins,
-                                                               int* __restrict__ status, long long* __restrict__ dbg) {
+                                                               int* __restrict__ status, long long* __restrict__ dbg,
+                                                               int test_stall) {
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #define VX_STAMP(k) do { if (dbg && threadIdx.x == 0) stamp[k] = (long long)wall_clock64(); } while (0)
   VX_STAMP(0);
@@ -452,6 +453,10 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
   // microseconds.  Workgroups start in index order and none waits for a later one, so the wait cannot deadlock; 20 ms
   // without an answer gives up (status 2: the host runs the sort path).
   auto publish = [&](int count) {
+    if (test_stall && g == 0 && tid == 0) {  // test hook: group 0 answers after everybody's patience has run out
+      const long long t0 = (long long)wall_clock64();
+      while ((long long)wall_clock64() - t0 < 3000000) __builtin_amdgcn_s_sleep(64);
+    }
     if (tid == 0)
       __hip_atomic_store(&published[g], ((unsigned long long)epoch << 32) | (unsigned int)count, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
@@ -650,8 +655,10 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   long long* dbg = nullptr;
   if (debug && hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)groups * 8 * sizeof(long long)) == hipSuccess)
     (void)hipMemsetAsync(dbg, 0, (size_t)groups * 8 * sizeof(long long), stream);
+  // ICPGPU_VOXEL_TEST_STALL=1 (tests): the first group publishes 30 ms late -- the others give up, the sort path takes over
+  static const int test_stall = [] { const char* e = std::getenv("ICPGPU_VOXEL_TEST_STALL"); return e ? std::atoi(e) : 0; }();
   hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, published, epoch, out,
-                     d_n_out, hist, nbins, status, dbg);
+                     d_n_out, hist, nbins, status, dbg, test_stall);
   if (dbg) {
     std::vector<long long> h((size_t)groups * 8);
     (void)hipStreamSynchronize(stream);

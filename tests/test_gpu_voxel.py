@@ -162,3 +162,24 @@ def test_voxel_index_wraps_like_pcl(ctx):
     assert 0 < len(ref) < n                       # filtered, not passed through
     assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
     assert ref[0, 2] > ref[1, 2] + 100            # the wrapped voxel: highest z, first in the output
+
+
+def test_voxel_published_count_timeout_hands_over_to_the_sort_path(tmp_path):
+    """The groups of the direct path wait for their predecessors' published counts; a count that never comes (here: group 0
+    answers 30 ms late, a test hook) must end in the sort path's result, not in a hang or a wrong cloud."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np, oracle\n"
+        "from icpslam_amd import Context, synth\n"
+        "c = synth.scan(synth.make_scene(2), np.eye(4), 30000, seed=1)\n"
+        "with Context(0) as ctx:\n"
+        "    for leaf in (0.2, 0.4):\n"
+        "        got, ref = ctx.voxel_grid(c, leaf), oracle.voxel_grid(c, leaf)\n"
+        "        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))\n"
+        "print('ok')\n")
+    env = dict(os.environ, ICPGPU_VOXEL_TEST_STALL="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
