@@ -479,7 +479,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
     if (!ok) *status = 2;
     int total = 0;
     (void)block_exclusive_scan_1024(part, wsum, &total);
-    return total;
+    return __syncthreads_or(ok ? 0 : 1) ? -1 : total;  // -1: no offset (whatever the stale words held must not place a write)
   };
   if (m <= 0 || m > VX_CAP) {
     publish(0);
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
     if (g == (int)gridDim.x - 1) {  // the last group reports the number of cells
       const int before = voxels_before();
       if (tid == 0) {
-        d_n_out[0] = before;
+        d_n_out[0] = max(before, 0);
         d_n_out[1] = 0;
       }
     }
@@ -571,6 +571,10 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
   }
   if (tid == 0) head_pos[heads] = (unsigned short)m;
   const int before = voxels_before();  // (its barriers publish coord / head_pos)
+  if (before < 0) {  // gave up waiting (status 2): nothing is written, the host runs the sort path
+    if (tid == 0 && g == (int)gridDim.x - 1) d_n_out[0] = d_n_out[1] = 0;
+    return;
+  }
   VX_STAMP(3);
   // one lane per (voxel, axis): the members in sorted order = input order
   for (int q = tid; q < 3 * heads; q += VX_BLOCK) {
