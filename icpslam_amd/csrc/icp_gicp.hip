@@ -360,63 +360,78 @@ struct GicpAcc {
   DD s[kGicpSums];
 };
 
+// Four correspondences of a lane (positions i0, i0 + stride, ...): everything an evaluation reads from memory.  Their loads
+// are issued together: key -> (target point, Mahalanobis matrix) is a dependent chain of random reads, and one after the
+// other they made the evaluation 14-16 us long (latency, not bandwidth).
+struct GicpQuad {
+  bool use[4];
+  float d2[4];
+  float4 s[4], q[4];
+  double M[4][6];
+};
+__device__ __forceinline__ void gicp_load_quad(GicpQuad& L, int i0, int stride, const float4* __restrict__ src, int n_s,
+                                               const float4* __restrict__ tgt, const unsigned long long* __restrict__ keys,
+                                               float thr, const double* __restrict__ maha6) {
+  unsigned long long key[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u * stride;
+    key[u] = i < n_s ? keys[i] : kEmptyKey;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = min(i0 + u * stride, n_s - 1);
+    const unsigned int j = (unsigned int)key[u];
+    L.d2[u] = __uint_as_float((unsigned int)(key[u] >> 32));
+    L.use[u] = j != 0xFFFFFFFFu && L.d2[u] < thr;
+    L.s[u] = src[i];
+    L.q[u] = tgt[L.use[u] ? j : 0u];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L.M[u][k] = maha6[(size_t)i * 6 + k];
+  }
+}
+__device__ __forceinline__ void gicp_add_quad(GicpAcc& acc, const GicpQuad& L, const Xform& T, const Xform& base) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (!L.use[u]) continue;
+    const float4 s = L.s[u], q = L.q[u];
+    float px, py, pz, bx, by, bz;
+    xform_point(T, s.x, s.y, s.z, px, py, pz);
+    xform_point(base, s.x, s.y, s.z, bx, by, bz);
+    const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);
+    const double t0 = L.M[u][0] * r0 + L.M[u][1] * r1 + L.M[u][2] * r2;
+    const double t1 = L.M[u][1] * r0 + L.M[u][3] * r1 + L.M[u][4] * r2;
+    const double t2 = L.M[u][2] * r0 + L.M[u][4] * r1 + L.M[u][5] * r2;
+    acc.m += 1.0;
+    dd_add_term(acc.s[0], r0 * t0 + r1 * t1 + r2 * t2);
+    dd_add_term(acc.s[1], t0);
+    dd_add_term(acc.s[2], t1);
+    dd_add_term(acc.s[3], t2);
+    const double pb[3] = {(double)bx, (double)by, (double)bz};
+    const double tt[3] = {t0, t1, t2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dd_add_term(acc.s[4 + 3 * r + c], pb[r] * tt[c]);
+    acc.d2 += (double)L.d2[u];
+  }
+}
+__device__ __forceinline__ void gicp_clear(GicpAcc& acc) {
+  acc.m = acc.d2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < kGicpSums; ++k) acc.s[k].hi = acc.s[k].lo = 0.0;
+}
+
 __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __restrict__ src, int n_s,
                                                 const float4* __restrict__ tgt,
                                                 const unsigned long long* __restrict__ keys, float thr, const Xform& T,
                                                 const Xform& base, const double* __restrict__ maha6) {
-  acc.m = acc.d2 = 0.0;
-#pragma unroll
-  for (int k = 0; k < kGicpSums; ++k) acc.s[k].hi = acc.s[k].lo = 0.0;
-  // Four correspondences per lane and trip, their loads issued together: key -> (target point, Mahalanobis matrix) is a
-  // dependent chain of random reads, and with <= 64 workgroups in direct mode every lane owns several correspondences --
-  // one after the other they made this kernel 14-16 us long (latency, not bandwidth).
+  gicp_clear(acc);
   const int stride = gridDim.x * 256;
   for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n_s; i0 += 4 * stride) {
-    unsigned long long key[4];
-    bool use[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * stride;
-      key[u] = i < n_s ? keys[i] : kEmptyKey;
-    }
-    float4 sv[4], qv[4];
-    double M[4][6];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = min(i0 + u * stride, n_s - 1);
-      const unsigned int j = (unsigned int)key[u];
-      const float d2 = __uint_as_float((unsigned int)(key[u] >> 32));
-      use[u] = j != 0xFFFFFFFFu && d2 < thr;
-      sv[u] = src[i];
-      qv[u] = tgt[use[u] ? j : 0u];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) M[u][k] = maha6[(size_t)i * 6 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!use[u]) continue;
-      const float4 s = sv[u], q = qv[u];
-      const float d2 = __uint_as_float((unsigned int)(key[u] >> 32));
-      float px, py, pz, bx, by, bz;
-      xform_point(T, s.x, s.y, s.z, px, py, pz);
-      xform_point(base, s.x, s.y, s.z, bx, by, bz);
-      const double r0 = (double)(px - q.x), r1 = (double)(py - q.y), r2 = (double)(pz - q.z);
-      const double t0 = M[u][0] * r0 + M[u][1] * r1 + M[u][2] * r2;
-      const double t1 = M[u][1] * r0 + M[u][3] * r1 + M[u][4] * r2;
-      const double t2 = M[u][2] * r0 + M[u][4] * r1 + M[u][5] * r2;
-      acc.m += 1.0;
-      dd_add_term(acc.s[0], r0 * t0 + r1 * t1 + r2 * t2);
-      dd_add_term(acc.s[1], t0);
-      dd_add_term(acc.s[2], t1);
-      dd_add_term(acc.s[3], t2);
-      const double pb[3] = {(double)bx, (double)by, (double)bz};
-      const double tt[3] = {t0, t1, t2};
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dd_add_term(acc.s[4 + 3 * r + c], pb[r] * tt[c]);
-      acc.d2 += (double)d2;
-    }
+    GicpQuad L;
+    gicp_load_quad(L, i0, stride, src, n_s, tgt, keys, thr, maha6);
+    gicp_add_quad(acc, L, T, base);
   }
 }
 
@@ -489,6 +504,7 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
 // share and stores its 17 partials + flag into the host mailbox exactly like gicp_cost_kernel's direct mode.  Sequence
 // number kGicpServerExit ends the run; so does 50 ms without a command (the host fell asleep or died: never leave a
 // spinning kernel behind -- the host notices the idle stream and goes back to single launches).
+template <bool RESIDENT>
 __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restrict__ src, int n_s,
                                                           const float4* __restrict__ tgt,
                                                           const unsigned long long* __restrict__ keys, float thr, Xform base,
@@ -499,6 +515,11 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
   __shared__ unsigned int s_seq;
   const long long patience = 5000000;  // 50 ms of the 100 MHz wall clock
   unsigned int expect = first_seq;
+  // RESIDENT (small problems: every lane's share is one quad): the correspondences do not change during a run, so they are
+  // read ONCE and stay in registers -- an evaluation then starts without the key -> (target point, matrix) chain of reads.
+  // (For large clouds this was measured slower: 298 registers, one wave per SIMD; there the reads are not what is waited for.)
+  GicpQuad mine;
+  if constexpr (RESIDENT) gicp_load_quad(mine, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, src, n_s, tgt, keys, thr, maha6);
   for (;;) {
     if (threadIdx.x < 64) {
       // lane k < 13 reads word k of the line, all in ONE coalesced read per poll (the line is uncached: every load reads
@@ -527,7 +548,12 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
     }
     const Xform T = s_T;
     GicpAcc acc;
-    gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
+    if constexpr (RESIDENT) {
+      gicp_clear(acc);
+      gicp_add_quad(acc, mine, T, base);
+    } else {
+      gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
+    }
     gicp_block_reduce_store(acc, host_partials);
     if (threadIdx.x == 0)
       __hip_atomic_store(&host_flags[blockIdx.x], ((unsigned long long)seq_hi << 32) | seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -558,8 +584,8 @@ int gicp_direct_blocks(int n_s, int most) {
   // ICPGPU_GICP_BLOCKS (tuning): the most workgroups an evaluation may use.  64 until round 2; with one workgroup per 1024
   // points up to 256 a 200k x 200k registration takes 3.9 instead of 4.45 ms (12 instead of 15 us per evaluation: the
   // workgroups' share shrinks faster than the host's merge of their partial sums grows).  Keeping each lane's
-  // correspondences in registers for the whole run of the server was measured too (no memory reads per evaluation):
-  // slower -- 298 registers, one wave per SIMD; the reads come from the Infinity Cache and were not what an evaluation waits for.
+  // correspondences in registers for the whole run of the server (gicp_server_kernel<true>) is slower at this size -- 298
+  // registers, one wave per SIMD -- and faster below 64k points (launch_gicp_server picks).
   static const int cap = [] {
     const char* e = std::getenv("ICPGPU_GICP_BLOCKS");
     const int v = e ? std::atoi(e) : kGicpDirectBlocks;
@@ -583,8 +609,14 @@ hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
                               unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream) {
-  hipLaunchKernelGGL(gicp_server_kernel, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base,
-                     maha6, host_partials, host_flags, cmd, first_seq, seq_hi);
+  // every lane's share fits one quad and the problem is small enough for the registers to pay (ICPGPU_GICP_RESIDENT_MAX, tuning)
+  static const int resident_max = [] { const char* e = std::getenv("ICPGPU_GICP_RESIDENT_MAX"); return e ? std::atoi(e) : 65536; }();
+  if ((long long)blocks * 1024 >= n_s && n_s <= resident_max)
+    hipLaunchKernelGGL(gicp_server_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
+                       host_partials, host_flags, cmd, first_seq, seq_hi);
+  else
+    hipLaunchKernelGGL(gicp_server_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
+                       host_partials, host_flags, cmd, first_seq, seq_hi);
   return hipGetLastError();
 }
 
