@@ -3,10 +3,13 @@
 // Replaces pcl::VoxelGrid<PointXYZ>::filter as the reference calls it in IcpOdometer::voxelFilterCloud
 // (/root/reference/src/icpslam/icp_odometer.cpp:96-101, leaf 0.2 m in /root/reference/config/icpslam.yaml:14):
 // cell index = (floor(x/L) - min_b) . (1, div_x, div_x*div_y); one output point per occupied cell = arithmetic mean of
-// its points; output ordered by ascending cell index.  HBM-bound: 16 B read + 8 B (key, index) written per point, a
-// 4-pass 8-bit LSD radix sort over the 31-bit keys (rocPRIM device primitive -- stable, so points of a cell stay in
-// input order and the float32 mean is accumulated in exactly the oracle's order), boundary flags + scan, one gather
-// pass.  Same float32 arithmetic as oracle/icp_oracle.c::orc_voxel_grid, so the output is bit-identical to it.
+// its points, added in INPUT order (float32: the order is part of the result); output ordered by ascending cell index.
+// Two paths, same float32 arithmetic as oracle/icp_oracle.c::orc_voxel_grid, output bit-identical to it:
+//   * the direct path (round 2, below): one bucket-distribution pass + a register-resident bitonic sort of LDS-sized groups --
+//     three hand-written launches, 37 us for a raw 200k-point scan;
+//   * the library-sort path (round 1): rocPRIM's stable radix sort over the 31-bit keys (32 when the index wraps, see
+//     launch_voxel_grid), boundary flags + scan, one gather pass -- 14 launches, 105 us; kept for what the direct path hands
+//     over (a voxel bucket beyond its LDS capacity, wrapped indices, clouds over 2M points).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
