@@ -438,7 +438,16 @@ __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __re
 // Workgroup reduction of the lanes' accumulators into partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = the
 // sums' high parts, [14] = sum d2, [16..28] = their low parts.  The 13 double-double sums go through LDS: thread
 // (sum, chunk) adds the 16 lanes of its chunk in lane order, then thread `sum` adds the 16 chunk results in order.
-__device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, double* __restrict__ partials) {
+__device__ __forceinline__ void gicp_store_tagged(double* __restrict__ out, int entry, double value, unsigned long long tag) {
+  // ONE 16-byte store, written through to system memory (sc0 sc1): the server kernel never ends, nothing else would push
+  // a cached line out, and a release fence is exactly what this protocol is there to avoid
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(value);
+  const u32x4 v = {(unsigned int)bits, (unsigned int)(bits >> 32), (unsigned int)tag, (unsigned int)(tag >> 32)};
+  double* p = out + 2 * entry;
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, double* __restrict__ partials, unsigned long long tag) {
   __shared__ DD s_lane[kGicpSums][16][17];  // [sum][lane % 16][lane / 16], rows padded: neither the writes (a lane per
                                             // thread) nor the reads (a chunk per thread) pile up on one LDS bank
   __shared__ DD s_chunk[kGicpSums][16];
@@ -470,11 +479,11 @@ __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, doub
     DD v = x[0];
 #pragma unroll
     for (int c = 1; c < 16; ++c) v = dd_add(v, x[c]);
-    out[1 + threadIdx.x] = v.hi;
-    out[16 + threadIdx.x] = v.lo;
+    gicp_store_tagged(out, 1 + threadIdx.x, v.hi, tag);
+    gicp_store_tagged(out, 16 + threadIdx.x, v.lo, tag);
   } else if (threadIdx.x == kGicpSums) {
-    out[0] = (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]);
-    out[14] = (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]);
+    gicp_store_tagged(out, 0, (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]), tag);
+    gicp_store_tagged(out, 14, (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]), tag);
   }
 }
 
@@ -489,8 +498,8 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
                                                         unsigned long long seq) {
   GicpAcc acc;
   gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
-  gicp_block_reduce_store(acc, partials);
-  if (threadIdx.x == 0) __hip_atomic_store(&flags[blockIdx.x], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  (void)flags;
+  gicp_block_reduce_store(acc, partials, seq);
 }
 
 // ---- resident evaluation server ------------------------------------------------------------------------------------
@@ -513,6 +522,7 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
                                                           unsigned int first_seq, unsigned int seq_hi) {
   __shared__ Xform s_T;
   __shared__ unsigned int s_seq;
+  __shared__ long long s_seen;
   const long long patience = 5000000;  // 50 ms of the 100 MHz wall clock
   unsigned int expect = first_seq;
   // RESIDENT (small problems: every lane's share is one quad): the correspondences do not change during a run, so they are
@@ -521,6 +531,7 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
   GicpQuad mine;
   if constexpr (RESIDENT) gicp_load_quad(mine, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, src, n_s, tgt, keys, thr, maha6);
   for (;;) {
+    const long long t_loop = (long long)wall_clock64();
     if (threadIdx.x < 64) {
       // lane k < 13 reads word k of the line, all in ONE coalesced read per poll (the line is uncached: every load reads
       // memory).  The words of T were posted before the number, so a read that returns the number returns them too.
@@ -536,7 +547,10 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
         if ((long long)wall_clock64() - t0 > patience) break;  // got stays kGicpServerExit
       }
       if (threadIdx.x < 12) s_T.m[threadIdx.x] = __uint_as_float(word);
-      if (threadIdx.x == 12) s_seq = got;
+      if (threadIdx.x == 12) {
+        s_seq = got;
+        s_seen = (long long)wall_clock64();
+      }
     }
     __syncthreads();
     const unsigned int seq = s_seq;
@@ -554,9 +568,12 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
     } else {
       gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
     }
-    gicp_block_reduce_store(acc, host_partials);
-    if (threadIdx.x == 0)
-      __hip_atomic_store(&host_flags[blockIdx.x], ((unsigned long long)seq_hi << 32) | seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (development, ICPGPU_GICP_TIMING: two spare entries of the mailbox)
+      const long long t_now = (long long)wall_clock64();
+      host_partials[2 * 30] = (double)(s_seen - t_loop) * 0.01;   // polling
+      host_partials[2 * 31] = (double)(t_now - s_seen) * 0.01;    // work up to the reduction
+    }
+    gicp_block_reduce_store(acc, host_partials, ((unsigned long long)seq_hi << 32) | seq);
     expect = seq + 1u;
     if (expect == kGicpServerExit) expect = 0u;
     __syncthreads();  // s_T / s_seq are rewritten in the next round

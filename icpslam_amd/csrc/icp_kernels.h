@@ -144,7 +144,11 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
 // host-mapped memory (host_partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = high parts of sum r^T M r, sum M r
 // (3), sum (base p)(M r)^T (9), [14] = sum d2, [16..28] = the 13 low parts -- the sums are double-double, see icp_gicp.hip)
 // followed by host_flags[block] = seq; the host adds the partials in block order.  blocks = gicp_direct_blocks(n_s, share).
-static constexpr int kGicpPartialStride = 32;
+// Since round 2 every value travels WITH its sequence number: entry e of a block is the 16-byte pair {value, tag} at doubles
+// [2e, 2e + 1], written by ONE 16-byte store -- a pair is never seen half-written, so no flag and no system-scope release
+// (a write-back + a wait for the earlier stores' acknowledgements, 1-1.5 us) stands between the sums and the host; the host
+// takes a block's entry when its tag equals the evaluation's number.
+static constexpr int kGicpPartialStride = 64;
 static constexpr int kGicpDirectBlocks = 256;  // capacity of the mailbox; gicp_direct_blocks() may use fewer
 int gicp_direct_blocks(int n_s, int most = kGicpDirectBlocks);
 hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,

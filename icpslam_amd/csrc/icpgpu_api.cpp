@@ -157,7 +157,11 @@ struct icpgpu_ctx {
   unsigned int* gicp_cmd = nullptr;
   bool gicp_server_on = false;
   bool gicp_server_allowed = true;  // align_batch with more than kMaxServerWorkers threads: single launches (below)
-  int gicp_blocks_most = kGicpDirectBlocks;  // workgroups per cost evaluation: the whole chip, or this worker's share of it
+  int gicp_blocks_most = kGicpDirectBlocks;
+  // ICPGPU_GICP_TIMING=1 (development): where an evaluation's microseconds go, printed when the context is destroyed
+  double gt_cmd = 0, gt_wait = 0, gt_merge = 0, gt_between = 0, gt_dev_wait = 0, gt_dev_work = 0;
+  unsigned long long gt_n = 0;
+  std::chrono::steady_clock::time_point gt_last{};  // workgroups per cost evaluation: the whole chip, or this worker's share of it
   // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
   std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
   struct PendingSweep { int slot; bool grid; };
@@ -1156,20 +1160,32 @@ static void gicp_server_stop(icpgpu_ctx* c) {
 }
 
 // 0: the flags arrived; 1: the stream went idle without them (the server gave up waiting); < 0: error
-static int wait_flags_server(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_flags, unsigned long long seq) {
+// The entries a block publishes (icp_kernels.h: {value, tag} pairs): m, the 13 sums' high parts, sum d2, their low parts.
+static const int kGicpEntries[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
+static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
+  const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(mailbox);
+  bool all = true;
+  for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
+    for (int e : kGicpEntries) all = all && (w[2 * e + 1] == seq);
+  return all;
+}
+// 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
+static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, bool server) {
+  std::chrono::steady_clock::time_point t0;
   for (unsigned spins = 1;; ++spins) {
-    bool all = true;
-    for (int k = 0; k < n_flags; ++k) all = all && (flags[k] == seq);
-    if (all) break;
+    if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) break;
     if ((spins & 0x3FFu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {
-        bool ok = true;
-        for (int k = 0; k < n_flags; ++k) ok = ok && (flags[k] == seq);
-        if (ok) break;
-        return 1;
+        if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) break;
+        if (server) return 1;
+        return fail(c, ICPGPU_ERR_HIP, "GICP evaluation finished without publishing its result");
       }
       if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a GICP evaluation: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a GICP evaluation (hung kernel?)", wait_timeout_ms());
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
@@ -1268,9 +1284,17 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       if ((unsigned int)seq == kGicpServerExit) seq = (c->sums_seq += 2);  // (never a command number; the server skips it too)
       const int nblk = gicp_direct_blocks(n_s, c->gicp_blocks_most);
       bool have = false;
+      static const bool timing = [] { const char* e = std::getenv("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
+      std::chrono::steady_clock::time_point tq0, tq1, tq2;
+      if (timing) {
+        tq0 = std::chrono::steady_clock::now();
+        if (c->gt_n && c->gicp_server_on) c->gt_between += std::chrono::duration<double, std::micro>(tq0 - c->gt_last).count();
+      }
       if (c->gicp_server_on) {  // the resident server evaluates; no launch
         gicp_server_command(c, (unsigned int)seq, xform_from_f16(T));
-        const int w = wait_flags_server(c, c->h_gicp_flags, nblk, seq);
+        if (timing) tq1 = std::chrono::steady_clock::now();
+        const int w = wait_gicp_tags(c, nblk, seq, /*server=*/true);
+        if (timing) tq2 = std::chrono::steady_clock::now();
         if (w < 0) return false;
         have = w == 0;
         if (!have) c->gicp_server_on = false;  // it gave up (50 ms without a command): single launches from here on
@@ -1280,19 +1304,29 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         if (launch_gicp_cost_direct(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
                                     c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
           return false;
-        if (wait_flags(c, c->h_gicp_flags, nblk, seq) != ICPGPU_OK) return false;
+        if (wait_gicp_tags(c, nblk, seq, /*server=*/false) != 0) return false;
       }
       {  // workgroup by workgroup, in double-double like the kernel (icp_gicp.hip): the 13 sums are rounded once, here
         double m = 0.0, d2 = 0.0, hi[13] = {}, lo[13] = {};
         const double* part = c->h_gicp;
-        for (int b = 0; b < nblk; ++b, part += kGicpPartialStride) {
+        for (int b = 0; b < nblk; ++b, part += kGicpPartialStride) {  // (entry e = doubles [2e] value, [2e + 1] tag)
           m += part[0];
-          d2 += part[14];
-          for (int k = 0; k < 13; ++k) gicp_dd_add(hi[k], lo[k], part[1 + k], part[16 + k]);
+          d2 += part[2 * 14];
+          for (int k = 0; k < 13; ++k) gicp_dd_add(hi[k], lo[k], part[2 * (1 + k)], part[2 * (16 + k)]);
         }
         c->h_sums[0] = m;
         c->h_sums[14] = d2;
         for (int k = 0; k < 13; ++k) c->h_sums[1 + k] = hi[k] + lo[k];
+      }
+      if (timing && have) {
+        const auto tq3 = std::chrono::steady_clock::now();
+        c->gt_cmd += std::chrono::duration<double, std::micro>(tq1 - tq0).count();
+        c->gt_wait += std::chrono::duration<double, std::micro>(tq2 - tq1).count();
+        c->gt_merge += std::chrono::duration<double, std::micro>(tq3 - tq2).count();
+        c->gt_dev_wait += c->h_gicp[2 * 30];   // block 0's stamps (icp_gicp.hip): polling, then work, in microseconds
+        c->gt_dev_work += c->h_gicp[2 * 31];
+        c->gt_n += 1;
+        c->gt_last = tq3;
       }
       c->prof.gicp_cost_launches += 1;
       const double* s = c->h_sums;
@@ -1492,6 +1526,11 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
 }
 
 int icpgpu_destroy(icpgpu_ctx* c) {
+  if (c && c->gt_n)
+    fprintf(stderr, "[icpgpu] GICP evaluations through the server: %llu; per evaluation: command write %.2f us, wait for the flags %.2f us "
+                    "(device: polling %.2f us, work %.2f us), merge %.2f us, solver between evaluations %.2f us\n",
+            c->gt_n, c->gt_cmd / c->gt_n, c->gt_wait / c->gt_n, c->gt_dev_wait / c->gt_n, c->gt_dev_work / c->gt_n, c->gt_merge / c->gt_n,
+            c->gt_between / c->gt_n);
   if (!c) return ICPGPU_OK;
   for (icpgpu_ctx* w : c->workers) icpgpu_destroy(w);
   c->workers.clear();
