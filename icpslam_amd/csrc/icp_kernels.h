@@ -53,8 +53,9 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
                          float d2_threshold, double* partials, double* sums_out, unsigned long long* flags,
                          unsigned long long seq, hipStream_t stream);
 
-// sums_out may be host-mapped pinned memory.  flags (nullable, 17 entries, host-mapped): every term's workgroup stores
-// `seq` there after its sum (system-scope release), so the host can poll instead of synchronising the stream.
+// flags (nullable; 34 64-bit words, host-mapped, 16-byte aligned): term k's workgroup stores the pair {sum bits, seq} at
+// words 2k, 2k + 1 in ONE 16-byte write-through store, so the host can poll instead of synchronising the stream and never
+// sees a sum without its number; sums_out is then left alone.  Without flags the sums go to sums_out (device memory).
 // term_major: partials are laid out [term][block] (what launch_nn_grid_search writes) instead of [block][term].
 hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,
                                unsigned long long* flags, unsigned long long seq, hipStream_t stream);

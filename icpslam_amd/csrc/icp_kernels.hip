@@ -277,8 +277,8 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
 
 // stage 2: one 256-thread workgroup per term; thread t adds partials t, t+256, ... in that order (independent loads),
 // then a fixed shuffle + LDS tree -> bitwise reproducible run to run.
-// `flags` (optional) lets a host that polls pinned memory see the result without a stream synchronisation: each
-// workgroup publishes `seq` after its sum, with system-scope release ordering.
+// `flags` (optional) lets a host that polls pinned memory see the result without a stream synchronisation: term k's
+// workgroup publishes the pair {sum, seq} at flags[2k], flags[2k + 1] (then `sums` is not written).
 // term_major: partials[k * n_blocks + b] (coalesced reads here; the fused grid search writes this layout) instead of
 // partials[b * 17 + k].
 __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks, int term_major,
@@ -297,8 +297,19 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
-    sums[k] = (w[0] + w[1]) + (w[2] + w[3]);
-    if (flags) __hip_atomic_store(&flags[k], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double sum = (w[0] + w[1]) + (w[2] + w[3]);
+    if (flags) {
+      // the host mailbox: {sum, seq} as ONE 16-byte store written through to system memory -- a pair is never seen
+      // half-written, so the host needs no flag behind a system-scope release (a write-back + a wait for the sum's
+      // acknowledgement before the flag may leave: ~1 us of every ICP iteration)
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
+      const u32x4 v = {(unsigned int)bits, (unsigned int)(bits >> 32), (unsigned int)seq, (unsigned int)(seq >> 32)};
+      unsigned long long* p = flags + 2 * k;
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    } else {
+      sums[k] = sum;
+    }
   }
 }
 

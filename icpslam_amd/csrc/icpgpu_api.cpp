@@ -640,10 +640,18 @@ static double wait_timeout_ms() {
   return v;
 }
 
-bool flags_ready(const volatile unsigned long long* flags, int n_flags, unsigned long long seq) {
+// the sums mailbox: pair k = {sum bits, sequence number} at words 2k, 2k + 1 (reduce_final_kernel)
+bool flags_ready(const volatile unsigned long long* pairs, int n_pairs, unsigned long long seq) {
   bool all = true;
-  for (int k = 0; k < n_flags; ++k) all = all && (flags[k] == seq);
+  for (int k = 0; k < n_pairs; ++k) all = all && (pairs[2 * k + 1] == seq);
   return all;
+}
+// ... into c->h_sums, where everybody reads them
+void take_sums(icpgpu_ctx* c) {
+  for (int k = 0; k < kReduceTerms; ++k) {
+    const unsigned long long bits = c->h_flags[2 * k];
+    std::memcpy(&c->h_sums[k], &bits, sizeof bits);
+  }
 }
 
 // Spin on the mailbox flags until every term of sweep `seq` has landed.  The stream is queried now and then so that a
@@ -673,7 +681,11 @@ int wait_flags(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_fl
   return ICPGPU_OK;
 }
 
-int wait_sums(icpgpu_ctx* c, unsigned long long seq) { return wait_flags(c, c->h_flags, kReduceTerms, seq); }
+int wait_sums(icpgpu_ctx* c, unsigned long long seq) {
+  const int rc = wait_flags(c, c->h_flags, kReduceTerms, seq);
+  if (!rc) take_sums(c);
+  return rc;
+}
 
 // One NN sweep + reduction with transform T, in three steps so that one host thread can keep several contexts busy
 // (icpgpu_align_batch): sweep_issue queues the kernels, the 17 sums land in c->h_sums when flags_ready(c->h_flags, ...,
@@ -774,6 +786,7 @@ bool sweep_ready(const icpgpu_ctx* c, const SweepTicket& tk) { return flags_read
 // after the sums of tk have arrived
 int sweep_complete(icpgpu_ctx* c, SweepTicket& tk) {
   std::atomic_thread_fence(std::memory_order_acquire);
+  take_sums(c);  // (callers that polled sweep_ready themselves have not)
   if (!tk.few_host) return ICPGPU_OK;
   // ungated search: the few-queries kernel completed the unmatched points unless there were too many for it (then the sums
   // just received miss them: tiled brute-force completion and a second reduction)
@@ -1477,12 +1490,13 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  // mailbox: 17 sums then 17 flags (kept apart by 64 B so that the flags sit in their own cache lines)
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + kReduceTerms) * sizeof(double),
+  // mailbox: 24 doubles the host keeps the current sums (and a few spare slots) in, then the 17 {sum, number} pairs the
+  // device writes (reduce_final_kernel)
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + 2 * kReduceTerms) * sizeof(double),
                          hipHostMallocMapped | hipHostMallocCoherent)) !=  // fine-grained: the polled flags must become visible without a sync
       hipSuccess)
     return bail("hipHostMalloc", e);
-  std::memset(c->h_sums, 0, (24 + kReduceTerms) * sizeof(double));
+  std::memset(c->h_sums, 0, (24 + 2 * kReduceTerms) * sizeof(double));
   if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_sums_dev), c->h_sums, 0)) != hipSuccess)
     return bail("hipHostGetDevicePointer", e);
   c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
