@@ -161,6 +161,10 @@ struct icpgpu_ctx {
   // ICPGPU_GICP_TIMING=1 (development): where an evaluation's microseconds go, printed when the context is destroyed
   double gt_cmd = 0, gt_wait = 0, gt_merge = 0, gt_between = 0, gt_dev_wait = 0, gt_dev_work = 0;
   unsigned long long gt_n = 0;
+  // ICPGPU_P2P_TIMING=1 (development): host time between a sweep's sums and the next search kernel's launch
+  double pt_wait = 0, pt_solve = 0, pt_prelaunch = 0, pt_launch = 0, pt_rest = 0;
+  unsigned long long pt_n = 0;
+  std::chrono::steady_clock::time_point pt_ready{}, pt_issue_in{};
   std::chrono::steady_clock::time_point gt_last{};  // workgroups per cost evaluation: the whole chip, or this worker's share of it
   // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
   std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
@@ -701,6 +705,11 @@ struct SweepTicket {
 };
 
 int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, SweepTicket& tk) {
+  static const bool timing = [] { const char* e = std::getenv("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
+  if (timing) {
+    c->pt_issue_in = std::chrono::steady_clock::now();
+    if (c->pt_n) c->pt_solve += std::chrono::duration<double, std::micro>(c->pt_issue_in - c->pt_ready).count();
+  }
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   int rc = ensure(c, c->keys, (size_t)(n_s ? n_s : 1) * sizeof(unsigned long long));
   if (rc) return rc;
@@ -730,9 +739,17 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     float4* prev = nullptr;
     bool use_prev = false;
     if ((rc = prev_neighbours(c, c->grid, src_pts, n_q, grid_flags(c->grid, ordered), prev, use_prev))) return rc;
+    std::chrono::steady_clock::time_point tl0;
+    if (timing) tl0 = std::chrono::steady_clock::now();
     HIP_TRY(c, launch_nn_grid_search(src_pts, n_q, grid_flags(c->grid, ordered), T, static_cast<const float4*>(c->grid.sorted.ptr),
                                      static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, nullptr, partials, nullptr,
                                      nullptr, c->stream, prev, use_prev));
+    if (timing) {
+      const auto tl1 = std::chrono::steady_clock::now();
+      c->pt_prelaunch += std::chrono::duration<double, std::micro>(tl0 - c->pt_issue_in).count();
+      c->pt_launch += std::chrono::duration<double, std::micro>(tl1 - tl0).count();
+      c->pt_issue_in = tl1;
+    }
     EVREC(ev[1]);
     HIP_TRY(c, launch_reduce_final(partials, blocks, /*term_major=*/true, d_sums, c->h_flags_dev, seq, c->stream));
   } else {
@@ -772,6 +789,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
   }
   c->prof.reduce_launches += 1;
   c->prof.reduce_bytes += (use_grid && !open_range) ? 136ull * (uint64_t)grid_search_blocks(n_s) : 40ull * (uint64_t)n_s + 136;
+  if (timing) c->pt_rest += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c->pt_issue_in).count();
   tk.seq = seq;
   tk.few_host = few_host;
   tk.red_src = red_src;
@@ -1059,8 +1077,15 @@ int p2p_advance(icpgpu_ctx* c, P2PRun& r) {
 int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
   P2PRun r;
   int rc = p2p_begin(c, r, guess, out_xyzw, want_fitness, res);
+  static const bool timing = [] { const char* e = std::getenv("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
   while (!rc && r.phase != P2PRun::Done) {
+    const auto t0 = std::chrono::steady_clock::now();
     if ((rc = wait_sums(c, r.ticket.seq))) break;
+    if (timing) {
+      c->pt_ready = std::chrono::steady_clock::now();
+      c->pt_wait += std::chrono::duration<double, std::micro>(c->pt_ready - t0).count();
+      c->pt_n += 1;
+    }
     rc = p2p_advance(c, r);
   }
   return rc;
@@ -1540,6 +1565,11 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
 }
 
 int icpgpu_destroy(icpgpu_ctx* c) {
+  if (c && c->pt_n)
+    fprintf(stderr, "[icpgpu] point-to-point sweeps waited for: %llu; per sweep: waiting for the sums %.2f us, sums -> sweep_issue (take, solve, "
+                    "convergence) %.2f us, sweep_issue up to the search launch %.2f us, the launch call %.2f us, the rest of sweep_issue "
+                    "(final-reduction launch, events) %.2f us\n",
+            c->pt_n, c->pt_wait / c->pt_n, c->pt_solve / c->pt_n, c->pt_prelaunch / c->pt_n, c->pt_launch / c->pt_n, c->pt_rest / c->pt_n);
   if (c && c->gt_n)
     fprintf(stderr, "[icpgpu] GICP evaluations through the server: %llu; per evaluation: command write %.2f us, wait for the flags %.2f us "
                     "(device: polling %.2f us, work %.2f us), merge %.2f us, solver between evaluations %.2f us\n",
