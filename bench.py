@@ -342,7 +342,7 @@ def main():
             ctx.align()
             pb = ctx.profile()
             brute[name] = {"avg_launch_ms": pb.nn_ms / max(1, pb.nn_timed), "launches": int(pb.nn_launches)}
-        ctx.profile_sampling(7)
+        ctx.profile_sampling(13)
         ctx.set_params(nn_mode=nn_mode, max_iterations=a.iters, brute_variant=0)
 
     if rank == 0:

@@ -172,7 +172,7 @@ struct icpgpu_ctx {
   std::vector<PendingSweep> pending;
   double dev_ms_accum = 0.0;
   unsigned call_sweeps = 0, call_timed = 0;  // sweeps of the current align call: all / timed
-  int timing_every = 7;       // time one sweep in 7 (coprime with the 10 / 30 iterations of the reference's aligns)
+  int timing_every = 13;      // time one sweep in 13 (coprime with the 10 / 30 iterations of the reference's aligns; 7 until round 2: an event triple costs 6-7 us)
   unsigned sweep_counter = 0;
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
   bool have_final = false;

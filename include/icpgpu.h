@@ -97,7 +97,7 @@ typedef struct {
   double t_device_ms;         /* kernel time of the call on the context's stream: HIP-event time of the TIMED sweeps
                                * (icpgpu_profile_set_sampling), scaled to all sweeps of the call.  An estimate: timings are
                                * read without blocking, and one that was not ready at the end of the call counts towards
-                               * the next one (icpgpu_profile_get always waits and is exact) */
+                               * the next one; 0 when none of the call's sweeps was a timed one (icpgpu_profile_get always waits and is exact) */
 } icpgpu_result;
 
 /* Kernel-level accounting since the last icpgpu_profile_reset(); times are HIP-event times on the
@@ -275,7 +275,7 @@ int icpgpu_posegraph_get_edge(const icpgpu_posegraph* g, long new_kf, icpgpu_pos
 int icpgpu_posegraph_write_g2o(const icpgpu_posegraph* g, const char* path);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
-/* time one correspondence sweep in `every` (default 7, coprime with the reference's 10 / 30 iterations; 1 = every sweep).
+/* time one correspondence sweep in `every` (default 13, coprime with the reference's 10 / 30 iterations; 1 = every sweep).
  * Average kernel durations are *_ms / *_timed. */
 int icpgpu_profile_set_sampling(icpgpu_ctx* ctx, int every);
 int icpgpu_profile_reset(icpgpu_ctx* ctx);
