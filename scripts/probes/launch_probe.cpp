@@ -53,5 +53,26 @@ int main() {
     if (fn) std::printf(" | hipModuleLaunchKernel, packed buffer %.2f us", time_calls(module, s, 2000, drain));
     std::printf("\n");
   }
+  {
+    double tot = 0;
+    for (int i = 0; i < 2000; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
+      (void)hipGetLastError();
+      tot += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    std::printf("hipGetLastError: %.3f us\n", tot / 2000);
+    // the launch after 60 us of spinning on a host word (what the iteration loop does between launches)
+    volatile unsigned long long word = 0;
+    double t2 = 0;
+    for (int i = 0; i < 500; ++i) {
+      (void)hipStreamSynchronize(s);
+      const auto w0 = std::chrono::steady_clock::now();
+      while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count() < 60.0) word = word + 1;
+      const auto t0 = std::chrono::steady_clock::now();
+      many();
+      t2 += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    std::printf("17-arg launch after 60 us of spinning: %.2f us\n", t2 / 500);
+  }
   return 0;
 }
