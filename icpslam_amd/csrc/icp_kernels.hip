@@ -281,7 +281,9 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
 // workgroup publishes the pair {sum, seq} at flags[2k], flags[2k + 1] (then `sums` is not written).
 // term_major: partials[k * n_blocks + b] (coalesced reads here; the fused grid search writes this layout) instead of
 // partials[b * 17 + k].
-__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks, int term_major,
+// 1024 threads per term: a 200k-point sweep's 3128 partials are ONE batch of loads per thread (one memory round trip).
+constexpr int RF_BLOCK = 1024;
+__global__ __launch_bounds__(RF_BLOCK) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks, int term_major,
                                                            double* __restrict__ sums, unsigned long long* flags,
                                                            unsigned long long seq) {
   const int k = blockIdx.x;
@@ -291,23 +293,33 @@ __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restr
   // iteration's critical path).
   const double* __restrict__ base = term_major ? partials + (size_t)k * n_blocks : partials + k;
   const size_t step = term_major ? 1 : (size_t)kReduceTerms;
-  for (int b0 = threadIdx.x; b0 < n_blocks; b0 += 8 * 256) {
+  for (int b0 = threadIdx.x; b0 < n_blocks; b0 += 8 * RF_BLOCK) {
     double x[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int b = b0 + u * 256;
+      const int b = b0 + u * RF_BLOCK;
       x[u] = b < n_blocks ? base[(size_t)b * step] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (b0 + u * 256 < n_blocks) v += x[u];  // (no "+ 0.0": -0.0 partials must add up as before)
+      if (b0 + u * RF_BLOCK < n_blocks) v += x[u];  // (no "+ 0.0": -0.0 partials must add up as before)
   }
   v = wave_sum(v);
-  __shared__ double w[4];
+  __shared__ double w[RF_BLOCK / 64];
   if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double sum = (w[0] + w[1]) + (w[2] + w[3]);
+    double sum = 0.0;  // a fixed tree over the waves' sums
+    {
+      double t[RF_BLOCK / 64];
+#pragma unroll
+      for (int i = 0; i < RF_BLOCK / 64; ++i) t[i] = w[i];
+#pragma unroll
+      for (int span = 1; span < RF_BLOCK / 64; span <<= 1)
+#pragma unroll
+        for (int i = 0; i + span < RF_BLOCK / 64; i += 2 * span) t[i] += t[i + span];
+      sum = t[0];
+    }
     if (flags) {
       // the host mailbox: {sum, seq} as ONE 16-byte store written through to system memory -- a pair is never seen
       // half-written, so the host needs no flag behind a system-scope release (a write-back + a wait for the sum's
@@ -432,7 +444,7 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
 
 hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,
                                unsigned long long* flags, unsigned long long seq, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(256), 0, stream, partials, n_blocks, term_major ? 1 : 0,
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(RF_BLOCK), 0, stream, partials, n_blocks, term_major ? 1 : 0,
                      sums_out, flags, seq);
   return hipGetLastError();
 }
