@@ -260,16 +260,29 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
 #pragma unroll
   for (int k = 0; k < kReduceTerms; ++k) acc[k] = 0.0;
 
-  for (int i = blockIdx.x * RED_BLOCK + threadIdx.x; i < n_s; i += gridDim.x * RED_BLOCK) {
-    const unsigned long long key = keys[i];
-    const unsigned int j = (unsigned int)key;
-    const float d2 = __uint_as_float((unsigned int)(key >> 32));
-    if (j != 0xFFFFFFFFu && d2 <= thr) {
-      const float4 s = src[i];
+  // Four points per trip, their loads issued together (keys, then sources and the targets the keys name), accumulated in
+  // the order of one at a time: key -> target is a dependent pair of reads, and one point after the other made a lane's four
+  // points eight serial memory round trips.
+  const int stride = gridDim.x * RED_BLOCK;
+  for (int i0 = blockIdx.x * RED_BLOCK + threadIdx.x; i0 < n_s; i0 += 4 * stride) {
+    unsigned long long key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) key[u] = i0 + u * stride < n_s ? keys[i0 + u * stride] : kEmptyKey;
+    float4 s[4], q[4];
+    bool use[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned int j = (unsigned int)key[u];
+      use[u] = j != 0xFFFFFFFFu && __uint_as_float((unsigned int)(key[u] >> 32)) <= thr;
+      s[u] = src[min(i0 + u * stride, n_s - 1)];
+      q[u] = tgt[use[u] ? j : 0u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!use[u]) continue;
       float px, py, pz;
-      xform_point(T, s.x, s.y, s.z, px, py, pz);
-      const float4 q = tgt[j];
-      accumulate_pair(acc, px, py, pz, q.x, q.y, q.z, d2);
+      xform_point(T, s[u].x, s[u].y, s[u].z, px, py, pz);
+      accumulate_pair(acc, px, py, pz, q[u].x, q[u].y, q[u].z, __uint_as_float((unsigned int)(key[u] >> 32)));
     }
   }
   block_reduce_store<RED_BLOCK / 64>(acc, partials);
