@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
   unsigned int expect = first_seq;
   // RESIDENT (small problems: every lane's share is one quad): the correspondences do not change during a run, so they are
   // read ONCE and stay in registers -- an evaluation then starts without the key -> (target point, matrix) chain of reads.
-  // (For large clouds this was measured slower: 298 registers, one wave per SIMD; there the reads are not what is waited for.)
+  // (298 registers, one wave per SIMD.  Measured twice: slower at 200k points while every evaluation also paid a system-scope
+  // release, 9-11 % faster at every size from 5k to 200k once the results travelled as self-tagged pairs.)
   GicpQuad mine;
   if constexpr (RESIDENT) gicp_load_quad(mine, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, src, n_s, tgt, keys, thr, maha6);
   for (;;) {
@@ -601,8 +602,8 @@ int gicp_direct_blocks(int n_s, int most) {
   // ICPGPU_GICP_BLOCKS (tuning): the most workgroups an evaluation may use.  64 until round 2; with one workgroup per 1024
   // points up to 256 a 200k x 200k registration takes 3.9 instead of 4.45 ms (12 instead of 15 us per evaluation: the
   // workgroups' share shrinks faster than the host's merge of their partial sums grows).  Keeping each lane's
-  // correspondences in registers for the whole run of the server (gicp_server_kernel<true>) is slower at this size -- 298
-  // registers, one wave per SIMD -- and faster below 64k points (launch_gicp_server picks).
+  // correspondences in registers for the whole run of the server (gicp_server_kernel<true>) takes another 9-11 % off at
+  // every size (launch_gicp_server picks it whenever a lane's share is one quad).
   static const int cap = [] {
     const char* e = std::getenv("ICPGPU_GICP_BLOCKS");
     const int v = e ? std::atoi(e) : kGicpDirectBlocks;
@@ -626,8 +627,8 @@ hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
                               unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream) {
-  // every lane's share fits one quad and the problem is small enough for the registers to pay (ICPGPU_GICP_RESIDENT_MAX, tuning)
-  static const int resident_max = [] { const char* e = std::getenv("ICPGPU_GICP_RESIDENT_MAX"); return e ? std::atoi(e) : 65536; }();
+  // every lane's share fits one quad: up to 256 workgroups x 1024 points (ICPGPU_GICP_RESIDENT_MAX: tuning switch; 0 = never)
+  static const int resident_max = [] { const char* e = std::getenv("ICPGPU_GICP_RESIDENT_MAX"); return e ? std::atoi(e) : 262144; }();
   if ((long long)blocks * 1024 >= n_s && n_s <= resident_max)
     hipLaunchKernelGGL(gicp_server_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
                        host_partials, host_flags, cmd, first_seq, seq_hi);
