@@ -174,3 +174,36 @@ def test_pcl_flavour_config3_200k_vs_1m(ctx, scan_vs_submap):
     ctx.set_source(src)
     ctx.set_target(tgt)
     _assert_close_to_pcl_flavour(ctx.align(), ref, "config 3, 200k x 1M")
+
+
+def test_source_of_a_million_points(ctx):
+    """1M source points = 15 625 search workgroups: the final reduction's threads take more than one batch of partial sums
+    (a 200k sweep fits one).  Against the oracle: exact counts, transforms within tolerance."""
+    tgt, src, _ = synth.make_scan_vs_submap(100000, 1000000, seed=9)      # roles swapped: the big cloud is the SOURCE
+    ref = oracle.icp_align(src, tgt, oracle.default_params(max_iterations=3))
+    ctx.set_params(ctx.default_params(), max_iterations=3)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    r = ctx.align(want_fitness=True)
+    assert (r["iterations"], r["n_corr"], r["converged"]) == (ref["iterations"], ref["n_corr"], ref["converged"])
+    assert _close(r["T"], ref["T"])
+    # the keys path (reduce_kernel + the same final kernel) over the fitness sweep's keys, at the final transform: the gate
+    # admits at least as many pairs as the last iteration saw, and the sums repeat bit for bit
+    sums = ctx.reduce(r["T"], 1.0)
+    assert r["n_corr"] <= sums[0] <= src.shape[0] and np.array_equal(sums, ctx.reduce(r["T"], 1.0))
+
+
+def test_results_repeat_bit_for_bit(ctx, pair200k):
+    """The sums reach the host as {value, sequence number} pairs in single 16-byte stores: a pair seen half-written would make
+    a result differ from run to run (scripts/mailbox_soak.py is the long version: millions of pairs)."""
+    from icpslam_amd import GICP, P2P_SVD
+    src, tgt, _ = pair200k
+    for method, n, reps in ((P2P_SVD, 200000, 150), (GICP, 30000, 40)):
+        ctx.set_params(ctx.default_params(), method=method, max_iterations=10)
+        ctx.set_source(src[:n])
+        ctx.set_target(tgt[:n])
+        first = ctx.align(want_fitness=True)
+        key = (first["T"].tobytes(), first["iterations"], first["n_corr"], first["mse"], first["fitness"])
+        for _ in range(reps):
+            r = ctx.align(want_fitness=True)
+            assert (r["T"].tobytes(), r["iterations"], r["n_corr"], r["mse"], r["fitness"]) == key

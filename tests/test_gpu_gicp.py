@@ -192,3 +192,30 @@ def test_gicp_vs_pcl_ordered_evaluation(ctx):
     (ok_gpu, worst_gpu), (ok_yard, _) = oks["GPU vs PCL-ordered"], oks["PCL-ordered vs the same loop backwards"]
     assert ok_gpu >= 0.95 * len(seeds) and ok_gpu >= ok_yard - 4, (ok_gpu, ok_yard)
     assert worst_gpu[0] <= 5e-3 and worst_gpu[1] <= 5e-2, worst_gpu
+
+
+def test_gicp_server_variants_agree_bit_for_bit(tmp_path):
+    """The evaluation server keeps a lane's correspondences in registers when its share is one quad and streams them
+    otherwise; single launches (no server) are the third way to the same sums.  Same registration, three ways, same bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "from icpslam_amd import Context, GICP, synth\n"
+        "src, tgt, _ = synth.make_pair(30000, 26000, seed=12)\n"
+        "with Context(0) as ctx:\n"
+        "    ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10)\n"
+        "    ctx.set_source(src); ctx.set_target(tgt)\n"
+        "    r = ctx.align(want_fitness=True)\n"
+        "np.savez(sys.argv[1], T=r['T'], meta=np.array([r['iterations'], r['n_corr'], r['converged']]), f=np.array([r['mse'], r['fitness']]))\n")
+    outs = []
+    for name, env in (("resident", {}), ("streamed", {"ICPGPU_GICP_RESIDENT_MAX": "0"}), ("launches", {"ICPGPU_GICP_SERVER": "0"})):
+        e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=300)
+        outs.append(dict(np.load(path)))
+    for o in outs[1:]:
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], o[k]), k
