@@ -255,6 +255,12 @@ def main():
     for _ in range(a.warmup):
         last = step()
     ctx.profile_reset()
+    # the harness's own interpreter must not stop the clock's world: a generation-2 garbage collection of CPython takes ~40 ms
+    # here (the synthetic clouds and records are large containers) and used to land in the SIXTH batch of every batch50k run --
+    # one 52 ms step among 15 ms ones (scripts/batch_jitter.py with and without gc.disable(): profiles/r02_batch_scheduler.txt)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -263,6 +269,7 @@ def main():
         gather(last)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     prof = ctx.profile()
     iters_done = int(prof.iterations)
     pairs_done = int(prof.aligns)

@@ -1,7 +1,8 @@
 """Dev tool: run-to-run spread of icpgpu_align_batch (64 pairs of 50k, <= 10 iterations + fitness) per (threads, depth)
 setting: "TxK,TxK,..." (default: the library's own choice).  One subprocess per setting (the switches are read per call,
 but worker contexts are kept across calls)."""
-import os, sys, time
+import gc, os, sys, time
+if not os.environ.get('KEEP_GC'): gc.disable()   # a gen-2 collection of CPython (~40 ms) is not the library's jitter
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from icpslam_amd import Context, synth

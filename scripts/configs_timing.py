@@ -1,6 +1,7 @@
 """Dev tool: the five BASELINE.json configs on ONE MI355X (configs 4 and 5: one GPU's share of the 8-GPU job), with the
 CPU oracle beside them where it finishes in seconds.  Output is committed as profiles/r01_configs.txt."""
-import os, sys, time, tempfile
+import gc, os, sys, time, tempfile
+if not os.environ.get('KEEP_GC'): gc.disable()   # a gen-2 collection of CPython (~40 ms) is not the library's jitter
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import oracle
