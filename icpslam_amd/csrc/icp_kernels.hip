@@ -451,6 +451,9 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
   int blocks = (n_s + 4 * RED_BLOCK - 1) / (4 * RED_BLOCK);
   if (blocks > kMaxReduceBlocks) blocks = kMaxReduceBlocks;
   if (blocks < 1) blocks = 1;
+  // reduce_kernel reads tgt[0] for every slot it does not use (its loads are issued before the keys are judged).  An EMPTY
+  // target never allocated a buffer: every key is empty then, and the unused reads go to the source instead of address 0.
+  if (!tgt) tgt = src;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
   return launch_reduce_final(partials, blocks, false, sums_out, flags, seq, stream);
 }

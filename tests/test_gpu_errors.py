@@ -87,6 +87,26 @@ def test_non_convergence_is_not_an_error(ctx):
     assert not r["converged"] and r["n_corr"] == 0
 
 
+def test_fitness_and_reduce_on_a_fresh_context_with_an_empty_target(built):
+    """an empty target never allocates its buffer; reduce_kernel's unconditional tgt[0] reads must not go
+    to device address 0 (a memory fault that aborts the process).  getFitnessScore then reports PCL's DBL_MAX."""
+    from icpslam_amd import Context
+    src, _, _ = synth.make_pair(3000, 3000, seed=5)
+    with Context(0) as c:                                   # fresh: the target buffer has never been allocated
+        c.set_source(src)
+        c.set_target(np.zeros((0, 4), np.float32))
+        r = c.align()
+        assert not r["converged"]
+        assert c.fitness() == np.finfo(np.float64).max
+        idx, d2 = c.nn(np.eye(4))
+        assert (idx == -1).all()
+        sums = c.reduce(np.eye(4), 1.0)
+        assert np.array_equal(sums, np.zeros(17))
+        _, tgt, _ = synth.make_pair(3000, 3000, seed=5)
+        c.set_target(tgt)                                   # and the context is still alive
+        assert c.align()["converged"]
+
+
 def test_gicp_needs_twenty_points(ctx):
     src, tgt, _ = synth.make_pair(3000, 3000, seed=3)
     ctx.set_params(ctx.default_params(), method=GICP)
