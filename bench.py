@@ -135,6 +135,40 @@ def _cpu_model() -> str:
     return "unknown"
 
 
+def shim_pipeline(scan_a, scan_b, leaf: float, iters: int, n_scans: int = 24, threads: int = 4) -> dict:
+    """The boundary as INTEGRATION.md integrates it, timed: builds tests/cpp/odometer_pipeline_demo.cpp (g++, header-only shim +
+    libicpgpu.so) and runs it on the two raw scans.  Also run with ICPGPU_RECOGNISE=0 (every target uploaded and rebuilt: what
+    the shim did until round 3) for the difference."""
+    import tempfile
+    from icpslam_amd import _lib
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            exe = os.path.join(td, "odometer_pipeline_demo")
+            libdir = os.path.dirname(_lib.LIB_PATH)
+            subprocess.check_call(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"),
+                                   os.path.join(ROOT, "tests", "cpp", "odometer_pipeline_demo.cpp"), "-o", exe, "-L", libdir,
+                                   "-licpgpu", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
+            pa, pb = os.path.join(td, "a.bin"), os.path.join(td, "b.bin")
+            scan_a.tofile(pa)
+            scan_b.tofile(pb)
+            for key, env in (("scans_per_sec", {}), ("scans_per_sec_without_recognition", {"ICPGPU_RECOGNISE": "0"}),
+                             ("scans_per_sec_one_thread", {})):
+                th = 1 if key.endswith("one_thread") else threads
+                r = subprocess.run([exe, pa, str(scan_a.shape[0]), pb, str(scan_b.shape[0]), str(n_scans), repr(leaf), str(iters),
+                                    str(th), "4"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+                if r.returncode != 0:
+                    out[key] = None
+                    out["error"] = r.stderr.strip()[-300:]
+                    continue
+                out[key] = float(r.stdout.strip().splitlines()[-1].split()[6])
+            out["scans"] = n_scans - 4
+            out["threads"] = threads
+    except Exception as e:  # the headline must not die with a secondary figure
+        out["error"] = repr(e)[:300]
+    return out
+
+
 def cpu_baseline(pairs, iters: int, force: bool, budget_s: float):
     """The oracle (C restatement of PCL's ICP, kd-tree NN, single thread like PCL 1.8) timed on this box's host, on a bounded
     sample of the same workload.  Every align builds its kd-tree, as PCL does for every scan (`icp` is a stack object at
@@ -329,7 +363,15 @@ def main():
         # (3) ... and the reference's whole per-scan pipeline: VoxelGrid at icpslam.yaml's 0.2 m in front of it
         leaf = 0.2
         pipeline = odometry_loop(max(4, n_e2e // 2), voxel_leaf=leaf, method=GICP, max_iterations=a.iters, force_iterations=0)
+        shim = shim_pipeline(src, tgt, leaf, a.iters)
         extras["gicp"] = {"scan_pairs_per_sec_e2e": gicp,
+                          "shim_pipeline_scans_per_sec": shim.get("scans_per_sec"),
+                          "shim_pipeline_def": "the SAME pipeline as integrated (INTEGRATION.md): tests/cpp/odometer_pipeline_demo.cpp = "
+                                               "laserCloudCallback (icp_odometer.cpp:96-101,147-220) with the two swapped type names, a fresh "
+                                               "icpgpu::VoxelGrid + icpgpu::GeneralizedIterativeClosestPoint object per scan, host clouds in and "
+                                               "out, `*prev_cloud_ = *curr_cloud_`, callbacks rotating over 4 threads (AsyncSpinner(4)); a C++ "
+                                               "process of its own, timed inside",
+                          "shim_pipeline": shim,
                           "def": f"the same odometry loop with method = GICP (<= {a.iters} outer iterations, BFGS inner "
                                  "solver): what pcl::GeneralizedIterativeClosestPoint at icp_odometer.cpp:188 runs per scan",
                           "reference_pipeline_scans_per_sec": pipeline,

@@ -40,7 +40,7 @@ class Profile(C.Structure):
                 ("map_inserts", C.c_uint64), ("map_insert_ms", C.c_double), ("map_points_in", C.c_uint64),
                 ("map_nn_launches", C.c_uint64), ("map_nn_ms", C.c_double),
                 ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64),
-                ("grid_bounded", C.c_uint64)]
+                ("grid_bounded", C.c_uint64), ("targets_recognised", C.c_uint64)]
 
 
 class Pose(C.Structure):
@@ -52,9 +52,10 @@ EXPORTS = [
     "icpgpu_create", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params",
     "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
     "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
+    "icpgpu_fingerprint", "icpgpu_cloud_sizes",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_profile_set_sampling", "icpgpu_get_stream", "icpgpu_synchronize",
-    "icpgpu_voxel_grid", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
+    "icpgpu_voxel_grid", "icpgpu_voxel_grid_fetch", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
     "icpgpu_pose_from_matrix", "icpgpu_pose_to_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
     "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
@@ -101,6 +102,9 @@ def load():
     L.icpgpu_set_source_device.argtypes = [vp, vp, C.c_size_t]
     L.icpgpu_set_target_device.argtypes = [vp, vp, C.c_size_t]
     L.icpgpu_promote_source_to_target.argtypes = [vp]
+    L.icpgpu_fingerprint.argtypes = [fp, C.c_size_t]
+    L.icpgpu_fingerprint.restype = C.c_uint64
+    L.icpgpu_cloud_sizes.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.icpgpu_align.argtypes = [vp, fp, fp, C.c_int, C.POINTER(Result)]
     L.icpgpu_fitness.argtypes = [vp, C.c_double, dp]
     L.icpgpu_align_batch.argtypes = [vp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp),
@@ -111,6 +115,7 @@ def load():
     L.icpgpu_transform.argtypes = [vp, fp, fp]
     L.icpgpu_gicp_covariances.argtypes = [vp, C.c_int, dp]
     L.icpgpu_voxel_grid.argtypes = [vp, fp, C.c_size_t, C.c_float, fp, C.POINTER(C.c_size_t)]
+    L.icpgpu_voxel_grid_fetch.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]
     pp, lp = C.POINTER(Pose), C.POINTER(C.c_long)
     L.icpgpu_pose_from_matrix.argtypes = [fp, pp]

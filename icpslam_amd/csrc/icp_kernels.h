@@ -64,6 +64,29 @@ hipError_t launch_transform(const float4* src, int n_s, const Xform& T, float4* 
 
 hipError_t launch_fill_keys(unsigned long long* keys, int n, hipStream_t stream);
 
+// Content fingerprint of a cloud (icpgpu_set_target's recognition of the previous source): the SUM over the points of a
+// 64-bit mix of (bits of the point, its index), plus a mix of n -- an order-independent sum, so the host (a loop) and the
+// device (any grid) compute the same number.  Two different clouds collide with probability ~2^-64.
+#if defined(__HIPCC__)
+#define ICPGPU_HD __host__ __device__
+#else
+#define ICPGPU_HD
+#endif
+ICPGPU_HD inline unsigned long long fp_mix(unsigned long long x) {  // splitmix64's finaliser
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
+ICPGPU_HD inline unsigned long long fp_point(unsigned long long w0, unsigned long long w1, unsigned long long i) {
+  return fp_mix(w0 + 0x9e3779b97f4a7c15ull * (2ull * i + 1ull)) + fp_mix(w1 ^ (0xd6e8feb86659fd93ull * (2ull * i + 2ull)));
+}
+ICPGPU_HD inline unsigned long long fp_finish(unsigned long long sum, unsigned long long n) { return sum + fp_mix(n ^ 0xa5a5a5a5a5a5a5a5ull); }
+// *d_acc (zeroed by the launcher) receives the sum of fp_point over pts[0..n)
+hipError_t launch_fingerprint(const float4* pts, int n, unsigned long long* d_acc, hipStream_t stream);
+
 // keys -> (idx, d2) arrays for the kernel-level C-ABI entry point.
 hipError_t launch_unpack_keys(const unsigned long long* keys, int n, int32_t* idx, float* d2, hipStream_t stream);
 

@@ -480,6 +480,30 @@ hipError_t launch_fill_keys(unsigned long long* keys, int n, hipStream_t stream)
   return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void fingerprint_kernel(const float4* __restrict__ pts, int n, unsigned long long* __restrict__ acc) {
+  unsigned long long s = 0ull;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    const unsigned long long w0 = ((unsigned long long)__float_as_uint(p.y) << 32) | __float_as_uint(p.x);
+    const unsigned long long w1 = ((unsigned long long)__float_as_uint(p.w) << 32) | __float_as_uint(p.z);
+    s += fp_point(w0, w1, (unsigned long long)i);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += (unsigned long long)__shfl_down((long long)s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(acc, s);  // integer addition: any order gives the same sum
+}
+}  // namespace
+
+hipError_t launch_fingerprint(const float4* pts, int n, unsigned long long* d_acc, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_acc, 0, sizeof(unsigned long long), stream);
+  if (e != hipSuccess || n <= 0) return e;
+  int blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fingerprint_kernel, dim3(blocks), dim3(256), 0, stream, pts, n, d_acc);
+  return hipGetLastError();
+}
+
 hipError_t launch_unpack_keys(const unsigned long long* keys, int n, int32_t* idx, float* d2, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(unpack_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, idx, d2);

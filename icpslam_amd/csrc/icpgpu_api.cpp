@@ -135,6 +135,11 @@ struct icpgpu_ctx {
   BruteSeed brute_seed;      // the same for the matrix-core brute-force kernel
   VoxelMap map;              // the mapper's map
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
+  // content fingerprints of the clouds in HBM (icpgpu_set_target's recognition of a cloud it already holds), computed on
+  // demand and cached per version
+  unsigned long long src_fp = 0, tgt_fp = 0;
+  uint64_t src_fp_version = 0, tgt_fp_version = 0;
+  DeviceBuf fp_acc;
   uint64_t src_version = 1;  // bumped whenever the source cloud changes
   // GICP mode: grids used for the 20-NN covariances, per-point covariances (6 doubles), Mahalanobis matrices
   GridIndex cov_grid_src, cov_grid_tgt;
@@ -181,6 +186,7 @@ struct icpgpu_ctx {
   int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
   DeviceBuf vox_bins, vox_pub;   // ... of the direct (no library sort) path: self-cleaning histogram + group ranges; published counts
+  size_t vox_last_n = 0;         // points of the last icpgpu_voxel_grid result (still in vox_out)
   void* vox_bins_zeroed = nullptr;  // the allocation (address, size) whose histogram is known to be zero
   size_t vox_bins_zeroed_cap = 0;
   void* vox_pub_zeroed = nullptr;
@@ -286,6 +292,31 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
   cl.buf.external = true;
   cl.n = n;
   cl.set = true;
+  return ICPGPU_OK;
+}
+
+// ICPGPU_RECOGNISE=0: icpgpu_set_target always uploads (A/B measurements)
+static bool recognise_enabled() {
+  static const bool v = [] { const char* e = std::getenv("ICPGPU_RECOGNISE"); return !e || std::atoi(e) != 0; }();
+  return v;
+}
+
+// fingerprint of a cloud in HBM (cached per version): one small kernel + an 8-byte read-back
+int device_fingerprint(icpgpu_ctx* c, const Cloud& cl, uint64_t version, unsigned long long& cache, uint64_t& cache_version,
+                       unsigned long long* out) {
+  if (cache_version != version) {
+    int rc = ensure(c, c->fp_acc, sizeof(unsigned long long));
+    if (rc) return rc;
+    auto* d_acc = static_cast<unsigned long long*>(c->fp_acc.ptr);
+    HIP_TRY(c, launch_fingerprint(cl.data(), (int)cl.n, d_acc, c->stream));
+    unsigned long long sum = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_acc, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(&sum, c->h_ints, sizeof sum);
+    cache = fp_finish(sum, (unsigned long long)cl.n);
+    cache_version = version;
+  }
+  *out = cache;
   return ICPGPU_OK;
 }
 
@@ -1667,8 +1698,54 @@ int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
   c->src_version++;
   return set_cloud_host(c, c->src, xyzw, n);
 }
+static int promote_internal(icpgpu_ctx* c);
+
+// setInputTarget from a host buffer.  The reference's odometer hands over, as the target of scan k, the cloud it handed
+// over as the source of scan k - 1 (`*prev_cloud_ = *curr_cloud_`, icp_odometer.cpp:209, then :194 on the next scan) -- a
+// fresh registration object cannot know that, the context can: when the buffer has the size of a cloud it already holds
+// it compares content fingerprints (one pass over the host buffer, ~0.1 ms per MB, + one 8-byte read-back) and
+//   * keeps the current target with its grid and GICP covariances when the content is the same (a rejected scan keeps
+//     prev_cloud_: icp_odometer.cpp:201-210), or
+//   * takes the promote path when it is the current SOURCE's content (no upload, grid and covariances carried over).
+// Results are identical either way: the target cloud in HBM holds the same bits.  External (zero-copy) buffers never take
+// part.  Callers that replace the source in the same step must set the target FIRST (the C++ shim does).
 int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
+  if (recognise_enabled() && n > 0 && xyzw) {
+    const bool tgt_cand = c->tgt.set && c->tgt.n == n && !c->tgt.buf.external;
+    const bool src_cand = c->src.set && c->src.n == n && !c->src.buf.external;
+    if (tgt_cand || src_cand) {
+      const unsigned long long fp = icpgpu_fingerprint(xyzw, n);
+      unsigned long long have = 0;
+      int rc;
+      if (tgt_cand) {
+        if ((rc = device_fingerprint(c, c->tgt, c->tgt_version, c->tgt_fp, c->tgt_fp_version, &have))) return rc;
+        if (have == fp) {
+          c->prof.targets_recognised += 1;
+          return ICPGPU_OK;
+        }
+      }
+      if (src_cand) {
+        if ((rc = device_fingerprint(c, c->src, c->src_version, c->src_fp, c->src_fp_version, &have))) return rc;
+        if (have == fp) {
+          c->prof.targets_recognised += 1;
+          rc = promote_internal(c);
+          if (rc == ICPGPU_OK) {
+            c->tgt_fp = fp;
+            c->tgt_fp_version = c->tgt_version;
+          }
+          return rc;
+        }
+      }
+      c->tgt_version++;
+      rc = set_cloud_host(c, c->tgt, xyzw, n);
+      if (rc == ICPGPU_OK) {  // what was just uploaded has the fingerprint just computed
+        c->tgt_fp = fp;
+        c->tgt_fp_version = c->tgt_version;
+      }
+      return rc;
+    }
+  }
   c->tgt_version++;
   return set_cloud_host(c, c->tgt, xyzw, n);
 }
@@ -1685,8 +1762,34 @@ int icpgpu_set_target_device(icpgpu_ctx* c, const void* d, size_t n) {
 
 int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
   ENTER(c);
+  return promote_internal(c);
+}
+
+unsigned long long icpgpu_fingerprint(const float* xyzw, size_t n) {
+  unsigned long long s0 = 0, s1 = 0;
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(xyzw);
+  for (size_t i = 0; i < n; ++i) {  // (two independent multiply chains per point: ~5 GB/s on one core)
+    unsigned long long w0, w1;
+    std::memcpy(&w0, b + 16 * i, 8);
+    std::memcpy(&w1, b + 16 * i + 8, 8);
+    s0 += fp_mix(w0 + 0x9e3779b97f4a7c15ull * (2ull * i + 1ull));
+    s1 += fp_mix(w1 ^ (0xd6e8feb86659fd93ull * (2ull * i + 2ull)));
+  }
+  return fp_finish(s0 + s1, (unsigned long long)n);
+}
+
+int icpgpu_cloud_sizes(const icpgpu_ctx* c, size_t* n_source, size_t* n_target) {
+  if (!c) return ICPGPU_ERR_INVALID_ARG;
+  if (n_source) *n_source = c->src.set ? c->src.n : 0;
+  if (n_target) *n_target = c->tgt.set ? c->tgt.n : 0;
+  return ICPGPU_OK;
+}
+
+static int promote_internal(icpgpu_ctx* c) {
   if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "promote_source_to_target: no source set");
   std::swap(c->src, c->tgt);
+  c->tgt_fp = c->src_fp;  // (versions are re-stamped below)
+  const bool fp_follows = c->src_fp_version == c->src_version;
   // the source's GICP covariances stay valid for the cloud that is now the target
   std::swap(c->cov_src, c->cov_tgt);
   std::swap(c->cov_grid_src, c->cov_grid_tgt);
@@ -1694,6 +1797,8 @@ int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
   std::swap(c->grid, c->src_grid);
   const bool grid_follows = c->grid.built && c->grid.version == c->src_version;
   c->tgt_version++;
+  c->tgt_fp_version = fp_follows ? c->tgt_version : 0;
+  c->src_fp_version = 0;
   if (grid_follows) c->grid.version = c->tgt_version;
   else c->grid.built = c->grid.usable = false;
   c->src_grid.built = c->src_grid.usable = false;
@@ -2010,20 +2115,35 @@ int icpgpu_transform(icpgpu_ctx* c, const float* T, float* out_xyzw) {
 
 int icpgpu_voxel_grid(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, float* out_xyzw, size_t* n_out) {
   ENTER(c);
-  if (!n_out || (n && (!xyzw || !out_xyzw))) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (!n_out || (n && !xyzw)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
   *n_out = 0;
+  c->vox_last_n = 0;
   int rc = ensure(c, c->vox_in, n * sizeof(float4));
   if (rc) return rc;
   if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   int m = 0;
   bool pass = false;
   if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass))) return rc;
-  if (m) {
+  if (m && out_xyzw) {
     HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
   }
+  c->vox_last_n = (size_t)m;  // out_xyzw == NULL: the filtered cloud waits in HBM for icpgpu_voxel_grid_fetch
   *n_out = (size_t)m;
+  return ICPGPU_OK;
+}
+
+int icpgpu_voxel_grid_fetch(icpgpu_ctx* c, float* out_xyzw, size_t capacity, size_t* n_out) {
+  ENTER(c);
+  const size_t m = c->vox_last_n;
+  if (n_out) *n_out = m;
+  if (m > capacity) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel_grid_fetch: %zu points, room for %zu", m, capacity);
+  if (m && !out_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (m) {
+    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
   return ICPGPU_OK;
 }
 

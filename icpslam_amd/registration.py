@@ -100,7 +100,10 @@ class Context:
     def set_target(self, cloud):
         cloud = _as_cloud(cloud)
         self._check(self._L.icpgpu_set_target(self._h, _fp(cloud), cloud.shape[0]))
-        self.n_target = cloud.shape[0]
+        # the library may have recognised the context's current SOURCE in `cloud` and taken the promote path (icpgpu.h)
+        ns, nt = C.c_size_t(), C.c_size_t()
+        self._check(self._L.icpgpu_cloud_sizes(self._h, C.byref(ns), C.byref(nt)))
+        self.n_source, self.n_target = int(ns.value), int(nt.value)
 
     def set_source_device(self, ptr: int, n: int):
         self._check(self._L.icpgpu_set_source_device(self._h, C.c_void_p(ptr), n))

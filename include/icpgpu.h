@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 #define ICPGPU_VERSION_MAJOR 0
-#define ICPGPU_VERSION_MINOR 1
+#define ICPGPU_VERSION_MINOR 2
 
 typedef struct icpgpu_ctx icpgpu_ctx; /* opaque */
 
@@ -136,6 +136,7 @@ typedef struct {
   uint64_t grid_timed;        /*   event records around a sweep are barrier packets that cost 6-7 us per iteration */
   uint64_t reduce_timed;
   uint64_t grid_bounded;      /* grid sweeps whose searches were pruned by the neighbours the previous sweep found */
+  uint64_t targets_recognised; /* icpgpu_set_target calls that found the cloud already in HBM (no upload, no rebuild) */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -158,6 +159,16 @@ int icpgpu_set_source(icpgpu_ctx* ctx, const float* xyzw, size_t n);
 /* replaces setInputTarget (icp_odometer.cpp:194, octree_mapper.cpp:110). PCL rejects an empty
  * target; here n == 0 is accepted and align() then reports converged = 0 with T = identity. */
 int icpgpu_set_target(icpgpu_ctx* ctx, const float* xyzw, size_t n);
+/* The reference hands scan k-1's SOURCE cloud back as scan k's TARGET (`*prev_cloud_ = *curr_cloud_`,
+ * icp_odometer.cpp:209, then setInputTarget(prev_cloud_) at :194): icpgpu_set_target recognises a buffer
+ * whose content (size, then a 64-bit content fingerprint) is the context's current source or target and
+ * keeps what it has in HBM -- the cloud, its search grid, its GICP covariances -- instead of uploading
+ * and rebuilding (the promote path for the source; nothing at all for the unchanged target of a rejected
+ * scan).  Call set_target BEFORE set_source when both change.  icpgpu_fingerprint is that fingerprint of
+ * a host buffer (n points of 16 bytes); icpgpu_cloud_sizes reports what a context holds (the C++ shim's
+ * context pool picks the context whose source has the new target's size). */
+unsigned long long icpgpu_fingerprint(const float* xyzw, size_t n);
+int icpgpu_cloud_sizes(const icpgpu_ctx* ctx, size_t* n_source, size_t* n_target);
 /* same, for clouds already resident in this device's HBM (zero copy; must stay valid and
  * unmodified until replaced; 16-byte aligned). */
 int icpgpu_set_source_device(icpgpu_ctx* ctx, const void* d_xyzw, size_t n);
@@ -208,6 +219,10 @@ int icpgpu_gicp_covariances(icpgpu_ctx* ctx, int of_target, double* out6);
  * non-finite points are skipped; if the cell index space overflows int32 the input is returned
  * unchanged (PCL's "leaf size is too small" behaviour). out_xyzw must hold n points. */
 int icpgpu_voxel_grid(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, float* out_xyzw, size_t* n_out);
+/* two-step form for callers that size their output by the result (pcl::VoxelGrid::filter resizes `output`): pass
+ * out_xyzw = NULL above -- *n_out is the number of voxels, the filtered cloud stays in HBM -- then fetch it into a
+ * buffer of `capacity` >= *n_out points.  Valid until the context's next voxel-filter call. */
+int icpgpu_voxel_grid_fetch(icpgpu_ctx* ctx, float* out_xyzw, size_t capacity, size_t* n_out);
 /* the odometer's pre-step fused with setInputSource: upload, filter on the device, and make the
  * filtered cloud the source without a round trip to the host (icp_odometer.cpp:177 then :193). */
 int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, size_t* n_out);

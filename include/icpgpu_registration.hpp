@@ -24,12 +24,13 @@
 #include <cmath>
 #include <cstddef>
 #include <cstring>
-#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 #include "icpgpu.h"
 
@@ -65,32 +66,87 @@ inline Matrix4 make_matrix4(const float* colmajor) {
 #endif
 
 namespace detail {
-// The reference constructs its registration object on the stack for every scan (icp_odometer.cpp:188); the device
-// context (stream, scratch, HBM buffers) is therefore cached per (thread, device), not per object.  Objects hold it by
-// shared_ptr: a context lives as long as anything uses it (an OctreeMap member keeps its map alive even if the thread
-// later works on another device), and the objects of one thread on one device share it on purpose -- that is how
-// setInputTargetFromMap() finds the nn cloud OctreeMap::approxNearestNeighbors left in HBM.
-using ContextPtr = std::shared_ptr<icpgpu_ctx>;
-inline ContextPtr thread_context(int device) {
-  static thread_local std::map<int, ContextPtr> cache;
-  ContextPtr& slot = cache[device];
-  if (!slot) {
+// The reference constructs its registration object on the stack for every scan (icp_odometer.cpp:188), and its callbacks
+// run on whichever of the ROS AsyncSpinner(4) threads is free (icpslam_node.cpp:9).  The device context (stream, scratch,
+// the clouds, grids and covariances in HBM) therefore lives in a per-process POOL, not in the object and not in the
+// thread: an object leases a context for its lifetime and hands it back; the next object -- on any thread -- gets the most
+// recently returned one, or, at align(), the idle one whose source cloud has the size of the target it is about to set
+// (the odometer's previous scan: icpgpu_set_target then recognises the content and keeps cloud, grid and covariances).
+// Two objects alive at once (the odometer's callback and the mapper's main loop, or two objects on one thread) hold two
+// different contexts.  Contexts are never destroyed behind the caller's back: the pool is leaked at process end (no static
+// destructor may run after the HIP runtime's own), release_cached_contexts() frees the idle ones on request.
+struct Slot {
+  icpgpu_ctx* ctx = nullptr;
+  int device = 0;
+  unsigned long long generation = 0;  // bumped whenever the context's clouds are replaced (only the lease holder writes it)
+};
+struct Pool {
+  std::mutex m;
+  std::vector<Slot*> idle;  // most recently returned last
+};
+inline Pool& pool() {
+  static Pool* p = new Pool;
+  return *p;
+}
+using ContextPtr = std::shared_ptr<Slot>;
+inline void give_back(Slot* s) {
+  std::lock_guard<std::mutex> g(pool().m);
+  pool().idle.push_back(s);
+}
+// idle context of `device`: the one whose source cloud has want_source_n points if there is one, else the most recently
+// returned one; nullptr if none is idle
+inline Slot* take_idle(int device, std::size_t want_source_n) {
+  Pool& P = pool();
+  std::lock_guard<std::mutex> g(P.m);
+  std::size_t pick = P.idle.size();
+  for (std::size_t i = P.idle.size(); i-- > 0;) {
+    if (P.idle[i]->device != device) continue;
+    if (pick == P.idle.size()) pick = i;
+    if (want_source_n == static_cast<std::size_t>(-1)) break;
+    std::size_t ns = 0;
+    icpgpu_cloud_sizes(P.idle[i]->ctx, &ns, nullptr);
+    if (ns == want_source_n) {
+      pick = i;
+      break;
+    }
+  }
+  if (pick == P.idle.size()) return nullptr;
+  Slot* s = P.idle[pick];
+  P.idle.erase(P.idle.begin() + static_cast<std::ptrdiff_t>(pick));
+  return s;
+}
+inline ContextPtr acquire_context(int device, std::size_t want_source_n = static_cast<std::size_t>(-1)) {
+  Slot* s = take_idle(device, want_source_n);
+  if (!s) {
     icpgpu_ctx* raw = nullptr;
     const int rc = icpgpu_create(&raw, device);
     if (rc != ICPGPU_OK)
       throw std::runtime_error(std::string("icpgpu_create failed: ") + icpgpu_last_error(nullptr));
-    slot = ContextPtr(raw, [](icpgpu_ctx* c) { icpgpu_destroy(c); });
+    s = new Slot;
+    s->ctx = raw;
+    s->device = device;
   }
-  return slot;
+  return ContextPtr(s, give_back);
 }
-// every align() through a context gets a number: a registration object knows whether it was the last to use the context
-inline unsigned long long next_generation() {
-  static thread_local unsigned long long g = 0;
-  return ++g;
+// a better-matching idle context for an object about to set a target of n points; keeps `have` when there is none
+inline ContextPtr rebind_for_target(const ContextPtr& have, std::size_t n_target) {
+  std::size_t ns = 0;
+  icpgpu_cloud_sizes(have->ctx, &ns, nullptr);
+  if (ns == n_target) return have;
+  Slot* s = take_idle(have->device, n_target);
+  if (!s) return have;
+  std::size_t ns2 = 0;
+  icpgpu_cloud_sizes(s->ctx, &ns2, nullptr);
+  if (ns2 != n_target) {  // just the most recently returned one: no better than what we hold
+    give_back(s);
+    return have;
+  }
+  return ContextPtr(s, give_back);
 }
-inline unsigned long long& context_generation(icpgpu_ctx* c) {
-  static thread_local std::map<icpgpu_ctx*, unsigned long long> gen;
-  return gen[c];
+// the context of the OctreeMap that last built an nn cloud on this thread (setInputTargetFromMap() without an argument)
+inline ContextPtr& last_map_context() {
+  static thread_local ContextPtr p;
+  return p;
 }
 
 // pcl::PointCloud keeps width / height / is_dense beside `points` (pcl::toROSMsg asserts width * height == size): set
@@ -105,11 +161,24 @@ template <class C>
 void set_cloud_shape(C&, std::size_t, long) {}
 }  // namespace detail
 
+// destroys the pool's idle contexts (their HBM); contexts leased by live objects are untouched
+inline void release_cached_contexts() {
+  std::vector<detail::Slot*> idle;
+  {
+    std::lock_guard<std::mutex> g(detail::pool().m);
+    idle.swap(detail::pool().idle);
+  }
+  for (detail::Slot* s : idle) {
+    icpgpu_destroy(s->ctx);
+    delete s;
+  }
+}
+
 template <class CloudT>
 class IterativeClosestPoint {
  public:
   explicit IterativeClosestPoint(int device = 0, icpgpu_method method = ICPGPU_P2P_SVD)
-      : ctx_holder_(detail::thread_context(device)), ctx_(ctx_holder_.get()) {
+      : ctx_holder_(detail::acquire_context(device)), ctx_(ctx_holder_->ctx) {
     icpgpu_default_params(&params_);
     params_.method = method;
     std::memset(&result_, 0, sizeof(result_));
@@ -129,9 +198,18 @@ class IterativeClosestPoint {
     target_ = &*cloud;
     target_from_map_ = false;
   }
-  // the target is the nn cloud OctreeMap::approxNearestNeighbors just left in HBM: skips one host round trip
-  void setInputTargetFromMap() { target_from_map_ = true; }
+  // the target is the nn cloud OctreeMap::approxNearestNeighbors just left in HBM (skips one host round trip): this
+  // object then works on the MAP's context -- the one given, or the one of the map that last built an nn cloud on this thread
+  void setInputTargetFromMap() { setInputTargetFromMap(detail::last_map_context()); }
+  void setInputTargetFromMap(const detail::ContextPtr& map_context) {
+    target_from_map_ = true;
+    if (map_context) {
+      ctx_holder_ = map_context;
+      ctx_ = ctx_holder_->ctx;
+    }
+  }
 
+  void setFitnessWithAlign(bool on) { fitness_with_align_ = on; }  // no PCL counterpart
   int getMaximumIterations() const { return params_.max_iterations; }
   double getTransformationEpsilon() const { return params_.transformation_epsilon; }
   double getMaxCorrespondenceDistance() const { return params_.max_correspondence_distance; }
@@ -145,9 +223,9 @@ class IterativeClosestPoint {
   double getFitnessScore(double max_range = DBL_MAX) {                        // icp_odometer.cpp:201
     double f = DBL_MAX;
     if (!aligned_) return DBL_MAX;
-    // Another object of this thread may have used the shared context since (the mapper's ICP between the odometer's
-    // align and its getFitnessScore): put this object's clouds and transform back first.
-    if (detail::context_generation(ctx_) != generation_) {
+    // Something else may have replaced the context's clouds since (a map's context is shared with its OctreeMap, whose
+    // next approxNearestNeighbors call does): put this object's clouds and transform back first.
+    if (ctx_holder_->generation != generation_) {
       if (target_from_map_ || !source_ || !target_ || !upload()) return DBL_MAX;
       double sums[17];
       std::size_t n = source_->points.size();
@@ -156,6 +234,7 @@ class IterativeClosestPoint {
       if (fitness_sums_at(result_.T, max_range, sums) != ICPGPU_OK) return DBL_MAX;
       return sums[0] > 0.0 ? sums[16] / sums[0] : DBL_MAX;
     }
+    if (fitness_with_align_ && max_range == DBL_MAX && result_.fitness == result_.fitness) return result_.fitness;
     if (icpgpu_fitness(ctx_, max_range, &f) != ICPGPU_OK) return DBL_MAX;
     return f;
   }
@@ -167,14 +246,26 @@ class IterativeClosestPoint {
   static_assert(sizeof(PointT) == 16, "point type must be the 16-byte pcl::PointXYZ layout");
 
   bool upload() {
-    if (icpgpu_set_params(ctx_, &params_) != ICPGPU_OK) return false;
-    const std::size_t ns = source_->points.size();
-    if (icpgpu_set_source(ctx_, ns ? reinterpret_cast<const float*>(&source_->points[0]) : nullptr, ns) != ICPGPU_OK) return false;
+    // the TARGET first: it is usually the cloud the context still holds as the previous scan's source
+    // (`*prev_cloud_ = *curr_cloud_`, icp_odometer.cpp:209), which icpgpu_set_target recognises -- no upload, the grid
+    // and the GICP covariances stay -- but only as long as set_source has not replaced it
     if (!target_from_map_) {
       const std::size_t nt = target_->points.size();
+      if (!bound_) {
+        detail::ContextPtr better = detail::rebind_for_target(ctx_holder_, nt);
+        if (better != ctx_holder_) {
+          ctx_holder_ = better;
+          ctx_ = ctx_holder_->ctx;
+        }
+        bound_ = true;
+      }
+      if (icpgpu_set_params(ctx_, &params_) != ICPGPU_OK) return false;
       if (icpgpu_set_target(ctx_, nt ? reinterpret_cast<const float*>(&target_->points[0]) : nullptr, nt) != ICPGPU_OK) return false;
+    } else if (icpgpu_set_params(ctx_, &params_) != ICPGPU_OK) {
+      return false;
     }
-    return true;
+    const std::size_t ns = source_->points.size();
+    return icpgpu_set_source(ctx_, ns ? reinterpret_cast<const float*>(&source_->points[0]) : nullptr, ns) == ICPGPU_OK;
   }
 
   // fitness through the kernel-level entry points, for a transform that is not the context's last one
@@ -197,9 +288,10 @@ class IterativeClosestPoint {
     output.points.resize(ns);
     detail::set_cloud_shape(output, ns, 0);
     float* out = ns ? reinterpret_cast<float*>(&output.points[0]) : nullptr;
-    generation_ = detail::next_generation();
-    detail::context_generation(ctx_) = generation_;
-    if (icpgpu_align(ctx_, guess, out, 0, &result_) != ICPGPU_OK) {
+    generation_ = ++ctx_holder_->generation;
+    // getFitnessScore() nearly always follows (icp_odometer.cpp:201): evaluated inside align it is one more sweep queued behind
+    // the last iteration instead of a call of its own (setFitnessWithAlign(false) for callers that never ask: octree_mapper.cpp:117)
+    if (icpgpu_align(ctx_, guess, out, fitness_with_align_ ? 1 : 0, &result_) != ICPGPU_OK) {
       result_.converged = 0;
       return;
     }
@@ -216,6 +308,8 @@ class IterativeClosestPoint {
   int ransac_iterations_ = 0;
   bool aligned_ = false;
   bool target_from_map_ = false;
+  bool fitness_with_align_ = true;
+  bool bound_ = false;  // the pool has been asked once for the context that suits this object's target
 };
 
 // pcl::GeneralizedIterativeClosestPoint<PointXYZ, PointXYZ>'s counterpart -- the class the reference instantiates at
@@ -234,7 +328,7 @@ class GeneralizedIterativeClosestPoint : public IterativeClosestPoint<CloudT> {
 template <class CloudT>
 class VoxelGrid {
  public:
-  explicit VoxelGrid(int device = 0) : ctx_holder_(detail::thread_context(device)), ctx_(ctx_holder_.get()) {}
+  explicit VoxelGrid(int device = 0) : ctx_holder_(detail::acquire_context(device)), ctx_(ctx_holder_->ctx) {}
   template <class CloudPtr>
   void setInputCloud(const CloudPtr& cloud) { input_ = &*cloud; }
   void setLeafSize(float lx, float ly, float lz) {
@@ -244,11 +338,13 @@ class VoxelGrid {
   void filter(CloudT& output) {
     if (!input_) return;
     const std::size_t n = input_->points.size();
-    output.points.resize(n);
     std::size_t m = 0;
-    const int rc = icpgpu_voxel_grid(ctx_, n ? reinterpret_cast<const float*>(&input_->points[0]) : nullptr, n, leaf_,
-                                     n ? reinterpret_cast<float*>(&output.points[0]) : nullptr, &m);
+    // two steps: filter (the result stays in HBM), size `output` by the voxel count, fetch -- sizing it for the worst case
+    // first would value-initialise n points (3.2 MB for a raw 200k-point scan) to receive a tenth of them
+    int rc = icpgpu_voxel_grid(ctx_, n ? reinterpret_cast<const float*>(&input_->points[0]) : nullptr, n, leaf_, nullptr, &m);
     output.points.resize(rc == ICPGPU_OK ? m : 0);
+    if (rc == ICPGPU_OK && m) rc = icpgpu_voxel_grid_fetch(ctx_, reinterpret_cast<float*>(&output.points[0]), m, &m);
+    if (rc != ICPGPU_OK) output.points.resize(0);
     detail::set_cloud_shape(output, output.points.size(), 0);
   }
 
@@ -267,7 +363,8 @@ template <class CloudT>
 class OctreeMap {
  public:
   explicit OctreeMap(double resolution, int device = 0)
-      : ctx_holder_(detail::thread_context(device)), ctx_(ctx_holder_.get()), resolution_(resolution) { resetMap(); }
+      : ctx_holder_(detail::acquire_context(device)), ctx_(ctx_holder_->ctx), resolution_(resolution) { resetMap(); }
+  const detail::ContextPtr& context() const { return ctx_holder_; }  // for IterativeClosestPoint::setInputTargetFromMap(map.context())
   void resetMap() { icpgpu_map_reset(ctx_, resolution_); }                                     // :55-59
   std::size_t addPointsToMap(const CloudT& cloud, const Matrix4& pose) {                         // :62-69 (+ :135, :152)
     std::size_t added = 0;
@@ -287,7 +384,8 @@ class OctreeMap {
       m = 0;
     nearest_neighbors.points.resize(m);
     detail::set_cloud_shape(nearest_neighbors, m, 0);
-    detail::context_generation(ctx_) = detail::next_generation();  // the context's source / target are the map's now
+    ++ctx_holder_->generation;  // the context's source / target are the map's now
+    detail::last_map_context() = ctx_holder_;
     return m > 0;
   }
   std::size_t size() const {

@@ -109,3 +109,22 @@ def test_product_never_imports_oracle():
                     "oracle/icp_oracle.c", ""), f
     for f in os.listdir(os.path.join(ROOT, "include")):
         assert "oracle" not in open(os.path.join(ROOT, "include", f)).read()
+
+
+def test_fingerprint_is_a_content_hash(built):
+    """icpgpu_fingerprint (host side of icpgpu_set_target's recognition): equal for equal content wherever the buffer lives,
+    different for one flipped bit, for two swapped points, for a shorter cloud."""
+    import ctypes as C
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(1000, 4)).astype(np.float32)
+    fp = lambda x: lib.icpgpu_fingerprint(x.ctypes.data_as(C.POINTER(C.c_float)), x.shape[0])
+    assert fp(a) == fp(a.copy()) != 0
+    b = a.copy()
+    b.view(np.uint32)[517, 2] ^= 1
+    assert fp(b) != fp(a)
+    c = a.copy()
+    c[[3, 4]] = c[[4, 3]]
+    assert fp(c) != fp(a)
+    assert fp(a[:999]) != fp(a)
+    assert fp(np.zeros((0, 4), np.float32)) == fp(np.zeros((0, 4), np.float32))

@@ -16,7 +16,7 @@ def _build_demo(tmp_path, name="shim_demo"):
     libdir = os.path.dirname(_lib.LIB_PATH)
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", str(exe), "-L", libdir, "-licpgpu",
-                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-pthread"])
     return exe
 
 
@@ -165,3 +165,62 @@ def test_plain_c_binding_matches_oracle(built, tmp_path):
         assert int(vals[0]) == int(ref["converged"]) and int(vals[1]) == ref["iterations"] and int(vals[2]) == ref["n_corr"]
         assert abs(float(vals[3]) - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
         assert np.abs(T[:3, :3] - ref["T"][:3, :3]).max() <= 1e-4 and np.linalg.norm(T[:3, 3] - ref["T"][:3, 3]) <= 1e-3
+
+
+# ---- the boundary exactly as integrated: fresh VoxelGrid + fresh GICP object per scan, host clouds, rotating threads ----------
+def _run_pipeline(exe, tmp_path, a, b, n_scans, leaf, iters, threads, env=None):
+    pa, pb = tmp_path / "a.bin", tmp_path / "b.bin"
+    a.tofile(pa)
+    b.tofile(pb)
+    return subprocess.run([str(exe), str(pa), str(a.shape[0]), str(pb), str(b.shape[0]), str(n_scans), repr(leaf), str(iters),
+                           str(threads), "2"], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+
+
+def test_odometer_pipeline_demo_compiles_and_fails_loudly_without_gpu(built, tmp_path):
+    import torch
+    exe = _build_demo(tmp_path, "odometer_pipeline_demo")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    a, b, _ = synth.make_pair(100, 100, seed=1)
+    r = _run_pipeline(exe, tmp_path, a, b, 4, 0.2, 10, 2)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_odometer_pipeline_as_integrated_matches_the_resident_pipeline_bit_for_bit(built, tmp_path):
+    """laserCloudCallback with the two swapped type names (tests/cpp/odometer_pipeline_demo.cpp), callbacks rotating over 4
+    threads: every scan's transform, iteration count and fitness equal the C-ABI pipeline's (device voxel filter -> GICP ->
+    fitness -> promote on ONE context) bit for bit -- with icpgpu_set_target's recognition of the previous source and
+    without it (ICPGPU_RECOGNISE=0: every target uploaded and rebuilt)."""
+    from icpslam_amd import GICP, Context
+    exe = _build_demo(tmp_path, "odometer_pipeline_demo")
+    a, b, _ = synth.make_pair(60000, 60000, seed=21)
+    n_scans, leaf = 9, 0.2
+    want = []
+    with Context(0) as c:
+        c.set_params(c.default_params(), method=GICP, max_iterations=10)
+        for k in range(n_scans):
+            c.set_source_voxel_filtered((a, b)[k % 2], leaf)
+            if k == 0:
+                c.promote_source_to_target()
+                continue
+            r = c.align(want_fitness=True)
+            want.append(r)
+            if r["converged"] and r["fitness"] < 20:
+                c.promote_source_to_target()
+    assert len(want) == n_scans - 1
+    rates = {}
+    for threads, env in ((4, {}), (1, {}), (4, {"ICPGPU_RECOGNISE": "0"})):
+        r = _run_pipeline(exe, tmp_path, a, b, n_scans, leaf, 10, threads, env)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.strip().splitlines()
+        assert lines[-1].startswith("TIMING")
+        rates[(threads, bool(env))] = float(lines[-1].split()[6])
+        rows = [ln.split() for ln in lines[:-1]]
+        assert len(rows) == len(want)
+        for row, ref in zip(rows, want):
+            T = np.array([float(v) for v in row[5:21]], np.float32).reshape(4, 4).T
+            assert int(row[1]) == int(ref["converged"]) and int(row[2]) == ref["iterations"]
+            assert np.array_equal(T, ref["T"]), (row[0], threads, env)
+            assert float(row[3]) == ref["fitness"]
+    print("shim pipeline scans/s:", rates)

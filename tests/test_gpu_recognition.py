@@ -1,0 +1,68 @@
+"""icpgpu_set_target recognises a cloud the context already holds (include/icpgpu.h): the reference hands scan k-1's source
+back as scan k's target (`*prev_cloud_ = *curr_cloud_`, /root/reference/src/icpslam/icp_odometer.cpp:209 then :194)."""
+import numpy as np
+import pytest
+
+from icpslam_amd import GICP, Context, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("method", ["p2p", "gicp"])
+@pytest.mark.parametrize("n", [30000, 120000])
+def test_previous_source_is_recognised_and_results_do_not_change(built, method, n):
+    a, b, _ = synth.make_pair(n, n, seed=31)
+    c3, _, _ = synth.make_pair(n, n, seed=32)
+    kw = dict(max_iterations=6)
+    if method == "gicp":
+        kw["method"] = GICP
+    with Context(0) as fresh:                      # what a context without history answers for (source c3, target a)
+        fresh.set_params(fresh.default_params(), **kw)
+        fresh.set_source(c3)
+        fresh.set_target(a)
+        want = fresh.align(want_fitness=True)
+    with Context(0) as c:
+        c.set_params(c.default_params(), **kw)
+        c.set_target(b)
+        c.set_source(a)
+        c.align()
+        before = c.profile()
+        c.set_target(a.copy())                     # the previous source, in another host buffer: the promote path
+        mid = c.profile()
+        assert mid.targets_recognised == before.targets_recognised + 1
+        assert c.n_target == n and c.n_source == 0
+        c.set_source(c3)
+        got = c.align(want_fitness=True)
+        assert np.array_equal(got["T"], want["T"]) and got["iterations"] == want["iterations"]
+        assert got["n_corr"] == want["n_corr"] and got["fitness"] == want["fitness"]
+        c.set_target(a.copy())                     # the unchanged target (a rejected scan keeps prev_cloud_): nothing to do
+        after = c.profile()
+        assert after.targets_recognised == mid.targets_recognised + 1 and after.grid_builds == c.profile().grid_builds
+        again = c.align(want_fitness=True)
+        assert np.array_equal(again["T"], want["T"]) and again["fitness"] == want["fitness"]
+        # same size, one bit different: NOT recognised, uploaded
+        a2 = a.copy()
+        a2.view(np.uint32)[n // 2, 1] ^= 1
+        c.set_target(a2)
+        assert c.profile().targets_recognised == after.targets_recognised
+        with Context(0) as fresh2:
+            fresh2.set_params(fresh2.default_params(), **kw)
+            fresh2.set_source(c3)
+            fresh2.set_target(a2)
+            want2 = fresh2.align()
+        got2 = c.align()
+        assert np.array_equal(got2["T"], want2["T"]) and got2["n_corr"] == want2["n_corr"]
+
+
+def test_device_and_host_fingerprints_agree(built):
+    """The recognition compares a host hash of the new buffer with a device hash of the resident cloud: sizes around the
+    kernel's block and grid boundaries, NaNs and negative zeros included."""
+    rng = np.random.default_rng(5)
+    with Context(0) as c:
+        for n in (1, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4097, 300001, 1048577 + 5):
+            a = rng.normal(size=(n, 4)).astype(np.float32)
+            a[0, :] = (-0.0, np.nan, np.inf, 1.0)
+            c.set_source(a)
+            base = c.profile().targets_recognised
+            c.set_target(a.copy())
+            assert c.profile().targets_recognised == base + 1, n
