@@ -609,7 +609,12 @@ int gicp_direct_blocks(int n_s, int most) {
     const int v = e ? std::atoi(e) : kGicpDirectBlocks;
     return v < 1 ? 1 : (v > kGicpDirectBlocks ? kGicpDirectBlocks : v);
   }();
-  int blocks = (n_s + 1023) / 1024;  // >= 4 points per thread: the grid-stride loop keeps the few workgroups busy
+  static const int per_block = [] {  // ICPGPU_GICP_PER_BLOCK (tuning): correspondences per workgroup of 256 lanes
+    const char* e = std::getenv("ICPGPU_GICP_PER_BLOCK");
+    const int v = e ? std::atoi(e) : 1024;
+    return v < 256 ? 256 : (v > 4096 ? 4096 : v);
+  }();
+  int blocks = (n_s + per_block - 1) / per_block;
   if (blocks > cap) blocks = cap;
   if (blocks > most) blocks = most;  // (the caller's share of the chip: several contexts' servers must all be resident)
   if (blocks < 1) blocks = 1;

@@ -1162,6 +1162,7 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
   c->prof.gicp_cov_launches += 1;
   c->prof.gicp_cov_ms += ms;
+  c->prof.gicp_cov_points += (uint64_t)cloud.n;
   cov_version = version;
   return ICPGPU_OK;
 }
@@ -1349,6 +1350,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       gicp_apply_state(T, x);
       // ~300 evaluations per align, each a dependent launch: ONE kernel of a few workgroups whose partial sums land in the
       // polled host mailbox; the host adds them in workgroup order (deterministic)
+      const auto t_eval0 = std::chrono::steady_clock::now();
       unsigned long long seq = ++c->sums_seq;
       if ((unsigned int)seq == kGicpServerExit) seq = (c->sums_seq += 2);  // (never a command number; the server skips it too)
       const int nblk = gicp_direct_blocks(n_s, c->gicp_blocks_most);
@@ -1398,7 +1400,9 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         c->gt_last = tq3;
       }
       c->prof.gicp_cost_launches += 1;
+      c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_eval0).count();
       const double* s = c->h_sums;
+      c->prof.gicp_eval_corr += (uint64_t)s[0];
       m_count = s[0];
       mse = s[0] > 0 ? s[14] / s[0] : 0.0;
       if (!(s[0] >= 1.0)) {
@@ -2028,6 +2032,8 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
     c->prof.voxel_launches += p.voxel_launches; c->prof.voxel_ms += p.voxel_ms; c->prof.voxel_bytes += p.voxel_bytes;
     c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;
+    c->prof.gicp_eval_ms += p.gicp_eval_ms; c->prof.gicp_eval_corr += p.gicp_eval_corr; c->prof.gicp_cov_points += p.gicp_cov_points;
+    c->prof.targets_recognised += p.targets_recognised;
     std::memset(&p, 0, sizeof(p));
   }
   for (const ThreadError& e : errors)  // the first failure in thread order (each thread stops at its first)

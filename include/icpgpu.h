@@ -136,6 +136,10 @@ typedef struct {
   uint64_t grid_timed;        /*   event records around a sweep are barrier packets that cost 6-7 us per iteration */
   uint64_t reduce_timed;
   uint64_t grid_bounded;      /* grid sweeps whose searches were pruned by the neighbours the previous sweep found */
+  double gicp_eval_ms;        /* GICP: host wall time of the BFGS cost evaluations, command written -> 13 sums merged (the
+                               * evaluations are dependent host <-> device round trips; this is what a registration waits for) */
+  uint64_t gicp_eval_corr;    /* correspondences those evaluations reduced over, summed (88 algorithmic bytes each) */
+  uint64_t gicp_cov_points;   /* points whose covariances the gicp_cov passes computed (16 B read + 48 B written each, + the 20-NN search) */
   uint64_t targets_recognised; /* icpgpu_set_target calls that found the cloud already in HBM (no upload, no rebuild) */
 } icpgpu_profile;
 
