@@ -42,89 +42,124 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// Left singular vectors of a symmetric 3x3 (row-major), columns sorted by decreasing singular value: one-sided Jacobi on
-// W = A V (sweeps over (0,1), (0,2), (1,2) until the largest relative off-diagonal of a sweep is below 1e-16, at most 60
-// sweeps), U = normalised columns of W, completed when a singular value vanishes.  OPERATION FOR OPERATION what the oracle
-// does (its restatement of the JacobiSVD call in PCL's computeCovariances): on a clean plane patch every method agrees to
-// 1e-15, but on a patch with two (nearly) equal singular values the vectors are whatever the method's rounding makes
-// them, and a regularised covariance that differs in its 10th digit is a different optimisation problem for the chaotic
-// BFGS that follows.  Same operations, same bits.
+// Left singular vectors of a symmetric 3x3 (row-major), columns by decreasing singular value: Eigen::JacobiSVD<Matrix3d>(A,
+// ComputeFullU).matrixU() as the CPU checker restates it for computeCovariances (Eigen 3.3's two-sided Jacobi iteration on the
+// scaled matrix, pairs (1,0) (2,0) (2,1), a pair rotated while an off-diagonal exceeds 2 eps x the largest diagonal met so far,
+// real_2x2_jacobi_svd + makeJacobi, diagonal signs into U, descending selection sort) -- OPERATION FOR OPERATION: on a patch
+// with two (nearly) equal singular values the vectors are whatever the method's rounding makes them, and a regularised
+// covariance that differs in its 10th digit is a different optimisation problem for the chaotic BFGS that follows.
+// Until round 3 both sides ran a one-sided iteration whose stopping rule was relative to each column pair: 0.6 % of a scan's
+// patches (near-planar: the third column is noise) hovered at it for all 60 sweeps and every wave waited for such a lane
+// (136 us per 22k-point cloud); Eigen's rule is relative to the LARGEST singular value and ends after 2-4 sweeps.
+constexpr int kSvdMaxSweeps = 64;  // (Eigen has no cap; this one only guards non-finite input, the checker has the same)
+__device__ __forceinline__ void svd_rot_rows(double* W, int p, int q, double c, double s) {
+  if (c == 1.0 && s == 0.0) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double xi = W[3 * p + i], yi = W[3 * q + i];
+    W[3 * p + i] = c * xi + s * yi;
+    W[3 * q + i] = -s * xi + c * yi;
+  }
+}
+__device__ __forceinline__ void svd_rot_cols(double* W, int p, int q, double c, double s) {
+  if (c == 1.0 && s == 0.0) return;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double xi = W[3 * i + p], yi = W[3 * i + q];
+    W[3 * i + p] = c * xi - s * yi;
+    W[3 * i + q] = s * xi + c * yi;
+  }
+}
 __device__ void svd3_left_vectors(const double A[9], double U[9]) {
+  const double kMin = 2.2250738585072014e-308, kEps = 2.220446049250313e-16;  // DBL_MIN, DBL_EPSILON
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+    if (fabs(A[i]) > scale) scale = fabs(A[i]);
+  if (scale == 0.0) scale = 1.0;
   double W[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) W[i] = A[i];
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0;
+  for (int i = 0; i < 9; ++i) {
+    W[i] = A[i] / scale;
+    U[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+  const double precision = 2.0 * kEps;
+  double max_diag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
+  for (int sweep = 0; sweep < kSvdMaxSweeps; ++sweep) {
+    bool finished = true;
 #pragma unroll
     for (int pq = 0; pq < 3; ++pq) {
-      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
-      double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        alpha += W[r * 3 + p] * W[r * 3 + p];
-        beta += W[r * 3 + q] * W[r * 3 + q];
-        gamma += W[r * 3 + p] * W[r * 3 + q];
+      const int p = pq == 0 ? 1 : 2, q = pq == 2 ? 1 : 0;  // (1,0) (2,0) (2,1)
+      const double threshold = fmax(kMin, precision * max_diag);
+      if (!(fabs(W[3 * p + q]) > threshold || fabs(W[3 * q + p]) > threshold)) continue;
+      finished = false;
+      double m00 = W[3 * p + p], m01 = W[3 * p + q], m10 = W[3 * q + p], m11 = W[3 * q + q];
+      double c1, s1;
+      const double t = m00 + m11, d = m10 - m01;
+      if (fabs(d) < kMin) {
+        s1 = 0.0;
+        c1 = 1.0;
+      } else {
+        const double u = t / d, tmp = sqrt(1.0 + u * u);
+        s1 = 1.0 / tmp;
+        c1 = u / tmp;
       }
-      if (gamma == 0.0) continue;
-      const double lim = sqrt(alpha * beta);
-      if (fabs(gamma) <= 1e-300 || fabs(gamma) <= 1e-17 * lim) continue;
-      off = fmax(off, fabs(gamma) / (lim > 0 ? lim : 1.0));
-      const double zeta = (beta - alpha) / (2.0 * gamma);
-      const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-      const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+      if (!(c1 == 1.0 && s1 == 0.0)) {
+        const double a0 = m00, a1 = m01, b0 = m10, b1 = m11;
+        m00 = c1 * a0 + s1 * b0;
+        m01 = c1 * a1 + s1 * b1;
+        m10 = -s1 * a0 + c1 * b0;
+        m11 = -s1 * a1 + c1 * b1;
+      }
+      double cr, sr;
+      const double deno = 2.0 * fabs(m01);
+      if (deno < kMin) {
+        cr = 1.0;
+        sr = 0.0;
+      } else {
+        const double tau = (m00 - m11) / deno, w = sqrt(tau * tau + 1.0);
+        const double tt = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        const double sign_t = tt > 0.0 ? 1.0 : -1.0, n = 1.0 / sqrt(tt * tt + 1.0);
+        sr = -sign_t * (m01 / fabs(m01)) * fabs(tt) * n;
+        cr = n;
+      }
+      const double cl = c1 * cr - s1 * (-sr), sl = c1 * (-sr) + s1 * cr;
+      svd_rot_rows(W, p, q, cl, sl);
+      svd_rot_cols(U, p, q, cl, -sl);
+      svd_rot_cols(W, p, q, cr, sr);
+      max_diag = fmax(max_diag, fmax(fabs(W[3 * p + p]), fabs(W[3 * q + q])));
+    }
+    if (finished) break;
+  }
+  double sv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double a = fabs(W[4 * i]);
+    sv[i] = a * scale;
+    if (a != 0.0) {
+      const double f = W[4 * i] / a;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) U[3 * r + i] *= f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int pos = i;
+#pragma unroll
+    for (int k = i + 1; k < 3; ++k)
+      if (sv[k] > sv[pos]) pos = k;
+    if (sv[pos] == 0.0) break;
+    if (pos != i) {
+      const double ts = sv[i];
+      sv[i] = sv[pos];
+      sv[pos] = ts;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const double wp = W[r * 3 + p], wq = W[r * 3 + q];
-        W[r * 3 + p] = c * wp - sn * wq;
-        W[r * 3 + q] = sn * wp + c * wq;
+        const double tu = U[3 * r + i];
+        U[3 * r + i] = U[3 * r + pos];
+        U[3 * r + pos] = tu;
       }
     }
-    if (off < 1e-16) break;
-  }
-  double nrm[3];
-  int ord[3] = {0, 1, 2};
-#pragma unroll
-  for (int j = 0; j < 3; ++j) nrm[j] = sqrt(W[0 * 3 + j] * W[0 * 3 + j] + W[1 * 3 + j] * W[1 * 3 + j] + W[2 * 3 + j] * W[2 * 3 + j]);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = a + 1; b < 3; ++b)
-      if (nrm[ord[b]] > nrm[ord[a]]) {
-        const int t = ord[a];
-        ord[a] = ord[b];
-        ord[b] = t;
-      }
-  double s[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int o = ord[j];
-    s[j] = nrm[o];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) U[r * 3 + j] = (nrm[o] > 0) ? W[r * 3 + o] / nrm[o] : 0.0;
-  }
-  const double tiny = 1e-13 * (s[0] > 0 ? s[0] : 1.0);
-  if (s[0] <= tiny) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    return;
-  }
-  if (s[1] <= tiny) {  // any unit vector orthogonal to u0: Gram-Schmidt on the least aligned axis
-    const double u0[3] = {U[0], U[3], U[6]};
-    const int k = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
-    double e[3] = {0.0, 0.0, 0.0};
-    e[k] = 1.0;
-    const double d = u0[k];
-    const double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
-    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    U[1] = v[0] / n;
-    U[4] = v[1] / n;
-    U[7] = v[2] / n;
-  }
-  if (s[2] <= tiny) {
-    const double a[3] = {U[0], U[3], U[6]}, b[3] = {U[1], U[4], U[7]};
-    U[2] = a[1] * b[2] - a[2] * b[1];
-    U[5] = a[2] * b[0] - a[0] * b[2];
-    U[8] = a[0] * b[1] - a[1] * b[0];
   }
 }
 

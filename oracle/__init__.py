@@ -80,6 +80,8 @@ def lib():
         L.orc_gicp_covariances_ex.argtypes = [fp, C.c_size_t, C.c_int, C.c_int, dp]
         L.orc_svd3.argtypes = [dp, dp, dp, dp]
         L.orc_svd3.restype = None
+        L.orc_svd3_eigen_u.argtypes = [dp, dp, dp]
+        L.orc_svd3_eigen_u.restype = None
         L.orc_map_create.argtypes = [C.c_double]
         L.orc_map_create.restype = C.c_void_p
         L.orc_map_destroy.argtypes = [C.c_void_p]
@@ -204,6 +206,15 @@ def gicp_covariances(cloud, arith=ARITH_FMA, pcl_order=False) -> np.ndarray:
     if rc != 0:
         raise RuntimeError("orc_gicp_covariances: cloud smaller than k = 20")
     return out.reshape(-1, 3, 3)
+
+
+def svd3_eigen_u(A):
+    """Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU): (U, singular values) as gicp_oracle.c restates it (computeCovariances)."""
+    A = np.ascontiguousarray(A, np.float64)
+    U, s = np.empty((3, 3)), np.empty(3)
+    dp = C.POINTER(C.c_double)
+    lib().orc_svd3_eigen_u(A.ctypes.data_as(dp), U.ctypes.data_as(dp), s.ctypes.data_as(dp))
+    return U, s
 
 
 def svd3(A):

@@ -77,6 +77,121 @@ static void inv3(const double A[9], double Inv[9]) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Eigen::JacobiSVD<Matrix3d>(cov, ComputeFullU).matrixU()                                     */
+/* ------------------------------------------------------------------------------------------ */
+/* What computeCovariances calls (PCL registration/impl/gicp.hpp: `Eigen::JacobiSVD<Eigen::Matrix3d> svd(cov,
+ * Eigen::ComputeFullU); ... col = svd.matrixU().col(k)`), restated from Eigen 3.3's SVD/JacobiSVD.h and Jacobi/Jacobi.h (not
+ * under /root/reference; unpinned like PCL itself): the TWO-SIDED Jacobi iteration on the matrix scaled by its largest
+ * entry -- pairs (1,0), (2,0), (2,1); a pair is rotated while |w_pq| or |w_qp| exceeds max(DBL_MIN, 2 eps * maxDiagEntry),
+ * maxDiagEntry the largest |diagonal| met so far (the stopping rule is relative to the LARGEST singular value: a near-planar
+ * patch does not make it hover, unlike the column-relative rule of the one-sided iteration this replaced in round 3);
+ * real_2x2_jacobi_svd = a rotation that symmetrises the 2x2 block followed by makeJacobi's symmetric Jacobi rotation; then
+ * signs of the diagonal into U's columns and a descending selection sort of the singular values.  Row-major 3x3 arrays.
+ * The sweep cap (Eigen has none) only guards non-finite input; the GPU kernel (icp_gicp.hip, svd3_eigen_u) performs the same
+ * operations in the same order. */
+#define ORC_SVD_MAX_SWEEPS 64
+static void rot_rows(double* W, int p, int q, double c, double s) { /* applyOnTheLeft(p, q, {c, s}) */
+  if (c == 1.0 && s == 0.0) return;
+  for (int i = 0; i < 3; ++i) {
+    const double xi = W[3 * p + i], yi = W[3 * q + i];
+    W[3 * p + i] = c * xi + s * yi;
+    W[3 * q + i] = -s * xi + c * yi;
+  }
+}
+static void rot_cols(double* W, int p, int q, double c, double s) { /* applyOnTheRight(p, q, {c, s}): the transposed rotation on columns */
+  if (c == 1.0 && s == 0.0) return;
+  for (int i = 0; i < 3; ++i) {
+    const double xi = W[3 * i + p], yi = W[3 * i + q];
+    W[3 * i + p] = c * xi - s * yi;
+    W[3 * i + q] = s * xi + c * yi;
+  }
+}
+void orc_svd3_eigen_u(const double A[9], double U[9], double sv[3]) {
+  double scale = 0.0;
+  for (int i = 0; i < 9; ++i)
+    if (fabs(A[i]) > scale) scale = fabs(A[i]);
+  if (scale == 0.0) scale = 1.0;
+  double W[9];
+  for (int i = 0; i < 9; ++i) W[i] = A[i] / scale;
+  for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  const double precision = 2.0 * DBL_EPSILON, consider_as_zero = DBL_MIN;
+  double max_diag = fmax(fabs(W[0]), fmax(fabs(W[4]), fabs(W[8])));
+  for (int sweep = 0; sweep < ORC_SVD_MAX_SWEEPS; ++sweep) {
+    int finished = 1;
+    for (int p = 1; p < 3; ++p)
+      for (int q = 0; q < p; ++q) {
+        const double threshold = fmax(consider_as_zero, precision * max_diag);
+        if (!(fabs(W[3 * p + q]) > threshold || fabs(W[3 * q + p]) > threshold)) continue;
+        finished = 0;
+        /* real_2x2_jacobi_svd on m = [w_pp w_pq; w_qp w_qq] */
+        double m00 = W[3 * p + p], m01 = W[3 * p + q], m10 = W[3 * q + p], m11 = W[3 * q + q];
+        double c1, s1;
+        const double t = m00 + m11, d = m10 - m01;
+        if (fabs(d) < DBL_MIN) {
+          s1 = 0.0;
+          c1 = 1.0;
+        } else {
+          const double u = t / d, tmp = sqrt(1.0 + u * u);
+          s1 = 1.0 / tmp;
+          c1 = u / tmp;
+        }
+        if (!(c1 == 1.0 && s1 == 0.0)) { /* m.applyOnTheLeft(0, 1, rot1) */
+          const double a0 = m00, a1 = m01, b0 = m10, b1 = m11;
+          m00 = c1 * a0 + s1 * b0;
+          m01 = c1 * a1 + s1 * b1;
+          m10 = -s1 * a0 + c1 * b0;
+          m11 = -s1 * a1 + c1 * b1;
+        }
+        /* j_right = makeJacobi(m00, m01, m11) */
+        double cr, sr;
+        const double deno = 2.0 * fabs(m01);
+        if (deno < DBL_MIN) {
+          cr = 1.0;
+          sr = 0.0;
+        } else {
+          const double tau = (m00 - m11) / deno, w = sqrt(tau * tau + 1.0);
+          const double tt = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+          const double sign_t = tt > 0.0 ? 1.0 : -1.0, n = 1.0 / sqrt(tt * tt + 1.0);
+          sr = -sign_t * (m01 / fabs(m01)) * fabs(tt) * n;
+          cr = n;
+        }
+        /* j_left = rot1 * j_right^T:  c = c1 cr - s1 (-sr),  s = c1 (-sr) + s1 cr */
+        const double cl = c1 * cr - s1 * (-sr), sl = c1 * (-sr) + s1 * cr;
+        rot_rows(W, p, q, cl, sl);           /* m_workMatrix.applyOnTheLeft(p, q, j_left) */
+        rot_cols(U, p, q, cl, -sl);          /* m_matrixU.applyOnTheRight(p, q, j_left.transpose()) */
+        rot_cols(W, p, q, cr, sr);           /* m_workMatrix.applyOnTheRight(p, q, j_right) */
+        max_diag = fmax(max_diag, fmax(fabs(W[3 * p + p]), fabs(W[3 * q + q])));
+      }
+    if (finished) break;
+  }
+  for (int i = 0; i < 3; ++i) { /* signs of the diagonal into U; singular values */
+    const double a = fabs(W[4 * i]);
+    sv[i] = a;
+    if (a != 0.0) {
+      const double f = W[4 * i] / a;
+      for (int r = 0; r < 3; ++r) U[3 * r + i] *= f;
+    }
+  }
+  for (int i = 0; i < 3; ++i) sv[i] *= scale;
+  for (int i = 0; i < 3; ++i) { /* descending selection sort, columns of U follow */
+    int pos = i;
+    for (int k = i + 1; k < 3; ++k)
+      if (sv[k] > sv[pos]) pos = k;
+    if (sv[pos] == 0.0) break;
+    if (pos != i) {
+      const double ts = sv[i];
+      sv[i] = sv[pos];
+      sv[pos] = ts;
+      for (int r = 0; r < 3; ++r) {
+        const double tu = U[3 * r + i];
+        U[3 * r + i] = U[3 * r + pos];
+        U[3 * r + pos] = tu;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* computeCovariances                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 int orc_gicp_covariances_ex(const float* cloud, size_t n, int arith, int pcl_order, double* cov_out /* n x 9 row-major */) {
@@ -107,8 +222,8 @@ int orc_gicp_covariances_ex(const float* cloud, size_t n, int arith, int pcl_ord
         cov[3 * k + l] -= mean[k] * mean[l];
         cov[3 * l + k] = cov[3 * k + l];
       }
-    double U[9], s[3], V[9];
-    orc_svd3(cov, U, s, V);
+    double U[9], s[3];
+    orc_svd3_eigen_u(cov, U, s);
     /* cov = sum_k v_k u_k u_k^T, v = (1, 1, epsilon).  The lower triangle is computed -- entry (r, c) = sum_k (v_k u_rk) u_ck,
      * the expression Eigen evaluates for `v * col * col.transpose()` -- and mirrored: in PCL the two triangles can differ in
      * the last bit of the epsilon term ((eps a) b vs (eps b) a), 1e-19 absolute; an implementation that stores six entries
