@@ -193,6 +193,12 @@ struct MapDesc {
   double ox, oy, oz;  // lattice origin = first inserted point - resolution / 2 (PCL OctreePointCloud bounding-box rule)
   double res;         // voxel size (octree_resolution_, 0.5 m)
 };
+// generic primitives (icp_scan.hip): exclusive prefix sum of int32 (scratch: exclusive_scan_scratch_ints(n) ints) and a stable
+// LSD radix sort of (key, value) int32 pairs from the first halves of keys / vals (2 n ints each) into the second halves
+size_t exclusive_scan_scratch_ints(int n);
+hipError_t launch_exclusive_scan(const int* in, int* out, int n, int* scratch, hipStream_t stream);
+size_t radix_sort_scratch_ints(int n);
+hipError_t launch_radix_sort_pairs(int* keys, int* vals, int n, unsigned int end_bit, int* scratch, hipStream_t stream);
 size_t map_scan_temp_bytes(int n);
 // hash set: keys (packed voxel coordinates, all-ones = empty), vals (map index, -1 = claimed this call), first (bids)
 hipError_t launch_map_fill(unsigned long long* keys, int* vals, int* first, unsigned int cap, hipStream_t stream);

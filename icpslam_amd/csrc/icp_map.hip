@@ -18,7 +18,6 @@
 #include "icp_kernels.h"
 
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>
 
 #include "icp_device.h"
 
@@ -193,12 +192,7 @@ __global__ __launch_bounds__(256) void map_unique_gather_kernel(const int* __res
 
 }  // namespace
 
-size_t map_scan_temp_bytes(int n) {
-  size_t b = 0;
-  int* ip = nullptr;
-  (void)rocprim::exclusive_scan(nullptr, b, ip, ip, 0, (size_t)(n > 0 ? n : 1), rocprim::plus<int>(), (hipStream_t) nullptr);
-  return b;
-}
+size_t map_scan_temp_bytes(int n) { return exclusive_scan_scratch_ints(n) * sizeof(int); }
 
 hipError_t launch_map_fill(unsigned long long* keys, int* vals, int* first, unsigned int cap, hipStream_t stream) {
   hipLaunchKernelGGL(map_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys, vals, first, cap);
@@ -219,7 +213,7 @@ hipError_t launch_map_insert(const float4* in, int n, const Xform& T, const MapD
   const dim3 grid((n + 255) / 256), block(256);
   hipLaunchKernelGGL(map_claim_kernel, grid, block, 0, stream, in, n, T, m, keys, vals, first, cap - 1, moved, slot_of);
   hipLaunchKernelGGL(map_flag_kernel, grid, block, 0, stream, slot_of, first, n, flags);
-  hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, flags, rank, 0, (size_t)n, rocprim::plus<int>(), stream);
+  hipError_t e = launch_exclusive_scan(flags, rank, n, static_cast<int*>(temp), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(map_commit_kernel, grid, block, 0, stream, moved, slot_of, flags, rank, n, base, map_pts, vals, first,
                      d_n_added);
@@ -231,7 +225,7 @@ hipError_t launch_map_nn_gather(const unsigned long long* keys, int n, const flo
   if (n <= 0) return hipSuccess;
   const dim3 grid((n + 255) / 256), block(256);
   hipLaunchKernelGGL(map_nn_flag_kernel, grid, block, 0, stream, keys, n, flags);
-  hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, flags, rank, 0, (size_t)n, rocprim::plus<int>(), stream);
+  hipError_t e = launch_exclusive_scan(flags, rank, n, static_cast<int*>(temp), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(map_nn_gather_kernel, grid, block, 0, stream, keys, flags, rank, n, map_pts, T_out, out, d_n_out);
   return hipGetLastError();
@@ -246,7 +240,7 @@ hipError_t launch_map_nn_unique(const unsigned long long* keys, const int* flags
   const dim3 grid((n + 255) / 256), block(256);
   hipLaunchKernelGGL(map_first_user_kernel, grid, block, 0, stream, keys, flags, n, first_user);
   hipLaunchKernelGGL(map_unique_flag_kernel, grid, block, 0, stream, keys, flags, n, first_user, uflags);
-  e = rocprim::exclusive_scan(temp, temp_bytes, uflags, urank, 0, (size_t)n, rocprim::plus<int>(), stream);
+  e = launch_exclusive_scan(uflags, urank, n, static_cast<int*>(temp), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(map_unique_gather_kernel, grid, block, 0, stream, uflags, urank, rank, n, nn_cloud, uniq, uniq_index,
                      d_n_uniq);

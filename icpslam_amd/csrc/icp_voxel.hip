@@ -7,7 +7,7 @@
 // Two paths, same float32 arithmetic as oracle/icp_oracle.c::orc_voxel_grid, output bit-identical to it:
 //   * the direct path (round 2, below): one bucket-distribution pass + a register-resident bitonic sort of LDS-sized groups --
 //     three hand-written launches, 37 us for a raw 200k-point scan;
-//   * the library-sort path (round 1): rocPRIM's stable radix sort over the 31-bit keys (32 when the index wraps, see
+//   * the sort path (round 1; its stable radix sort was a library call until round 3, now icp_scan.hip): 31-bit keys (32 when the index wraps, see
 //     launch_voxel_grid), boundary flags + scan, one gather pass -- 14 launches, 105 us; kept for what the direct path hands
 //     over (a voxel bucket beyond its LDS capacity, wrapped indices, clouds over 2M points).
 #include <hip/hip_runtime.h>
@@ -19,8 +19,6 @@
 #include <cstring>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "icp_kernels.h"
 
@@ -691,11 +689,8 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
 }
 
 size_t voxel_temp_bytes(int n) {
-  size_t a = 0, b = 0;
-  int* ip = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, a, ip, ip, ip, ip, (size_t)n, 0, 32, (hipStream_t) nullptr);
-  (void)rocprim::exclusive_scan(nullptr, b, ip, ip, 0, (size_t)n, rocprim::plus<int>(), (hipStream_t) nullptr);
-  return (a > b ? a : b) + 256;
+  const size_t a = radix_sort_scratch_ints(n), b = exclusive_scan_scratch_ints(n);
+  return (a > b ? a : b) * sizeof(int) + 256;
 }
 
 // keys/vals: 2*n ints each (ping-pong), flags/slots: n ints each, d_n_out: 1 int (cells written).
@@ -715,10 +710,10 @@ hipError_t launch_voxel_grid(const float4* pts, int n, float inv_leaf, const int
   // PCL tests the float extents for overflow and indexes with the integer ones: when those are a cell wider the topmost
   // cells' index wraps negative, and PCL's sort (signed) puts them first -- the sign bit must take part then
   if (ncells > 0x7FFFFFFFll) end_bit = 32;
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys + n, vals, vals + n, (size_t)n, 0, end_bit, stream);
+  hipError_t e = launch_radix_sort_pairs(keys, vals, n, end_bit, static_cast<int*>(temp), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(voxel_flag_kernel, dim3(blocks), dim3(256), 0, stream, keys + n, n, flags);
-  e = rocprim::exclusive_scan(temp, temp_bytes, flags, slots, 0, (size_t)n, rocprim::plus<int>(), stream);
+  e = launch_exclusive_scan(flags, slots, n, static_cast<int*>(temp), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(voxel_centroid_kernel, dim3((n + VC_BLOCK - 1) / VC_BLOCK), dim3(VC_BLOCK), 0, stream, pts, keys + n,
                      vals + n, flags, slots, n, out);
