@@ -53,7 +53,7 @@ EXPORTS = [
     "icpgpu_create", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params",
     "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
     "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
-    "icpgpu_fingerprint", "icpgpu_cloud_sizes",
+    "icpgpu_fingerprint", "icpgpu_cloud_sizes", "icpgpu_align_batch_multi", "icpgpu_multi_last_error",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_profile_set_sampling", "icpgpu_get_stream", "icpgpu_synchronize",
     "icpgpu_voxel_grid", "icpgpu_voxel_grid_fetch", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
@@ -110,6 +110,11 @@ def load():
     L.icpgpu_fitness.argtypes = [vp, C.c_double, dp]
     L.icpgpu_align_batch.argtypes = [vp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp),
                                      C.POINTER(C.c_size_t), C.c_int, C.POINTER(Result)]
+    L.icpgpu_align_batch_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(Params), C.c_size_t, C.POINTER(fp),
+                                           C.POINTER(C.c_size_t), C.POINTER(fp), C.POINTER(C.c_size_t), C.c_int,
+                                           C.POINTER(Result), dp, C.c_int]
+    L.icpgpu_multi_last_error.argtypes = []
+    L.icpgpu_multi_last_error.restype = C.c_char_p
     L.icpgpu_nn.argtypes = [vp, fp, ip, fp]
     L.icpgpu_reduce.argtypes = [vp, fp, C.c_double, dp]
     L.icpgpu_solve.argtypes = [dp, dp]
@@ -151,7 +156,7 @@ def load():
         fn = getattr(L, name)
         if name in ("icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes"):
             fn.restype = C.c_long
-        elif name not in ("icpgpu_last_error", "icpgpu_default_params"):
+        elif name not in ("icpgpu_last_error", "icpgpu_default_params", "icpgpu_fingerprint", "icpgpu_multi_last_error"):
             fn.restype = C.c_int
     _lib = L
     return L

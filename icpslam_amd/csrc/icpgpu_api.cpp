@@ -1868,6 +1868,13 @@ static int usable_cpus() {
 // Host threads of a batch: every one of them spins (on mailboxes, or inside a BFGS run), so there must be no more of them
 // than CPUs -- across ALL the processes of the job: one process per GPU is the deployment (LOCAL_WORLD_SIZE, set by
 // torch.distributed.run, says how many share this host's CPUs).  ICPGPU_BATCH_THREADS overrides.
+// batch drivers inside THIS process that share its CPUs (icpgpu_align_batch_multi: one per device)
+static std::atomic<int> g_host_share{1};
+extern "C++" {
+namespace icpgpu {
+void set_host_share(int peers) { g_host_share.store(peers < 1 ? 1 : peers); }
+}
+}
 static size_t batch_threads(size_t cap) {
   size_t t = 0;
   if (const char* v = std::getenv("ICPGPU_BATCH_THREADS")) t = (size_t)std::max(0, std::atoi(v));
@@ -1875,6 +1882,7 @@ static size_t batch_threads(size_t cap) {
   if (t == 0) {
     int local = 1;
     if (const char* l = std::getenv("LOCAL_WORLD_SIZE")) local = std::max(1, std::atoi(l));
+    local *= g_host_share.load();
     t = (size_t)std::max(1, usable_cpus() / local);
     t = std::min(t, cap);
   }

@@ -90,3 +90,35 @@ def run_sharded(n_items: int, rank: int, world: int, load_pair, align_pair, devi
         recs.append(make_record(k, align_pair(src, tgt)))
     local = np.stack(recs) if recs else np.zeros((0, RECORD_LEN))
     return gather_records(local, n_items, rank, world, device)
+
+
+COMM_NONE, COMM_RCCL, COMM_HOST = 0, 1, 2
+
+
+def align_batch_multi(devices, sources, targets, params=None, want_fitness: bool = False, communicator: int = COMM_RCCL):
+    """icpgpu_align_batch_multi (include/icpgpu.h): the single-process, one-host-thread-per-GPU form of the layer above --
+    contiguous shards over `devices`, one all-gather of the 184-byte records (RCCL, or host-staged for tests).
+    Returns (list of result dicts, records (n, RECORD_LEN) or None)."""
+    import ctypes as C
+
+    from . import _lib
+    from .registration import _as_cloud, _fp, result_dict
+    L = _lib.load()
+    n = len(sources)
+    srcs = [_as_cloud(s) for s in sources]
+    tgts = [_as_cloud(t) for t in targets]
+    FP = C.POINTER(C.c_float)
+    sp = (FP * n)(*[_fp(s) for s in srcs])
+    tp = (FP * n)(*[_fp(t) for t in tgts])
+    ns = (C.c_size_t * n)(*[s.shape[0] for s in srcs])
+    nt = (C.c_size_t * n)(*[t.shape[0] for t in tgts])
+    res = (_lib.Result * n)()
+    recs = np.zeros((n, RECORD_LEN), np.float64) if communicator != COMM_NONE else None
+    dev = (C.c_int * len(devices))(*devices)
+    rc = L.icpgpu_align_batch_multi(dev, len(devices), C.byref(params) if params is not None else None, n, sp, ns, tp, nt,
+                                    int(want_fitness), res, recs.ctypes.data_as(C.POINTER(C.c_double)) if recs is not None else None,
+                                    communicator)
+    if rc != 0:
+        from .registration import IcpGpuError
+        raise IcpGpuError(rc, (L.icpgpu_multi_last_error() or b"").decode())
+    return [result_dict(r, None) for r in res], recs

@@ -200,6 +200,23 @@ int icpgpu_fitness(icpgpu_ctx* ctx, double max_range, double* out_fitness);
 int icpgpu_align_batch(icpgpu_ctx* ctx, size_t n_pairs, const float* const* src, const size_t* n_src,
                        const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results);
 
+/* The same over the GPUs of one node, from ONE process (the reference is a single C++ process,
+ * /root/reference/src/icpslam_node.cpp:3-14): entry r of `devices` gets the contiguous shard r of the pairs (sizes differ by
+ * at most one) and its own host thread driving icpgpu_align_batch on a context the library keeps for that entry; no data
+ * is exchanged during the solve.  results[k] is filled for every k.  With a communicator the result records -- 23 float64 =
+ * 184 B per pair: pair id, iterations, converged, state, n_corr, mse, fitness, T[16] row-major -- are then all-gathered
+ * across the devices (each shard padded to the largest) and the checked copy of entry 0 is returned in `records`
+ * (n_pairs x 23 doubles):
+ *   ICPGPU_COMM_NONE  no gather (records may be NULL)
+ *   ICPGPU_COMM_RCCL  ncclCommInitAll over `devices` + one ncclAllGather (librccl is loaded on first use, not linked)
+ *   ICPGPU_COMM_HOST  the same buffers, exchanged through host memory (tests on one GPU: a device may be named twice)
+ * params NULL keeps the contexts' parameters.  Errors: status code + icpgpu_multi_last_error() (per calling thread). */
+enum { ICPGPU_COMM_NONE = 0, ICPGPU_COMM_RCCL = 1, ICPGPU_COMM_HOST = 2 };
+int icpgpu_align_batch_multi(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
+                             const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
+                             int want_fitness, icpgpu_result* results, double* records, int communicator);
+const char* icpgpu_multi_last_error(void);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels as align) ------------- */
 /* a2: idx[i], d2[i] = exact nearest neighbour of T*source[i] in target (lowest index on ties);
  * idx = -1, d2 = +inf when the target is empty or the point is non-finite. */
