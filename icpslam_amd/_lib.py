@@ -61,7 +61,7 @@ EXPORTS = [
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
     "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
     "icpgpu_posegraph_get_keyframe", "icpgpu_posegraph_get_edge", "icpgpu_posegraph_write_g2o",
-    "icpgpu_map_reset", "icpgpu_map_add_points", "icpgpu_map_add_source", "icpgpu_map_size", "icpgpu_map_get_points",
+    "icpgpu_map_set_search", "icpgpu_map_reset", "icpgpu_map_add_points", "icpgpu_map_add_source", "icpgpu_map_size", "icpgpu_map_get_points",
     "icpgpu_map_nn_target", "icpgpu_count_candidates", "icpgpu_count_candidates_read",
 ]
 
@@ -139,6 +139,7 @@ def load():
     L.icpgpu_posegraph_get_edge.argtypes = [vp, C.c_long, pp]
     L.icpgpu_posegraph_write_g2o.argtypes = [vp, C.c_char_p]
     sp = C.POINTER(C.c_size_t)
+    L.icpgpu_map_set_search.argtypes = [vp, C.c_int]
     L.icpgpu_map_reset.argtypes = [vp, C.c_double]
     L.icpgpu_map_add_points.argtypes = [vp, fp, C.c_size_t, fp, sp]
     L.icpgpu_map_add_source.argtypes = [vp, fp, sp]

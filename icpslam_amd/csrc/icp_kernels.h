@@ -193,6 +193,20 @@ struct MapDesc {
   double ox, oy, oz;  // lattice origin = first inserted point - resolution / 2 (PCL OctreePointCloud bounding-box rule)
   double res;         // voxel size (octree_resolution_, 0.5 m)
 };
+// PCL's octree geometry for the faithful approxNearestSearch mode (icp_map.hip): the bounding box as
+// OctreePointCloud::adoptBoundingBoxToPoint has grown it, in double; depth = levels below the root (side = 2^depth voxels)
+struct ApproxBox {
+  double min[3], max[3];
+  double res;
+  int depth;
+};
+hipError_t launch_approx_first_outside(const float4* pts, int n, const ApproxBox& b, int* d_first, hipStream_t stream);
+hipError_t launch_approx_fill(unsigned long long* keys, int* vals, unsigned int cap, hipStream_t stream);
+hipError_t launch_approx_insert(const float4* pts, int lo, int hi, const ApproxBox& b, unsigned long long* keys, int* vals,
+                                unsigned int cap, hipStream_t stream);
+hipError_t launch_approx_descend(const float4* queries, int n, const Xform& T, const ApproxBox& b, const unsigned long long* keys,
+                                 const int* vals, unsigned int cap, unsigned long long* out, hipStream_t stream);
+int approx_max_depth();
 // generic primitives (icp_scan.hip): exclusive prefix sum of int32 (scratch: exclusive_scan_scratch_ints(n) ints) and a stable
 // LSD radix sort of (key, value) int32 pairs from the first halves of keys / vals (2 n ints each) into the second halves
 size_t exclusive_scan_scratch_ints(int n);

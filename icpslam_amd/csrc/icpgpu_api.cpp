@@ -97,6 +97,17 @@ struct VoxelMap {
   DeviceBuf first_user, uflags, urank, uniq_index;
   Cloud uniq;             // the distinct points of the last nn cloud (what the ICP target's grid is built from)
   GridIndex grid;         // for the nn-cloud search
+  // PCL-faithful approxNearestSearch mode (icpgpu_map_set_search): the octree's bounding box as PCL grows it, replayed over
+  // the map points in insertion order, and the hash set of occupied octree nodes (icp_map.hip)
+  int search_mode = ICPGPU_MAP_SEARCH_EXACT;
+  bool box_defined = false;
+  ApproxBox box{};
+  int box_upto = 0;           // map points already folded into the box
+  uint64_t box_version = 0;   // bumped whenever the box grows
+  DeviceBuf node_keys, node_vals;
+  unsigned int node_cap = 0;
+  int nodes_upto = 0;         // map points whose paths are in the node set
+  uint64_t nodes_box_version = ~0ull;
 };
 
 constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
@@ -2308,6 +2319,104 @@ int map_insert_device(icpgpu_ctx* c, const float4* d_in, int n, const float* pos
 
 }  // namespace
 
+namespace {
+// OctreePointCloud::adoptBoundingBoxToPoint for one point outside the box (oracle/map_approx_np.py::_adopt restates the same):
+// the box doubles -- all three axes at once, the old root becoming the UPPER child on every axis the point does not violate
+// from above -- until the point is inside
+void approx_adopt(VoxelMap& M, const float p[3]) {
+  ApproxBox& b = M.box;
+  const double eps = (double)FLT_EPSILON;
+  for (;;) {
+    if (!M.box_defined) {
+      for (int a = 0; a < 3; ++a) {
+        b.min[a] = (double)p[a] - b.res / 2.0;
+        b.max[a] = (double)p[a] + b.res / 2.0;
+      }
+      b.depth = 0;
+      M.box_defined = true;
+      continue;
+    }
+    bool lower[3], upper[3], any = false;
+    for (int a = 0; a < 3; ++a) {
+      lower[a] = (double)p[a] < b.min[a];
+      upper[a] = (double)p[a] >= b.max[a];
+      any = any || lower[a] || upper[a];
+    }
+    if (!any) return;
+    const double side = (double)(1ll << b.depth) * b.res;
+    for (int a = 0; a < 3; ++a)
+      if (!upper[a]) b.min[a] -= side;
+    b.depth += 1;
+    for (int a = 0; a < 3; ++a) b.max[a] = b.min[a] + ((double)(1ll << b.depth) * b.res - eps);
+  }
+}
+
+// bring the box and the node set up to date with the map, then keys[i] = approxNearestSearch(pose * source[i])
+int approx_nn_keys(icpgpu_ctx* c, const Xform& T, int n_s, unsigned long long* keys) {
+  VoxelMap& M = c->map;
+  int rc;
+  if ((rc = ensure(c, M.counter, 4 * sizeof(int)))) return rc;
+  int* d_first = static_cast<int*>(M.counter.ptr) + 2;
+  M.box.res = M.desc.res;
+  // (1) the bounding box: replay the growth over the points added since the last call (a handful of round trips per map LIFE)
+  while (M.box_upto < M.n) {
+    if (M.box_defined) {
+      HIP_TRY(c, launch_approx_first_outside(M.pts.data() + M.box_upto, M.n - M.box_upto, M.box, d_first, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_first, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (c->h_ints[0] >= M.n - M.box_upto) {  // all inside
+        M.box_upto = M.n;
+        break;
+      }
+      M.box_upto += c->h_ints[0];
+    }
+    float p[4];
+    HIP_TRY(c, hipMemcpyAsync(p, M.pts.data() + M.box_upto, sizeof(p), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    approx_adopt(M, p);
+    M.box_version++;
+    M.box_upto += 1;
+    if (M.box.depth > approx_max_depth())
+      return fail(c, ICPGPU_ERR_UNSUPPORTED, "map: the octree would be %d levels deep (approximate search supports %d)", M.box.depth,
+                  approx_max_depth());
+  }
+  // (2) the set of occupied nodes: level d holds at most min(n, 8^d) of them
+  size_t nodes = 0;
+  for (int d = 1; d <= M.box.depth; ++d) {
+    const double full = std::pow(8.0, (double)d);
+    nodes += (size_t)std::min((double)M.n, full);
+  }
+  unsigned int cap = 1u << 12;
+  while ((size_t)cap < 2 * nodes + 16) cap <<= 1;
+  bool rebuild = M.nodes_box_version != M.box_version;
+  if (cap > M.node_cap) {
+    if ((rc = ensure(c, M.node_keys, (size_t)cap * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, M.node_vals, (size_t)cap * sizeof(int)))) return rc;
+    M.node_cap = cap;
+    rebuild = true;
+  }
+  auto* nk = static_cast<unsigned long long*>(M.node_keys.ptr);
+  auto* nv = static_cast<int*>(M.node_vals.ptr);
+  if (rebuild) {
+    HIP_TRY(c, launch_approx_fill(nk, nv, M.node_cap, c->stream));
+    M.nodes_upto = 0;
+    M.nodes_box_version = M.box_version;
+  }
+  HIP_TRY(c, launch_approx_insert(M.pts.data(), M.nodes_upto, M.n, M.box, nk, nv, M.node_cap, c->stream));
+  M.nodes_upto = M.n;
+  // (3) the descent
+  HIP_TRY(c, launch_approx_descend(c->src.data(), n_s, T, M.box, nk, nv, M.node_cap, keys, c->stream));
+  return ICPGPU_OK;
+}
+}  // namespace
+
+int icpgpu_map_set_search(icpgpu_ctx* c, int mode) {
+  ENTER(c);
+  if (mode != ICPGPU_MAP_SEARCH_EXACT && mode != ICPGPU_MAP_SEARCH_PCL_APPROX) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad map search mode");
+  c->map.search_mode = mode;
+  return ICPGPU_OK;
+}
+
 int icpgpu_map_reset(icpgpu_ctx* c, double resolution) {
   ENTER(c);
   if (!(resolution > 0.0) || !std::isfinite(resolution)) return fail(c, ICPGPU_ERR_INVALID_ARG, "map: resolution must be positive");
@@ -2320,6 +2429,11 @@ int icpgpu_map_reset(icpgpu_ctx* c, double resolution) {
   M.pts.set = true;
   M.version++;
   M.cap = 0;  // the hash set is rebuilt by the next insertion
+  M.box_defined = false;
+  M.box_upto = 0;
+  M.box_version++;
+  M.nodes_upto = 0;
+  M.nodes_box_version = ~0ull;
   M.grid.built = M.grid.usable = false;
   return ICPGPU_OK;
 }
@@ -2378,13 +2492,15 @@ int icpgpu_map_nn_target(icpgpu_ctx* c, const float* pose, const float* pose_inv
   if (M.n == 0 || n_s == 0) return ICPGPU_OK;  // approxNearestNeighbors() on an empty map: empty nn cloud
 
   // exact NN of pose * s in the map: grid where the neighbour is within 2 voxel sizes, brute force for the rest
-  int rc = build_grid(c, M.pts, M.version, 2.0 * M.desc.res, /*adapt=*/true, M.grid);
-  if (rc) return rc;
+  int rc = ICPGPU_OK;
+  if (M.search_mode == ICPGPU_MAP_SEARCH_EXACT && (rc = build_grid(c, M.pts, M.version, 2.0 * M.desc.res, /*adapt=*/true, M.grid))) return rc;
   if ((rc = ensure(c, M.nn_keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
   auto* keys = static_cast<unsigned long long*>(M.nn_keys.ptr);
   const Xform T = to_xform(pose), Tinv = to_xform(pose_inv);
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-  if (M.grid.usable) {
+  if (M.search_mode == ICPGPU_MAP_SEARCH_PCL_APPROX) {
+    if ((rc = approx_nn_keys(c, T, n_s, keys))) return rc;
+  } else if (M.grid.usable) {
     if ((rc = nn_keys_grid(c, M.grid, c->src.data(), n_s, M.pts.data(), M.n, T, keys))) return rc;
   } else {
     if ((rc = nn_keys_brute(c, M.pts.data(), M.n, T, keys))) return rc;

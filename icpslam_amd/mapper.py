@@ -4,7 +4,8 @@ against the map through the same ICP call, then grows the map.
 Mirrors, call for call (/root/reference/src/icpslam/octree_mapper.cpp):
   resetMap                     :55-59    one-point-per-voxel map, octree_resolution_ = 0.5 m (:41)
   addPointsToMap               :62-69    first point of every unoccupied voxel, in input order
-  approxNearestNeighbors       :72-90    nearest map point of every scan point (EXACT here, a heuristic descent in PCL)
+  approxNearestNeighbors       :72-90    nearest map point of every scan point (EXACT by default; pcl_approx_search=True gives
+                                         PCL's heuristic descent, the reference's own nn cloud)
   transformCloudToPoseFrame    :92-99    pcl_ros::transformPointCloud with Pose6DOF::toTFTransform
   estimateTransformICP         :101-124  the ICP call of the hot path: 30 iterations (octree_mapper.h:56), no fitness gate
   refineTransformAndGrowMap    :133-172  the sequence below
@@ -15,7 +16,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from ._lib import Pose
+from ._lib import GICP, Pose
 from .registration import Context
 from .sequence import pose_compose, pose_from_matrix, pose_inverse, pose_to_matrix
 
@@ -34,8 +35,13 @@ class OctreeMapper:
 
     def __init__(self, ctx: Context, octree_resolution: float = OCTREE_RESOLUTION, max_iterations: int = ICP_MAX_ITERS,
                  transformation_epsilon: float = ICP_EPSILON, max_correspondence_distance: float = ICP_MAX_CORR_DIST,
-                 method: int | None = None):
+                 method: int | None = GICP, pcl_approx_search: bool = False):
+        """method: the solver of estimateTransformICP -- GICP by default, as the reference instantiates it
+        (pcl::GeneralizedIterativeClosestPoint, octree_mapper.cpp:104); P2P_SVD for point-to-point.  pcl_approx_search: collect
+        the nn cloud with PCL's approxNearestSearch heuristic (what octree_mapper.cpp:84 literally calls) instead of the exact
+        nearest map point."""
         self.ctx = ctx
+        self.pcl_approx_search = bool(pcl_approx_search)
         self.octree_resolution = float(octree_resolution)
         self._icp = dict(max_iterations=max_iterations, transformation_epsilon=transformation_epsilon,
                          max_correspondence_distance=max_correspondence_distance)
@@ -46,6 +52,7 @@ class OctreeMapper:
     # octree_mapper.cpp:55-59
     def resetMap(self):
         self.ctx.map_reset(self.octree_resolution)
+        self.ctx.map_set_search(self.pcl_approx_search)
 
     # octree_mapper.cpp:62-69 (the cloud is given in the sensor frame together with its pose: the transform of
     # transformCloudToPoseFrame is fused into the insertion kernel)

@@ -118,6 +118,10 @@ class Context:
         self.n_target, self.n_source = self.n_source, 0
 
     # the mapper's map (octree_mapper.cpp:55-90) -----------------------------------------------
+    def map_set_search(self, pcl_approx: bool):
+        """False: exact nearest map point (default); True: PCL's approxNearestSearch as octree_mapper.cpp:84 calls it."""
+        self._check(self._L.icpgpu_map_set_search(self._h, 1 if pcl_approx else 0))
+
     def map_reset(self, resolution: float = 0.5):
         """resetMap(): empty one-point-per-voxel map (octree_resolution_, octree_mapper.cpp:41)."""
         self._check(self._L.icpgpu_map_reset(self._h, float(resolution)))

@@ -266,6 +266,14 @@ int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t 
  *                becomes the context's TARGET cloud (device to device).  Source points whose image is not
  *                finite are dropped, like the reference's "result_index < 0".  nn_out_xyzw (nullable) must
  *                hold n_source points; *n_nn = points in the nn cloud.  An empty map gives an empty target. */
+/*   set_search   which neighbour nn_target collects: ICPGPU_MAP_SEARCH_EXACT (default, above) or ICPGPU_MAP_SEARCH_PCL_APPROX =
+ *                what octree_mapper.cpp:84 literally calls, OctreePointCloudSearch::approxNearestSearch: from the root of
+ *                PCL's octree (bounding box grown point by point as adoptBoundingBoxToPoint does) to the existing child
+ *                whose voxel centre is nearest to the query (float squared distance, first child on ties), down to a leaf,
+ *                whose point is returned -- a heuristic that misses the true neighbour for ~40 % of a scan's points.
+ *                The exact search gives the better registration; this one gives the reference's nn cloud. */
+enum { ICPGPU_MAP_SEARCH_EXACT = 0, ICPGPU_MAP_SEARCH_PCL_APPROX = 1 };
+int icpgpu_map_set_search(icpgpu_ctx* ctx, int mode);
 int icpgpu_map_reset(icpgpu_ctx* ctx, double resolution);
 int icpgpu_map_add_points(icpgpu_ctx* ctx, const float* xyzw, size_t n, const float* pose, size_t* n_added);
 int icpgpu_map_add_source(icpgpu_ctx* ctx, const float* pose, size_t* n_added);

@@ -366,6 +366,9 @@ class OctreeMap {
       : ctx_holder_(detail::acquire_context(device)), ctx_(ctx_holder_->ctx), resolution_(resolution) { resetMap(); }
   const detail::ContextPtr& context() const { return ctx_holder_; }  // for IterativeClosestPoint::setInputTargetFromMap(map.context())
   void resetMap() { icpgpu_map_reset(ctx_, resolution_); }                                     // :55-59
+  // which neighbour approxNearestNeighbors collects: false (default) = the EXACT nearest map point; true = PCL's
+  // approxNearestSearch heuristic, i.e. the nn cloud the reference itself would see (icpgpu.h: icpgpu_map_set_search)
+  void setPclApproximateSearch(bool on) { icpgpu_map_set_search(ctx_, on ? ICPGPU_MAP_SEARCH_PCL_APPROX : ICPGPU_MAP_SEARCH_EXACT); }
   std::size_t addPointsToMap(const CloudT& cloud, const Matrix4& pose) {                         // :62-69 (+ :135, :152)
     std::size_t added = 0;
     const std::size_t n = cloud.points.size();
@@ -373,7 +376,8 @@ class OctreeMap {
     return added;
   }
   // :72-90 followed by the transform back at :146.  nearest_neighbors receives the nn cloud; it also stays in HBM as
-  // the registration target (IterativeClosestPoint::setInputTargetFromMap).  Exact nearest neighbours.
+  // the registration target (IterativeClosestPoint::setInputTargetFromMap).  Exact nearest neighbours unless
+  // setPclApproximateSearch(true).
   bool approxNearestNeighbors(const CloudT& cloud, const Matrix4& pose, const Matrix4& pose_inv, CloudT& nearest_neighbors) {
     const std::size_t n = cloud.points.size();
     nearest_neighbors.points.resize(n);

@@ -95,7 +95,8 @@ def test_refine_and_grow_matches_the_oracle_flow(ctx):
     scans = [synth.scan(scene, P, 30000, seed=400 + k) for k, P in enumerate(poses)]
     err = synth.pose_matrix(0.15, -0.1, 0.02, 0.0, 0.0, 0.01)
 
-    mapper = OctreeMapper(ctx, octree_resolution=0.5)
+    from icpslam_amd import P2P_SVD
+    mapper = OctreeMapper(ctx, octree_resolution=0.5, method=P2P_SVD)      # (the default is GICP, as octree_mapper.cpp:104 has it)
     ref = oracle.VoxelMap(0.5)
     p_icp = oracle.default_params(max_iterations=30)
     for k, (scan, P) in enumerate(zip(scans, poses)):
@@ -159,3 +160,46 @@ def test_fuzz_map_against_oracle(ctx, seed):
     pinv = np.linalg.inv(pose.astype(np.float64)).astype(np.float32)
     ctx.set_source(q)
     assert np.array_equal(_bits(ctx.map_nn_target(pose, pinv)), _bits(ref.nn_cloud(q, pose, pinv)))
+
+
+@pytest.mark.parametrize("seed,n_scans,res", [(7, 3, 0.5), (11, 4, 0.5), (13, 3, 0.3), (17, 2, 1.0)])
+def test_pcl_approx_search_mode_returns_the_restatements_nn_cloud(built, seed, n_scans, res):
+    """icpgpu_map_set_search(PCL_APPROX): the nn cloud of OctreePointCloudSearch::approxNearestSearch as the reference
+    literally calls it (octree_mapper.cpp:84) -- the octree's bounding box grown point by point, the greedy descent by voxel
+    centre -- equals oracle/map_approx_np.py's (the NumPy restatement of PCL 1.8's octree) bit for bit, map after map as the
+    box doubles; switching back gives the exact neighbours again."""
+    from icpslam_amd import Context
+    from oracle.map_approx_np import ApproxOctreeMap
+    rng = np.random.default_rng(seed)
+    scene = synth.make_scene(70 + seed)
+    poses = [np.eye(4)]
+    for _ in range(n_scans):
+        poses.append(poses[-1] @ synth.pose_matrix(rng.uniform(-0.6, 0.6), rng.uniform(-0.3, 0.3), 0.0, 0.0, 0.0,
+                                                   np.deg2rad(rng.uniform(-4, 4))))
+    scans = [synth.scan(scene, P, 9000, seed=900 + 10 * seed + k) for k, P in enumerate(poses)]
+    scans[1][5, :3] = np.nan                                   # a non-finite query / map candidate along the way
+    am = ApproxOctreeMap(res)
+    with Context(0) as c:
+        c.map_reset(res)
+        c.map_set_search(True)
+        for k in range(n_scans):
+            P = poses[k].astype(np.float32)
+            added = c.map_add_points(scans[k], P)
+            assert added == am.add_points(oracle.transform_cloud(scans[k], P))
+            assert np.array_equal(c.map_points(), am.map_points())
+            raw = poses[k + 1].copy()
+            raw[:3, 3] += (0.07, -0.04, 0.01)
+            raw = raw.astype(np.float32)
+            raw_inv = np.linalg.inv(raw.astype(np.float64)).astype(np.float32)
+            q = oracle.transform_cloud(scans[k + 1], raw)
+            fin = np.isfinite(q[:, :3]).all(axis=1)
+            ia = am.nn_indices_approx(q[fin])
+            want = oracle.transform_cloud(am.map_points()[ia], raw_inv)
+            c.set_source(scans[k + 1])
+            got = c.map_nn_target(raw, raw_inv)
+            assert got.shape == want.shape and np.array_equal(got, want), (k, am.depth)
+        assert am.depth >= 6                                   # the box has doubled a few times on the way
+        c.map_set_search(False)                                # ... and the exact search still is what it was
+        ie, _ = oracle.nn(scans[n_scans], am.map_points(), raw)
+        got = c.map_nn_target(raw, raw_inv)
+        assert np.array_equal(got, oracle.transform_cloud(am.map_points()[ie[fin]], raw_inv))
