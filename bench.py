@@ -503,7 +503,7 @@ def main():
                 "frac": v_ginst / VALU_ISSUE_PEAK_GINST,
                 "source": f"{BRUTE_VALU_INSTS_PER_PAIR:g} VALU instructions per pair and lane (ISA of the inner loop) x Ns x Nt / 64 "
                           "lanes / the live launch time; same peak as the grid kernel's `issue`"}
-        if used_grid:
+        if used_grid and prof.grid_timed and not batch:
             g_ms = prof.grid_ms / max(1, prof.grid_timed)
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
             roofline = {
@@ -543,10 +543,11 @@ def main():
             roofline = dict(brute_roofline or {}, kernel=(brute_roofline or {}).get("kernel", "nn_brute_kernel (LDS-tiled brute force)"), bound="mfma", achieved=tf,
                             peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP32_PEAK_TFLOPS, avg_launch_ms=nn_ms,
                             launches=int(prof.nn_launches), traffic=traffic.get("nn_brute_hbm_bytes_per_launch"))
-        if batch and used_grid:
+        if batch and used_grid and prof.grid_timed:
             g_ms = prof.grid_ms / max(1, prof.grid_timed)
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
-            roofline = {"kernel": "nn_quad_kernel<fused> at 50k x 50k, several contexts in flight", "bound": "hbm",
+            roofline = {"kernel": "nn_quad_batch_kernel (nn_quad_kernel's body, one pair per blockIdx.y): a lock-step sweep's HIP-event "
+                                  "time / its pairs, at 50k x 50k", "bound": "hbm",
                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_ms": g_ms, "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
                         "algorithmic_bytes_per_launch": alg_bytes_fused}

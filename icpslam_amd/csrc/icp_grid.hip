@@ -345,22 +345,24 @@ __global__ __launch_bounds__(WQ_BLOCK) void nn_wave_kernel(const float4* __restr
 // 16 product terms of the fused reduction go one to a lane (the count is an integer, the d2 sum shares lane 0).  That
 // removes most of the per-point fixed cost of nn_wave_kernel (merge, term selection, scalar row set-up: ~70 of ~150 wave
 // instructions).  Points the octant cannot certify fall back to the wave-wide cube search, one at a time, as before.
+// (the body: nn_quad_kernel below runs it for one scan pair per launch, nn_quad_batch_kernel for one pair per blockIdx.y;
+// n_blocks / bx stand for gridDim.x / blockIdx.x of the single-pair launch, so a pair's points go to the same workgroups, in
+// the same order, whichever kernel sweeps it: identical partial sums)
 template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool PACK_SHORT_ROWS>
-__global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_quad_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
-                                                           const float4* __restrict__ sorted,
-                                                           const int* __restrict__ cell_start, GridDesc g, float accept_thr,
-                                                           unsigned long long* __restrict__ keys,
-                                                           double* __restrict__ partials, int* __restrict__ unmatched,
-                                                           int* __restrict__ unmatched_count, float4* __restrict__ prev_nn,
-                                                           int use_prev, int cube_start,
-                                                           unsigned long long* __restrict__ count_candidates) {
+__device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, const Xform& T,
+                                             const float4* __restrict__ sorted, const int* __restrict__ cell_start,
+                                             const GridDesc& g, float accept_thr, unsigned long long* __restrict__ keys,
+                                             double* __restrict__ partials, int* __restrict__ unmatched,
+                                             int* __restrict__ unmatched_count, float4* __restrict__ prev_nn, int use_prev,
+                                             int cube_start, unsigned long long* __restrict__ count_candidates, int n_blocks,
+                                             int bx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp_base = lane & 48, sub = lane & 15;
   // counting runs (bench.py's useful-flop figure, ICPGPU_COUNT_CANDIDATES): target points this wave evaluates, octant lists
   // + cube rows, without the padding re-reads.  nullptr otherwise: the additions below are scalar and skipped.
   unsigned int n_cand = 0;
-  const int lb = xcd_map ? (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int k0 = lb * WQ_WAVES + wave, stride = gridDim.x * WQ_WAVES;
+  const int lb = xcd_map ? (bx & 7) * (n_blocks >> 3) + (bx >> 3) : bx;
+  const int k0 = lb * WQ_WAVES + wave, stride = n_blocks * WQ_WAVES;
 
   // fused reduction: lane s of a row owns one product term (term order of accumulate_pair; s = 0 takes the d2 sum, the
   // count is kept as an integer)
@@ -558,8 +560,47 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
         for (int k = 0; k < WQ_WAVES * 4; ++k) v += wterm[k][s];
       }
-      partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = v;
+      partials[(size_t)threadIdx.x * n_blocks + bx] = v;
     }
+  }
+}
+
+
+template <bool WRITE_KEYS, bool FUSE_REDUCE, bool LIST_UNMATCHED, bool PACK_SHORT_ROWS>
+__global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_quad_kernel(const float4* __restrict__ src, int n_s, int qpw, int xcd_map, Xform T,
+                                                           const float4* __restrict__ sorted,
+                                                           const int* __restrict__ cell_start, GridDesc g, float accept_thr,
+                                                           unsigned long long* __restrict__ keys,
+                                                           double* __restrict__ partials, int* __restrict__ unmatched,
+                                                           int* __restrict__ unmatched_count, float4* __restrict__ prev_nn,
+                                                           int use_prev, int cube_start,
+                                                           unsigned long long* __restrict__ count_candidates) {
+  nn_quad_body<WRITE_KEYS, FUSE_REDUCE, LIST_UNMATCHED, PACK_SHORT_ROWS>(src, n_s, qpw, xcd_map, T, sorted, cell_start, g, accept_thr, keys,
+                                                                        partials, unmatched, unmatched_count, prev_nn, use_prev,
+                                                                        cube_start, count_candidates, (int)gridDim.x, (int)blockIdx.x);
+}
+
+// Lock-step sweep of several independent scan pairs (icpgpu_align_batch, BASELINE configs 4 / 5): pair step.slot[blockIdx.y]
+// of the table, its transform from the kernel arguments, its own workgroup count (workgroups beyond it leave at once).
+// OPEN: the ungated sweep of getFitnessScore (keys + the list of points the grid leaves unmatched) instead of the fused one.
+template <bool PACK_SHORT_ROWS, bool OPEN>
+__global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_quad_batch_kernel(const BatchPair* __restrict__ pairs, BatchStep step,
+                                                                                                       int cube_start) {
+  const BatchPair& d = pairs[step.slot[blockIdx.y]];
+  const int n_blocks = d.blocks;
+  if ((int)blockIdx.x >= n_blocks) return;
+  const Xform T = step.T[blockIdx.y];
+  GridDesc g = d.g;
+  const int use_prev = (int)((step.use_prev_mask >> blockIdx.y) & 1u);
+  if constexpr (OPEN) {
+    g.r_max = d.r_max_open;
+    nn_quad_body<true, false, true, PACK_SHORT_ROWS>(d.src, d.n_s, d.qpw, d.xcd_map, T, d.sorted, d.cell_start, g, 0.f, d.keys, nullptr,
+                                                     d.unmatched, d.unmatched_count, d.prev_nn, use_prev, cube_start, nullptr, n_blocks,
+                                                     (int)blockIdx.x);
+  } else {
+    nn_quad_body<false, true, false, PACK_SHORT_ROWS>(d.src, d.n_s, d.qpw, d.xcd_map, T, d.sorted, d.cell_start, g, d.accept_thr, nullptr,
+                                                      d.partials, nullptr, nullptr, d.prev_nn, use_prev, cube_start, nullptr, n_blocks,
+                                                      (int)blockIdx.x);
   }
 }
 
@@ -648,6 +689,20 @@ static int queries_per_wave(int n_s) {
 }
 
 void grid_count_candidates(unsigned long long* device_counter) { g_count_candidates = device_counter; }
+
+bool grid_search_batchable(int n_s, int flags) { return use_quad(n_s) && !(flags & kGridOver4GiB) && queries_per_wave(n_s) > 0; }
+int grid_search_qpw(int n_s) { return queries_per_wave(n_s); }
+
+hipError_t launch_nn_grid_search_batch(const BatchPair* d_pairs, const BatchStep& step, int n_active, int max_blocks, bool pack,
+                                       bool open_range, hipStream_t stream) {
+  if (n_active <= 0 || max_blocks <= 0) return hipSuccess;
+  const dim3 grid((unsigned)max_blocks, (unsigned)n_active), block(WQ_BLOCK);
+  if (pack && open_range) hipLaunchKernelGGL((nn_quad_batch_kernel<true, true>), grid, block, 0, stream, d_pairs, step, cube_start_mask());
+  else if (pack) hipLaunchKernelGGL((nn_quad_batch_kernel<true, false>), grid, block, 0, stream, d_pairs, step, cube_start_mask());
+  else if (open_range) hipLaunchKernelGGL((nn_quad_batch_kernel<false, true>), grid, block, 0, stream, d_pairs, step, cube_start_mask());
+  else hipLaunchKernelGGL((nn_quad_batch_kernel<false, false>), grid, block, 0, stream, d_pairs, step, cube_start_mask());
+  return hipGetLastError();
+}
 
 bool grid_search_keeps_prev(int n_s, int flags) { return use_quad(n_s) && !(flags & kGridOver4GiB); }
 

@@ -130,6 +130,35 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 // step in the cube search), kGridOver4GiB (2^28 or more binned points: nn_quad_kernel's 32-bit byte offsets do not reach,
 // nn_wave_kernel takes over)
 static constexpr int kGridSrcInCellOrder = 1, kGridPackShortRows = 2, kGridOver4GiB = 4;
+// ---- lock-step sweeps over several independent pairs (icpgpu_align_batch) -------------------------------------------
+constexpr int kBatchMax = 16;
+struct BatchPair {  // what stays the same for a pair from sweep to sweep (a table in device memory)
+  const float4* src;
+  const float4* sorted;
+  const int* cell_start;
+  double* partials;
+  float4* prev_nn;
+  unsigned long long* flags;  // the pair's result mailbox (device alias of pinned host memory)
+  unsigned long long* keys;   // ungated (getFitnessScore) sweep: the pair's key array, its list of unmatched points + counter
+  int* unmatched;
+  int* unmatched_count;
+  int r_max_open;             // ... and how far its cubes may grow (nn_keys_grid)
+  GridDesc g;
+  float accept_thr;
+  int n_s, qpw, xcd_map, blocks;
+};
+struct BatchStep {  // what changes: passed by value with every launch (kernel arguments)
+  Xform T[kBatchMax];
+  unsigned long long seq[kBatchMax];
+  unsigned char slot[kBatchMax];  // blockIdx.y -> row of the table
+  unsigned int use_prev_mask;     // bit y: the pair's previous-neighbour buffer holds its last sweep
+};
+bool grid_search_batchable(int n_s, int flags);
+int grid_search_qpw(int n_s);
+hipError_t launch_nn_grid_search_batch(const BatchPair* d_pairs, const BatchStep& step, int n_active, int max_blocks, bool pack,
+                                       bool open_range, hipStream_t stream);
+hipError_t launch_reduce_final_batch(const BatchPair* d_pairs, const BatchStep& step, int n_active, hipStream_t stream);
+
 hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream,

@@ -296,9 +296,8 @@ __global__ __launch_bounds__(RED_BLOCK) void reduce_kernel(const float4* __restr
 // partials[b * 17 + k].
 // 1024 threads per term: a 200k-point sweep's 3128 partials are ONE batch of loads per thread (one memory round trip).
 constexpr int RF_BLOCK = 1024;
-__global__ __launch_bounds__(RF_BLOCK) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks, int term_major,
-                                                           double* __restrict__ sums, unsigned long long* flags,
-                                                           unsigned long long seq) {
+__device__ __forceinline__ void reduce_final_body(const double* __restrict__ partials, int n_blocks, int term_major,
+                                                  double* __restrict__ sums, unsigned long long* flags, unsigned long long seq) {
   const int k = blockIdx.x;
   double v = 0.0;
   // Eight loads in flight, then the eight additions in the same order as one at a time (same bits): a load -> wait -> add
@@ -346,6 +345,18 @@ __global__ __launch_bounds__(RF_BLOCK) void reduce_final_kernel(const double* __
       sums[k] = sum;
     }
   }
+}
+
+__global__ __launch_bounds__(RF_BLOCK) void reduce_final_kernel(const double* __restrict__ partials, int n_blocks, int term_major,
+                                                           double* __restrict__ sums, unsigned long long* flags,
+                                                           unsigned long long seq) {
+  reduce_final_body(partials, n_blocks, term_major, sums, flags, seq);
+}
+
+// the final reductions of a lock-step sweep: pair step.slot[blockIdx.y], 17 workgroups each, into that pair's mailbox
+__global__ __launch_bounds__(RF_BLOCK) void reduce_final_batch_kernel(const BatchPair* __restrict__ pairs, BatchStep step) {
+  const BatchPair& d = pairs[step.slot[blockIdx.y]];
+  reduce_final_body(d.partials, d.blocks, 1, nullptr, d.flags, step.seq[blockIdx.y]);
 }
 
 // a6: output cloud. 32 B/point of HBM traffic, float4 in / float4 out.
@@ -462,6 +473,12 @@ hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_m
                                unsigned long long* flags, unsigned long long seq, hipStream_t stream) {
   hipLaunchKernelGGL(reduce_final_kernel, dim3(kReduceTerms), dim3(RF_BLOCK), 0, stream, partials, n_blocks, term_major ? 1 : 0,
                      sums_out, flags, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_final_batch(const BatchPair* d_pairs, const BatchStep& step, int n_active, hipStream_t stream) {
+  if (n_active <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reduce_final_batch_kernel, dim3(kReduceTerms, (unsigned)n_active), dim3(RF_BLOCK), 0, stream, d_pairs, step);
   return hipGetLastError();
 }
 

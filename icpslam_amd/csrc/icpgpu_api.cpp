@@ -203,6 +203,7 @@ struct icpgpu_ctx {
   void* vox_pub_zeroed = nullptr;
   size_t vox_pub_zeroed_cap = 0;
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
+  DeviceBuf batch_table;             // lock-step batch: the BatchPair table of the group this context leads
   std::string err;
 };
 
@@ -280,14 +281,14 @@ float threshold_from(double r2) {
   return f;
 }
 
-int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n) {
+int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true) {
   if (n > 0 && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
   if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
   int rc = ensure(c, cl.buf, n * sizeof(float4));
   if (rc) return rc;
   if (n) {
     HIP_TRY(c, hipMemcpyAsync(cl.buf.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free xyzw as soon as we return
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free xyzw as soon as we return
   }
   cl.n = n;
   cl.set = true;
@@ -352,126 +353,211 @@ static double grid_divisor() {
 
 // (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
 // cannot help (no finite point, one cell holding > kMaxCellPopulation points).
-int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
-               const int* orig_index = nullptr, double knn_population = 0.0) {
-  const int n_t = (int)cloud.n;
+//
+// A build has two host round trips (the bounding box sizes the table; the occupancy statistics of the count pass may
+// change the cell size once or twice).  It is written as a resumable state machine so that the lock-step batch path
+// (icpgpu_align_batch) can take K builds through their round trips TOGETHER -- one stream synchronisation per stage for
+// the whole group instead of two or three per pair; build_grid() drives one build to the end.
+struct GridBuild {
+  enum State { Done, WaitBbox, WaitCount };
+  State state = Done;
+  const Cloud* cloud = nullptr;
+  uint64_t version = 0;
+  double cut = 0.0;
+  bool adapt = false;
+  GridIndex* G = nullptr;
+  const int* orig_index = nullptr;
+  double knn_population = 0.0;
+  double h = 0.0;
+  int attempt = 0;
+  bool shrunk = false;
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  GridDesc g{};
+  std::chrono::steady_clock::time_point t0{};
+};
+
+int gb_issue_count(icpgpu_ctx* c, GridBuild& b);
+
+// queue the bounding box (or find the grid already built)
+int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
+             const int* orig_index = nullptr, double knn_population = 0.0) {
+  b = GridBuild{};
+  b.cloud = &cloud;
+  b.version = version;
+  b.cut = cut;
+  b.adapt = adapt;
+  b.G = &G;
+  b.orig_index = orig_index;
+  b.knn_population = knn_population;
   const float cutoff = (float)cut;
-  if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;
+  if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;  // (state Done)
   G.built = true;
   G.usable = false;
   G.version = version;
   G.cutoff = cutoff;
-
   int rc = ensure(c, G.ints, (6 + kGridStatInts) * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(G.ints.ptr);
-  const auto t_build = std::chrono::steady_clock::now();
-  HIP_TRY(c, launch_bbox(cloud.data(), n_t, d_ints, c->stream));
+  b.t0 = std::chrono::steady_clock::now();
+  HIP_TRY(c, launch_bbox(cloud.data(), (int)cloud.n, d_ints, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  float lo[3], hi[3];
-  decode_bbox(c->h_ints, lo, hi);
-  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
+  b.state = GridBuild::WaitBbox;
+  return ICPGPU_OK;
+}
 
+// the bounding box has arrived (the caller synchronised the stream): size the table, queue the count pass
+int gb_on_bbox(icpgpu_ctx* c, GridBuild& b) {
+  decode_bbox(c->h_ints, b.lo, b.hi);
+  if (!(b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2])) {  // no finite point
+    b.state = GridBuild::Done;
+    return ICPGPU_OK;
+  }
   // Cell size: a quarter of the cutoff (cube radii 1, 2, 4, 5 cells for an unmatched point), grown until the dense
   // table fits.  If that leaves a typical point sharing its cell with more than kDenseCellPopulation others (a submap
   // of many scans), the cells shrink so that this population comes down to ~kTargetCellPopulation (populations of
   // surface samples scale with h^2): the octant stage then still certifies most points (their neighbour is closer than
   // h/2) and reads 4x fewer candidates.  Measured at 200k x 1M: 126 -> ~84 us per iteration.
-  double h = cut / grid_divisor();
-  GridDesc g;
-  long long ncells = 0;
-  bool shrunk = false;
-  for (int attempt = 0;; ++attempt) {
-    long long nx, ny, nz;
-    for (;;) {
-      nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
-      ny = (long long)std::floor((hi[1] - lo[1]) / h) + 3;
-      nz = (long long)std::floor((hi[2] - lo[2]) / h) + 3;
-      // at most 2^14 cells per axis: the float cell coordinates the search reasons with are then exact to 2^-9 of a
-      // cell, well inside the 1/64 safety margin of its distance tests (icp_grid_device.h)
-      if (nx * ny * nz <= kMaxGridCells && nx < (1 << 14) && ny < (1 << 14) && nz < (1 << 14)) break;
-      h *= 1.15;
-      if (!std::isfinite(h)) return ICPGPU_OK;
-    }
-    g.h = (float)h;
-    g.inv_h = 1.0f / g.h;
-    g.ox = lo[0] - g.h;
-    g.oy = lo[1] - g.h;
-    g.oz = lo[2] - g.h;
-    g.nx = (int)nx;
-    g.ny = (int)ny;
-    g.nz = (int)nz;
-    if (nz <= ny && !std::getenv("ICPGPU_Z_OUTER")) {
-      g.sy = g.nx * g.nz;  // y outermost, z in the middle (the usual case: a scene much wider than it is tall)
-      g.sz = g.nx;
-    } else {
-      g.sy = g.nx;
-      g.sz = g.nx * g.ny;
-    }
-    g.r_max = (int)std::ceil(cut / ((double)g.h * (double)kGridSafety));
-    if (g.r_max < 1) g.r_max = 1;
-    if (!std::isfinite(g.ox) || !std::isfinite(g.oy) || !std::isfinite(g.oz) || !(g.inv_h > 0.f) || !std::isfinite(g.inv_h))
+  b.h = b.cut / grid_divisor();
+  b.attempt = 0;
+  b.shrunk = false;
+  return gb_issue_count(c, b);
+}
+
+int gb_issue_count(icpgpu_ctx* c, GridBuild& b) {
+  GridIndex& G = *b.G;
+  const int n_t = (int)b.cloud->n;
+  int* d_ints = static_cast<int*>(G.ints.ptr);
+  double& h = b.h;
+  const float *lo = b.lo, *hi = b.hi;
+  GridDesc& g = b.g;
+  long long nx, ny, nz;
+  for (;;) {
+    nx = (long long)std::floor((hi[0] - lo[0]) / h) + 3;
+    ny = (long long)std::floor((hi[1] - lo[1]) / h) + 3;
+    nz = (long long)std::floor((hi[2] - lo[2]) / h) + 3;
+    // at most 2^14 cells per axis: the float cell coordinates the search reasons with are then exact to 2^-9 of a
+    // cell, well inside the 1/64 safety margin of its distance tests (icp_grid_device.h)
+    if (nx * ny * nz <= kMaxGridCells && nx < (1 << 14) && ny < (1 << 14) && nz < (1 << 14)) break;
+    h *= 1.15;
+    if (!std::isfinite(h)) {
+      b.state = GridBuild::Done;
       return ICPGPU_OK;
-    ncells = nx * ny * nz;
-    const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
-    if ((rc = ensure(c, G.cell_start, (size_t)(ncells + 1) * sizeof(int)))) return rc;
-    if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
-    if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
-    if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
-    HIP_TRY(c, launch_grid_count(cloud.data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
-                                 static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6,
-                                 c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, kGridStatInts * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long sumsq = 0;
-    std::memcpy(&sumsq, c->h_ints + 8, sizeof sumsq);
-    const int binned = c->h_ints[10];
-    const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
-    if (attempt == 0 && adapt && pop > kDenseCellPopulation) {
-      static const double target_pop = [] { const char* e = std::getenv("ICPGPU_TARGET_POP"); return e ? std::atof(e) : kTargetCellPopulation; }();
-      const double h_new = std::max(h * std::sqrt(target_pop / pop), cut / 16.0);
-      if (h_new < 0.9 * h) {
-        h = h_new;
-        shrunk = true;
-        continue;
-      }
     }
-    // k-nearest-neighbour searches (GICP covariances) read whole 3x3x3 cubes: they want only a few points per cell
-    if (attempt == 0 && knn_population > 0.0 && binned > 0 && (pop > 2.0 * knn_population || pop < 0.5 * knn_population)) {
-      // ... in both directions: over a sparse (voxel-filtered) cloud the 20 neighbours lie ~2.5 point spacings away, and
-      // cells that small make the search restart with cubes of 25 and 81 rows (22k-point cloud: 0.60 -> 0.35 ms)
-      const double h_new = std::min(std::max(h * std::sqrt(knn_population / pop), cut / 64.0), 8.0 * h);
-      if (h_new < 0.9 * h || h_new > 1.1 * h) {
-        h = h_new;
-        shrunk = true;
-        continue;
-      }
-    }
-    // ... and a sparse target (one point per 0.5 m voxel: the mapper's nn cloud, a voxel-filtered scan) gets cells of
-    // twice the size: neighbours are then typically farther than h/2 and would fall through the octant stage
-    if (attempt <= 1 && !shrunk && adapt && binned > 0 && pop < sparse_population() && 2.0 * h <= cut) {
-      h *= 2.0;
-      continue;
-    }
-    G.n_binned = binned;
-    G.max_pop = c->h_ints[7];
-    G.point_population = pop;
-    if (std::getenv("ICPGPU_DEBUG")) fprintf(stderr, "[icpgpu] grid n=%d binned=%d h=%.4f dims=%dx%dx%d pop=%.1f max=%d attempt=%d\n", n_t, binned, h, g.nx, g.ny, g.nz, pop, G.max_pop, attempt);
-    break;
   }
+  g.h = (float)h;
+  g.inv_h = 1.0f / g.h;
+  g.ox = lo[0] - g.h;
+  g.oy = lo[1] - g.h;
+  g.oz = lo[2] - g.h;
+  g.nx = (int)nx;
+  g.ny = (int)ny;
+  g.nz = (int)nz;
+  if (nz <= ny && !std::getenv("ICPGPU_Z_OUTER")) {
+    g.sy = g.nx * g.nz;  // y outermost, z in the middle (the usual case: a scene much wider than it is tall)
+    g.sz = g.nx;
+  } else {
+    g.sy = g.nx;
+    g.sz = g.nx * g.ny;
+  }
+  g.r_max = (int)std::ceil(b.cut / ((double)g.h * (double)kGridSafety));
+  if (g.r_max < 1) g.r_max = 1;
+  if (!std::isfinite(g.ox) || !std::isfinite(g.oy) || !std::isfinite(g.oz) || !(g.inv_h > 0.f) || !std::isfinite(g.inv_h)) {
+    b.state = GridBuild::Done;
+    return ICPGPU_OK;
+  }
+  const long long ncells = nx * ny * nz;
+  const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
+  int rc;
+  if ((rc = ensure(c, G.cell_start, (size_t)(ncells + 1) * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
+  HIP_TRY(c, launch_grid_count(b.cloud->data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
+                               static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, kGridStatInts * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  b.state = GridBuild::WaitCount;
+  return ICPGPU_OK;
+}
+
+// the occupancy statistics have arrived: another count pass with other cells, or the scan + scatter
+int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
+  GridIndex& G = *b.G;
+  const int n_t = (int)b.cloud->n;
+  int* d_ints = static_cast<int*>(G.ints.ptr);
+  double& h = b.h;
+  const double cut = b.cut;
+  unsigned long long sumsq = 0;
+  std::memcpy(&sumsq, c->h_ints + 8, sizeof sumsq);
+  const int binned = c->h_ints[10];
+  const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
+  const int attempt = b.attempt;
+  bool again = false;
+  if (attempt == 0 && b.adapt && pop > kDenseCellPopulation) {
+    static const double target_pop = [] { const char* e = std::getenv("ICPGPU_TARGET_POP"); return e ? std::atof(e) : kTargetCellPopulation; }();
+    const double h_new = std::max(h * std::sqrt(target_pop / pop), cut / 16.0);
+    if (h_new < 0.9 * h) {
+      h = h_new;
+      b.shrunk = true;
+      again = true;
+    }
+  }
+  // k-nearest-neighbour searches (GICP covariances) read whole 3x3x3 cubes: they want only a few points per cell
+  if (!again && attempt == 0 && b.knn_population > 0.0 && binned > 0 && (pop > 2.0 * b.knn_population || pop < 0.5 * b.knn_population)) {
+    // ... in both directions: over a sparse (voxel-filtered) cloud the 20 neighbours lie ~2.5 point spacings away, and
+    // cells that small make the search restart with cubes of 25 and 81 rows (22k-point cloud: 0.60 -> 0.35 ms)
+    const double h_new = std::min(std::max(h * std::sqrt(b.knn_population / pop), cut / 64.0), 8.0 * h);
+    if (h_new < 0.9 * h || h_new > 1.1 * h) {
+      h = h_new;
+      b.shrunk = true;
+      again = true;
+    }
+  }
+  // ... and a sparse target (one point per 0.5 m voxel: the mapper's nn cloud, a voxel-filtered scan) gets cells of
+  // twice the size: neighbours are then typically farther than h/2 and would fall through the octant stage
+  if (!again && attempt <= 1 && !b.shrunk && b.adapt && binned > 0 && pop < sparse_population() && 2.0 * h <= cut) {
+    h *= 2.0;
+    again = true;
+  }
+  if (again) {
+    b.attempt += 1;
+    return gb_issue_count(c, b);
+  }
+  G.n_binned = binned;
+  G.max_pop = c->h_ints[7];
+  G.point_population = pop;
+  if (std::getenv("ICPGPU_DEBUG")) fprintf(stderr, "[icpgpu] grid n=%d binned=%d h=%.4f dims=%dx%dx%d pop=%.1f max=%d attempt=%d\n", n_t, binned, h, b.g.nx, b.g.ny, b.g.nz, pop, G.max_pop, attempt);
+  int rc;
   if ((rc = ensure(c, G.sorted, (size_t)n_t * sizeof(float4)))) return rc;
-  HIP_TRY(c, launch_grid_finish(cloud.data(), n_t, g, static_cast<const int*>(G.cell_of_point.ptr),
+  HIP_TRY(c, launch_grid_finish(b.cloud->data(), n_t, b.g, static_cast<const int*>(G.cell_of_point.ptr),
                                 static_cast<const int*>(G.rank.ptr), static_cast<int*>(G.cell_start.ptr),
-                                static_cast<int*>(G.block_sums.ptr), d_ints + 6, orig_index, static_cast<float4*>(G.sorted.ptr), c->stream));
+                                static_cast<int*>(G.block_sums.ptr), d_ints + 6, b.orig_index, static_cast<float4*>(G.sorted.ptr), c->stream));
   // No synchronisation here: the search that follows is queued behind the scan and the scatter.  (The build used to end
   // with a stream synchronisation only to time itself with events: 10-20 us of a 0.12 ms build.)  grid_build_ms is the
   // host's time in this function -- it contains the two round trips above, not the tail of the last three kernels.
   c->prof.grid_builds += 1;
-  c->prof.grid_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
-  G.g = g;
+  c->prof.grid_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b.t0).count();
+  G.g = b.g;
   G.usable = G.n_binned > 0 && G.max_pop <= kMaxCellPopulation;
+  b.state = GridBuild::Done;
   return ICPGPU_OK;
+}
+
+// after the caller has synchronised the build's stream
+int gb_advance(icpgpu_ctx* c, GridBuild& b) {
+  if (b.state == GridBuild::WaitBbox) return gb_on_bbox(c, b);
+  if (b.state == GridBuild::WaitCount) return gb_on_count(c, b);
+  return ICPGPU_OK;
+}
+
+int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
+               const int* orig_index = nullptr, double knn_population = 0.0) {
+  GridBuild b;
+  int rc = gb_begin(c, b, cloud, version, cut, adapt, G, orig_index, knn_population);
+  while (!rc && b.state != GridBuild::Done) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rc = gb_advance(c, b);
+  }
+  return rc;
 }
 
 // The target's grid, if the parameters ask for it; otherwise (or when it cannot help) the brute-force kernel is used.
@@ -1032,7 +1118,8 @@ int p2p_finish(icpgpu_ctx* c, P2PRun& r) {
   return ICPGPU_OK;
 }
 
-int p2p_begin(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+// everything of p2p_begin that needs no index: the run is Done afterwards when the target is empty, Idle otherwise
+int p2p_prepare(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
   r = P2PRun{};
   r.t_start = std::chrono::steady_clock::now();
   r.res = res;
@@ -1062,16 +1149,24 @@ int p2p_begin(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int
   const icpgpu_params& P = c->params;
   r.crit = ConvergenceCriteria(P.max_iterations, P.transformation_epsilon, P.euclidean_fitness_epsilon, P.force_iterations != 0);
   r.thr = threshold_from(P.max_correspondence_distance * P.max_correspondence_distance);
-  int rc = ensure_grid(c, r.thr);
-  if (rc) return rc;
+  return ICPGPU_OK;
+}
+
+int p2p_begin(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  int rc = p2p_prepare(c, r, guess, out_xyzw, want_fitness, res);
+  if (rc || r.phase == P2PRun::Done) return rc;
+  if ((rc = ensure_grid(c, r.thr))) return rc;
   if ((rc = ensure_source_order(c, r.thr))) return rc;
   r.phase = P2PRun::Iterating;
   r.t_issue = std::chrono::steady_clock::now();
   return sweep_issue(c, to_xform(r.final_T), r.thr, false, r.ticket);
 }
 
-// precondition: sweep_ready(c, r.ticket)
-int p2p_advance(icpgpu_ctx* c, P2PRun& r) {
+// precondition: sweep_ready(c, r.ticket).  With `deferred` the next GATED sweep is not issued here: *deferred = true tells
+// the caller (the lock-step batch path) that the run wants one at r.final_T.
+// (*deferred: 0 nothing, 1 a gated sweep, 2 the ungated fitness sweep)
+int p2p_advance(icpgpu_ctx* c, P2PRun& r, int* deferred = nullptr) {
+  if (deferred) *deferred = 0;
   int rc = sweep_complete(c, r.ticket);
   if (rc) return rc;
   const double* sums = c->h_sums;
@@ -1099,7 +1194,13 @@ int p2p_advance(icpgpu_ctx* c, P2PRun& r) {
     }
   }
   r.t_issue = std::chrono::steady_clock::now();
-  if (!stop) return sweep_issue(c, to_xform(r.final_T), r.thr, false, r.ticket);
+  if (!stop) {
+    if (deferred) {
+      *deferred = 1;
+      return ICPGPU_OK;
+    }
+    return sweep_issue(c, to_xform(r.final_T), r.thr, false, r.ticket);
+  }
 
   c->final_T = r.final_T;
   c->have_final = true;
@@ -1111,6 +1212,10 @@ int p2p_advance(icpgpu_ctx* c, P2PRun& r) {
   r.res->mse_last = r.mse;
   if (r.want_fitness) {
     r.phase = P2PRun::Fitness;
+    if (deferred) {
+      *deferred = 2;
+      return ICPGPU_OK;
+    }
     return sweep_issue(c, to_xform(r.final_T), FLT_MAX, true, r.ticket);
   }
   return p2p_finish(c, r);
@@ -1912,10 +2017,19 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   if (n_pairs == 0) return ICPGPU_OK;
   const bool gicp = c->params.method == ICPGPU_GICP;
+  // Point-to-point batches run in LOCK-STEP (ICPGPU_BATCH_LOCKSTEP=0: the round-robin scheduler of round 2): a host thread
+  // leads a group of `depth` pairs on ONE stream -- their index builds go through their host round trips together, and
+  // every ICP iteration of the whole group is one search launch (pair = blockIdx.y, nn_quad_batch_kernel) + one final
+  // reduction launch (17 x K workgroups) + K host solves, instead of K x (launch + reduce + poll): ~35 launches per K
+  // pairs where there were ~35 per pair.  Two threads keep the GPU fed (one copies its next group in while the other's
+  // group iterates); results are bit-identical to icpgpu_align's (same kernels' bodies, same workgroup -> point mapping).
+  static const bool lockstep_on = [] { const char* e = std::getenv("ICPGPU_BATCH_LOCKSTEP"); return !e || std::atoi(e) != 0; }();
+  const bool lockstep = lockstep_on && !gicp;
   size_t n_threads = batch_threads(gicp ? 8 : 4), depth = 1;
   if (!gicp) {
     if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
-    else depth = std::max<size_t>(2, (8 + n_threads - 1) / n_threads);
+    else depth = lockstep ? 8 : std::max<size_t>(2, (8 + n_threads - 1) / n_threads);
+    if (lockstep) depth = std::min<size_t>(depth, (size_t)kBatchMax);
   }
   n_threads = std::min(n_threads, n_pairs);
   depth = std::min(depth, (n_pairs + n_threads - 1) / n_threads);
@@ -1934,11 +2048,11 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     std::string msg;
   };
   std::vector<ThreadError> errors(n_threads);
-  auto load_pair = [&](icpgpu_ctx* w, size_t k) {
+  auto load_pair = [&](icpgpu_ctx* w, size_t k, bool sync = true) {  // (the caller's buffers outlive this call: sync is optional)
     w->src_version++;
-    int rc = set_cloud_host(w, w->src, src[k], n_src[k]);
+    int rc = set_cloud_host(w, w->src, src[k], n_src[k], sync);
     w->tgt_version++;
-    if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k]);
+    if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k], sync);
     return rc;
   };
   auto work = [&](size_t t) {
@@ -1977,10 +2091,328 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
         if (rc) return failed(rc, k, w);
       }
     }
+    const double timeout_ms = wait_timeout_ms();
+    if (lockstep) {
+      // ---- lock-step groups ----------------------------------------------------------------------------------------
+      struct Slot {
+        icpgpu_ctx* w = nullptr;
+        size_t pair = 0;
+        P2PRun run;
+        GridBuild gb;
+        bool lock = false;     // iterates inside the group's lock-step launches (else: the single-pair state machine)
+        bool wants = false;    // lock-step: its next gated sweep is due
+        bool wants_fit = false;  // lock-step: its ungated fitness sweep is due
+        bool waiting = false;  // lock-step: a sweep of it is in flight
+        bool pack = false;
+        float4* prev = nullptr;
+      };
+      std::vector<Slot> slots(depth);
+      icpgpu_ctx* lead = ws[0];
+      hipStream_t gstream = lead->stream;
+      std::vector<hipStream_t> own(depth);
+      for (size_t s2 = 0; s2 < depth; ++s2) {
+        slots[s2].w = ws[s2];
+        own[s2] = ws[s2]->stream;
+        ws[s2]->stream = gstream;  // one queue for the group: builds, sweeps and fitness sweeps are ordered by it
+      }
+      struct Restore {
+        std::vector<hipStream_t>& own;
+        icpgpu_ctx* const* ws;
+        hipStream_t g;
+        ~Restore() {
+          (void)hipStreamSynchronize(g);
+          for (size_t i = 0; i < own.size(); ++i) ws[i]->stream = own[i];
+        }
+      } restore{own, ws, gstream};
+      if (ensure(lead, lead->batch_table, depth * sizeof(BatchPair))) return failed(ICPGPU_ERR_OOM, 0, lead);
+      std::vector<BatchPair> table(depth);
+      auto sync_or_fail = [&](Slot& sl) {
+        const hipError_t e = hipStreamSynchronize(gstream);
+        if (e == hipSuccess) return true;
+        fail(sl.w, ICPGPU_ERR_HIP, "lock-step batch: %s", hipGetErrorString(e));
+        failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+        return false;
+      };
+      int timed_pairs = 0;          // pairs of the launch whose events are outstanding
+      unsigned step_counter = 0;
+      static const bool bt_on = [] { const char* e = std::getenv("ICPGPU_BATCH_TIMING"); return e && std::atoi(e) != 0; }();
+      double bt_fill = 0, bt_build = 0, bt_iter = 0;
+      size_t bt_groups = 0, bt_steps = 0;
+      struct BtPrint {
+        const bool& on; double &f, &b, &i; size_t &g, &st; size_t t;
+        ~BtPrint() { if (on && g) fprintf(stderr, "[icpgpu] batch thread %zu: %zu groups, %zu steps; per group: fill (H2D) %.3f ms, index builds %.3f ms, iterations + fitness %.3f ms\n", t, g, st, f / g, b / g, i / g); }
+      } bt_print{bt_on, bt_fill, bt_build, bt_iter, bt_groups, bt_steps, t};
+      for (;;) {
+        const auto bt0 = std::chrono::steady_clock::now();
+        // (1) fill the group
+        size_t n_slots = 0;
+        while (n_slots < depth && !abort.load()) {
+          const size_t k = next.fetch_add(1);
+          if (k >= n_pairs) break;
+          Slot& sl = slots[n_slots];
+          sl.pair = k;
+          sl.lock = sl.wants = sl.wants_fit = sl.waiting = false;
+          int rc = load_pair(sl.w, k, /*sync=*/false);
+          if (!rc) rc = p2p_prepare(sl.w, sl.run, nullptr, nullptr, want_fitness, &results[k]);
+          if (rc) return failed(rc, k, sl.w);
+          ++n_slots;
+        }
+        if (n_slots == 0 || abort.load()) return;
+        const auto bt1 = std::chrono::steady_clock::now();
+        // (2) the target grids, every build's host round trips shared by the group
+        for (size_t i = 0; i < n_slots; ++i) {
+          Slot& sl = slots[i];
+          sl.gb = GridBuild{};
+          if (sl.run.phase == P2PRun::Done) continue;  // empty target
+          icpgpu_ctx* w = sl.w;
+          const int mode = w->params.nn_mode;
+          const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && w->tgt.n >= kGridMinTarget);
+          const double cut = std::sqrt((double)sl.run.thr) * (1.0 + 1e-6);
+          if (!want || !(sl.run.thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
+            w->grid.usable = w->grid.built = false;
+            continue;
+          }
+          const int rc = gb_begin(w, sl.gb, w->tgt, w->tgt_version, cut, /*adapt=*/true, w->grid);
+          if (rc) return failed(rc, sl.pair, w);
+        }
+        for (;;) {
+          bool pending = false;
+          for (size_t i = 0; i < n_slots; ++i) pending = pending || slots[i].gb.state != GridBuild::Done;
+          if (!pending) break;
+          if (!sync_or_fail(slots[0])) return;
+          for (size_t i = 0; i < n_slots; ++i)
+            if (slots[i].gb.state != GridBuild::Done) {
+              const int rc = gb_advance(slots[i].w, slots[i].gb);
+              if (rc) return failed(rc, slots[i].pair, slots[i].w);
+            }
+        }
+        const auto bt2 = std::chrono::steady_clock::now();
+        // (3) who can iterate in lock-step; the others start their own first sweep
+        size_t live = 0;
+        for (size_t i = 0; i < n_slots; ++i) {
+          Slot& sl = slots[i];
+          if (sl.run.phase == P2PRun::Done) continue;
+          icpgpu_ctx* w = sl.w;
+          ++live;
+          const int n_s = (int)w->src.n;
+          const int flags = grid_flags(w->grid, false);
+          sl.lock = grid_ready(w) && n_s > 0 && w->src.n < kOrderSourceMin && source_order_mode() != 1 &&
+                    grid_search_batchable(n_s, flags) && sl.run.thr <= w->grid.cutoff * w->grid.cutoff;
+          sl.run.phase = P2PRun::Iterating;
+          sl.run.t_issue = std::chrono::steady_clock::now();
+          if (!sl.lock) {
+            int rc = ensure_source_order(w, sl.run.thr);
+            if (!rc) rc = sweep_issue(w, to_xform(sl.run.final_T), sl.run.thr, false, sl.run.ticket);
+            if (rc) return failed(rc, sl.pair, w);
+            continue;
+          }
+          if (w->src_grid.version != w->src_version) w->src_grid.built = w->src_grid.usable = false;
+          const int blocks = grid_search_blocks(n_s);
+          int rc = ensure(w, w->partials, (size_t)blocks * kReduceTerms * sizeof(double));
+          bool use_prev = false;
+          if (!rc) rc = prev_neighbours(w, w->grid, w->src.data(), n_s, flags, sl.prev, use_prev);  // (allocates; the first sweep is cold)
+          if (rc) return failed(rc, sl.pair, w);
+          w->prev.valid = false;
+          sl.pack = (flags & kGridPackShortRows) != 0;
+          if (!rc) rc = ensure(w, w->keys, (size_t)n_s * sizeof(unsigned long long));
+          if (!rc) rc = ensure(w, w->grid.unmatched, (size_t)(n_s + 1) * sizeof(int));
+          if (rc) return failed(rc, sl.pair, w);
+          BatchPair& bp = table[i];
+          bp.keys = static_cast<unsigned long long*>(w->keys.ptr);
+          bp.unmatched = static_cast<int*>(w->grid.unmatched.ptr);
+          bp.unmatched_count = bp.unmatched + n_s;
+          bp.r_max_open = std::min(4 * w->grid.g.r_max, 48);
+          bp.src = w->src.data();
+          bp.sorted = static_cast<const float4*>(w->grid.sorted.ptr);
+          bp.cell_start = static_cast<const int*>(w->grid.cell_start.ptr);
+          bp.partials = static_cast<double*>(w->partials.ptr);
+          bp.prev_nn = sl.prev;
+          bp.flags = w->h_flags_dev;
+          bp.g = w->grid.g;
+          bp.accept_thr = sl.run.thr;
+          bp.n_s = n_s;
+          bp.qpw = grid_search_qpw(n_s);
+          bp.xcd_map = 0;
+          bp.blocks = blocks;
+          sl.wants = true;
+        }
+        // one row-walk variant for the whole group (the packed walk of sparse targets is a speed choice, the neighbours are the
+        // same): the majority's, so that a step is ONE launch
+        {
+          int n_lock = 0, n_pack = 0;
+          for (size_t i = 0; i < n_slots; ++i)
+            if (slots[i].lock) {
+              ++n_lock;
+              n_pack += slots[i].pack ? 1 : 0;
+            }
+          const bool group_pack = 2 * n_pack >= n_lock && n_pack > 0;
+          for (size_t i = 0; i < n_slots; ++i) slots[i].pack = group_pack;
+        }
+        if (hipMemcpyAsync(lead->batch_table.ptr, table.data(), n_slots * sizeof(BatchPair), hipMemcpyHostToDevice, gstream) != hipSuccess) {
+          fail(lead, ICPGPU_ERR_HIP, "lock-step batch: table upload");
+          return failed(ICPGPU_ERR_HIP, slots[0].pair, lead);
+        }
+        // (4) iterate: one search launch + one reduction launch per step and row-walk class for the whole group
+        unsigned idle_spins = 0;
+        while (live > 0) {
+          // a step is launched when no lock-step sweep of the group is in flight any more (the step IS the batch; pairs in
+          // their fitness sweep or on the single-pair path do not hold it up)
+          bool lock_in_flight = false;
+          for (size_t i = 0; i < n_slots; ++i) lock_in_flight = lock_in_flight || (slots[i].lock && slots[i].waiting);
+          for (int kind = 0; kind < 2 && !lock_in_flight; ++kind) {  // 0: the gated sweeps due, 1: the fitness sweeps due
+            BatchStep step;
+            int n_act = 0, max_blocks = 0;
+            bool group_pack = false;
+            step.use_prev_mask = 0u;
+            for (size_t i = 0; i < n_slots; ++i) {
+              Slot& sl = slots[i];
+              if (!sl.lock || !(kind == 0 ? sl.wants : sl.wants_fit)) continue;
+              icpgpu_ctx* w = sl.w;
+              group_pack = sl.pack;
+              bool use_prev = false;
+              float4* buf = nullptr;
+              if (prev_neighbours(w, w->grid, w->src.data(), (int)w->src.n, grid_flags(w->grid, false), buf, use_prev) || buf != sl.prev) {
+                fail(w, ICPGPU_ERR_HIP, "lock-step batch: previous-neighbour buffer moved");
+                return failed(ICPGPU_ERR_HIP, sl.pair, w);
+              }
+              step.T[n_act] = to_xform(sl.run.final_T);
+              step.seq[n_act] = ++w->sums_seq;
+              step.slot[n_act] = (unsigned char)i;
+              if (use_prev) step.use_prev_mask |= 1u << n_act;
+              max_blocks = std::max(max_blocks, table[i].blocks);
+              sl.run.ticket = SweepTicket{};
+              sl.run.ticket.seq = step.seq[n_act];
+              sl.run.t_issue = std::chrono::steady_clock::now();
+              sl.wants = sl.wants_fit = false;
+              sl.waiting = true;
+              w->call_sweeps += 1;
+              w->prof.grid_launches += 1;
+              w->prof.reduce_launches += 1;
+              w->prof.grid_bytes += 16ull * ((uint64_t)w->src.n + (uint64_t)w->tgt.n) +
+                                    (kind == 0 ? 136ull * (uint64_t)table[i].blocks : 8ull * (uint64_t)w->src.n);
+              w->prof.reduce_bytes += kind == 0 ? 136ull * (uint64_t)table[i].blocks : 40ull * (uint64_t)w->src.n + 136;
+              if (kind == 1) {  // the ungated sweep's set-up, as sweep_issue / nn_keys_grid do it for one pair
+                sl.run.ticket.few_host = reinterpret_cast<volatile int*>(w->h_sums + 20);
+                *sl.run.ticket.few_host = -1;
+                sl.run.ticket.red_src = w->src.data();
+                sl.run.ticket.red_n = (int)w->src.n;
+                sl.run.ticket.T = step.T[n_act];
+                sl.run.ticket.thr = FLT_MAX;
+                if (hipMemsetAsync(table[i].unmatched_count, 0, sizeof(int), gstream) != hipSuccess) {
+                  fail(w, ICPGPU_ERR_HIP, "lock-step batch: memset");
+                  return failed(ICPGPU_ERR_HIP, sl.pair, w);
+                }
+              }
+              ++n_act;
+            }
+            if (n_act == 0) continue;
+            bt_steps += 1;
+            // kernel timing, sampled like the single-pair path's: a launch's HIP-event time / its pairs = one pair's sweep
+            auto take_timing = [&](bool wait) {
+              if (!timed_pairs) return;
+              if (wait) (void)hipEventSynchronize(lead->ev[3]);
+              else if (hipEventQuery(lead->ev[3]) != hipSuccess) return;
+              float ms = 0.f;
+              if (hipEventElapsedTime(&ms, lead->ev[2], lead->ev[3]) == hipSuccess) {
+                lead->prof.grid_ms += (double)ms;  // (summed over the launch's pairs: grid_ms / grid_timed stays "per pair and sweep")
+                lead->prof.grid_timed += (uint64_t)timed_pairs;
+              }
+              timed_pairs = 0;
+            };
+            take_timing(false);
+            const bool timed = kind == 0 && timed_pairs == 0 && (step_counter++ % 5u) == 0;
+            if (timed) (void)hipEventRecord(lead->ev[2], gstream);
+            const BatchPair* d_table = static_cast<const BatchPair*>(lead->batch_table.ptr);
+            hipError_t e = launch_nn_grid_search_batch(d_table, step, n_act, max_blocks, group_pack, kind == 1, gstream);
+            if (timed) {
+              (void)hipEventRecord(lead->ev[3], gstream);
+              timed_pairs = n_act;
+            }
+            if (e == hipSuccess && kind == 0) e = launch_reduce_final_batch(d_table, step, n_act, gstream);
+            if (e != hipSuccess) {
+              fail(lead, ICPGPU_ERR_HIP, "lock-step batch launch: %s", hipGetErrorString(e));
+              return failed(ICPGPU_ERR_HIP, slots[step.slot[0]].pair, lead);
+            }
+            if (kind == 1) {
+              // per pair: the few points the grid left unmatched (completed on the device), then the keys-path reduction into
+              // the pair's mailbox -- three small launches each, queued without waiting
+              for (int a2 = 0; a2 < n_act; ++a2) {
+                Slot& sl = slots[step.slot[a2]];
+                icpgpu_ctx* w = sl.w;
+                const BatchPair& bp = table[step.slot[a2]];
+                hipError_t e2 = launch_nn_brute_few(w->src.data(), bp.unmatched, bp.unmatched_count, 0, w->tgt.data(), (int)w->tgt.n,
+                                                    step.T[a2], bp.keys, reinterpret_cast<int*>(w->h_sums_dev + 20), gstream);
+                int rc2 = e2 == hipSuccess ? ensure(w, w->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)) : ICPGPU_ERR_HIP;
+                if (!rc2 && launch_reduce(w->src.data(), (int)w->src.n, w->tgt.data(), bp.keys, step.T[a2], FLT_MAX,
+                                          static_cast<double*>(w->partials.ptr), w->h_sums_dev, w->h_flags_dev, step.seq[a2], gstream) != hipSuccess)
+                  rc2 = ICPGPU_ERR_HIP;
+                if (rc2) {
+                  fail(w, rc2, "lock-step batch: fitness sweep");
+                  return failed(rc2, sl.pair, w);
+                }
+              }
+            }
+          }
+          // wait for something to come back, then take everything that has
+          bool progressed = false;
+          for (size_t i = 0; i < n_slots; ++i) {
+            Slot& sl = slots[i];
+            if (sl.run.phase != P2PRun::Iterating && sl.run.phase != P2PRun::Fitness) continue;
+            if (sl.lock && !sl.waiting) continue;  // its sweep has not been launched yet
+            if (!sweep_ready(sl.w, sl.run.ticket)) continue;
+            sl.waiting = false;
+            int deferred = 0;
+            const int rc = p2p_advance(sl.w, sl.run, (sl.lock && sl.run.phase == P2PRun::Iterating) ? &deferred : nullptr);
+            if (rc) return failed(rc, sl.pair, sl.w);
+            sl.wants = deferred == 1;
+            sl.wants_fit = deferred == 2;
+            if (sl.run.phase == P2PRun::Done) --live;
+            progressed = true;
+          }
+          if (progressed) {
+            idle_spins = 0;
+            continue;
+          }
+          if ((++idle_spins & 0x3FFu) == 0) {  // nothing moved for a while: a faulted or hung kernel must not keep us here
+            const auto now = std::chrono::steady_clock::now();
+            const hipError_t q = hipStreamQuery(gstream);
+            for (size_t i = 0; i < n_slots; ++i) {
+              Slot& sl = slots[i];
+              if (sl.run.phase != P2PRun::Iterating && sl.run.phase != P2PRun::Fitness) continue;
+              if (q != hipSuccess && q != hipErrorNotReady) {
+                fail(sl.w, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+                return failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+              }
+              if (std::chrono::duration<double, std::milli>(now - sl.run.t_issue).count() > timeout_ms) {
+                fail(sl.w, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", timeout_ms);
+                return failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+              }
+            }
+          }
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+        if (timed_pairs) {  // (the group is finished: its last timed launch is, too)
+          float ms = 0.f;
+          if (hipEventSynchronize(lead->ev[3]) == hipSuccess && hipEventElapsedTime(&ms, lead->ev[2], lead->ev[3]) == hipSuccess) {
+            lead->prof.grid_ms += (double)ms;
+            lead->prof.grid_timed += (uint64_t)timed_pairs;
+          }
+          timed_pairs = 0;
+        }
+        if (bt_on) {
+          const auto bt3 = std::chrono::steady_clock::now();
+          bt_fill += std::chrono::duration<double, std::milli>(bt1 - bt0).count();
+          bt_build += std::chrono::duration<double, std::milli>(bt2 - bt1).count();
+          bt_iter += std::chrono::duration<double, std::milli>(bt3 - bt2).count();
+          bt_groups += 1;
+        }
+      }
+    }
     std::vector<P2PRun> runs(depth);
     std::vector<size_t> pair_of(depth, 0);
     bool exhausted = false;
-    const double timeout_ms = wait_timeout_ms();
     for (unsigned idle_spins = 0;;) {
       bool progressed = false;
       size_t in_flight = 0;

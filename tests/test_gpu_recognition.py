@@ -34,12 +34,14 @@ def test_previous_source_is_recognised_and_results_do_not_change(built, method, 
         c.set_source(c3)
         got = c.align(want_fitness=True)
         assert np.array_equal(got["T"], want["T"]) and got["iterations"] == want["iterations"]
-        assert got["n_corr"] == want["n_corr"] and got["fitness"] == want["fitness"]
+        # (fitness: a float64 sum over the source in CELL order from 100k points on, and the order inside a cell comes from
+        # atomic ranks -- the last bit may differ from run to run of the SAME call sequence, with or without recognition)
+        assert got["n_corr"] == want["n_corr"] and abs(got["fitness"] - want["fitness"]) <= 1e-12 * want["fitness"]
         c.set_target(a.copy())                     # the unchanged target (a rejected scan keeps prev_cloud_): nothing to do
         after = c.profile()
         assert after.targets_recognised == mid.targets_recognised + 1 and after.grid_builds == c.profile().grid_builds
         again = c.align(want_fitness=True)
-        assert np.array_equal(again["T"], want["T"]) and again["fitness"] == want["fitness"]
+        assert np.array_equal(again["T"], want["T"]) and abs(again["fitness"] - want["fitness"]) <= 1e-12 * want["fitness"]
         # same size, one bit different: NOT recognised, uploaded
         a2 = a.copy()
         a2.view(np.uint32)[n // 2, 1] ^= 1
