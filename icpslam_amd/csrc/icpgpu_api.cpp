@@ -1763,6 +1763,10 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->idx);
   release(c->d2);
   release(c->brute_seed.keys);
+  release(c->fp_acc);
+  release(c->batch_table);
+  release(c->map.node_keys);
+  release(c->map.node_vals);
   if (c->cand_counter.ptr) grid_count_candidates(nullptr);
   release(c->cand_counter);
   for (DeviceBuf* b : {&c->map.pts.buf, &c->map.keys, &c->map.vals, &c->map.first, &c->map.staged, &c->map.moved, &c->map.slot_of,

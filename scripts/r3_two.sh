@@ -1,0 +1,9 @@
+#!/bin/bash
+# Round 3: second grid level in nn_quad_kernel -- parity, then per-sweep times with and without it
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r3_two}; mkdir -p $O; cd $R
+timeout 1500 python -m pytest tests/test_gpu_grid.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -m gpu -x -q > $O/pytest.txt 2>&1; grep -E "passed|failed|rror" $O/pytest.txt | tail -5
+for rep in 1 2; do
+  for f in 0 1; do
+    for s in 200000x200000 50000x50000 200000x1000000; do echo -n "TWO_LEVEL=$f "; ICPGPU_TWO_LEVEL=$f python scripts/iter_profile.py $s 2>/dev/null; done
+  done
+done | tee $O/iter.txt
