@@ -523,9 +523,21 @@ def main():
                 valu = float(issue_pmc["valu_insts_per_launch"])
                 ginst = valu / (g_ms * 1e-3) / 1e9
                 cand = float(issue_pmc.get("candidates_per_launch", 0.0))
+                # ... and what the kernel's own instruction MIX can issue: 41 % of its vector instructions are full rate (2.35
+                # cycles measured), 59 % half rate (4.2: every compare, select, DPP move, lane read, min/max, shift, convert) --
+                # scripts/probes/valu_rate.cpp, profiles/r03_valu_issue_and_pmc.txt
+                mix_cycles = 0.41 * 2.35 + 0.59 * 4.2
+                mix_peak = N_SIMDS * CLOCK_GHZ / mix_cycles
+                act, gui = issue_pmc.get("valu_active_cycles_x4"), issue_pmc.get("grbm_gui_active_sum_over_xcds")
                 roofline["issue"] = {
                     "bound": "valu_issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instr/s",
-                    "frac": ginst / VALU_ISSUE_PEAK_GINST, "valu_insts_per_launch": valu,
+                    "frac": ginst / VALU_ISSUE_PEAK_GINST,
+                    "peak_for_this_instruction_mix": mix_peak, "frac_of_mix_peak": ginst / mix_peak,
+                    "valu_pipe_busy_frac_pmc": (4.0 * act / (N_SIMDS * gui / 8.0)) if act and gui else None,
+                    "note": "peak = every SIMD-32 issuing a full-rate wave64 instruction every 2 cycles (v_fma_f32); this kernel's "
+                            "static mix averages 3.4 cycles per instruction (measured class rates), and SQ_ACTIVE_INST_VALU x 4 / "
+                            "(SIMDs x GRBM_GUI_ACTIVE per XCD) of the same PMC pass says how busy the vector pipes were",
+                    "valu_insts_per_launch": valu,
                     "valu_insts_per_source_point": valu / n_s,
                     "salu_insts_per_launch": issue_pmc.get("salu_insts_per_launch"),
                     "candidates_per_launch": cand or None,
