@@ -30,6 +30,8 @@
 // tests/test_gpu_parity.py / test_gpu_grid.py / test_gpu_fullsize.py compare this kernel's keys with the VALU kernel and the
 // oracle bit for bit (ties, duplicates, NaN / inf points, far outliers, 200k x 200k and 200k x 1M).
 #include <hip/hip_runtime.h>
+
+#include <cstdio>
 #include <math.h>
 
 #include <cstdlib>
@@ -236,7 +238,12 @@ hipError_t launch_nn_brute_mfma(const float4* src_sorted, int n_q, const float4*
   // ICPGPU_MFMA_NO_EXACT (timing only: the exact path is skipped, results are wrong)
   static const int g_env = [] { const char* e = getenv("ICPGPU_MFMA_G"); return e ? atoi(e) : 2; }();
   static const int waves_env = [] { const char* e = getenv("ICPGPU_MFMA_WAVES"); return e ? atoi(e) : 32; }();
-  static const int no_exact = getenv("ICPGPU_MFMA_NO_EXACT") ? 1 : 0;
+  static const int no_exact = [] {
+    if (!getenv("ICPGPU_MFMA_NO_EXACT")) return 0;
+    fprintf(stderr, "[icpgpu] WARNING: ICPGPU_MFMA_NO_EXACT is set -- the matrix-core search skips its exact path, every brute-force result "
+                    "of this process is WRONG (a timing experiment's switch, never a production setting)\n");
+    return 1;
+  }();
   const int G = g_env == 4 ? 4 : 2;
   const int per_block = (MF_BLOCK / 64) * 32 * G;
   const int grid_x = (n_q + per_block - 1) / per_block;

@@ -661,7 +661,12 @@ static bool quad_enabled() {
 static unsigned long long* g_count_candidates = nullptr;
 // timing experiments only: ICPGPU_SKIP_UNCERT (uncertified points are dropped -- wrong results, the octant stage's time alone)
 static int quad_debug_bits() {
-  static const int v = getenv("ICPGPU_SKIP_UNCERT") ? 2 : 0;
+  static const int v = [] {
+    if (!getenv("ICPGPU_SKIP_UNCERT")) return 0;
+    fprintf(stderr, "[icpgpu] WARNING: ICPGPU_SKIP_UNCERT is set -- uncertified points are DROPPED, every result of this process is WRONG "
+                    "(a timing experiment's switch, never a production setting)\n");
+    return 2;
+  }();
   return v;
 }
 // First radius of the cube search (see nn_quad_kernel).  Bit 0: sweeps with a previous neighbour start at the seed's radius

@@ -661,7 +661,13 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   if (debug && hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)groups * 8 * sizeof(long long)) == hipSuccess)
     (void)hipMemsetAsync(dbg, 0, (size_t)groups * 8 * sizeof(long long), stream);
   // ICPGPU_VOXEL_TEST_STALL=1 (tests): the first group publishes 30 ms late -- the others give up, the sort path takes over
-  static const int test_stall = [] { const char* e = std::getenv("ICPGPU_VOXEL_TEST_STALL"); return e ? std::atoi(e) : 0; }();
+  static const int test_stall = [] {
+    const char* e = std::getenv("ICPGPU_VOXEL_TEST_STALL");
+    const int v = e ? std::atoi(e) : 0;
+    if (v) std::fprintf(stderr, "[icpgpu] WARNING: ICPGPU_VOXEL_TEST_STALL is set -- every voxel-filter call stalls 30 ms and falls back to the "
+                                "sort path (results unchanged; a test's switch, never a production setting)\n");
+    return v;
+  }();
   hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, published, epoch, out,
                      d_n_out, hist, nbins, status, dbg, test_stall);
   if (dbg) {

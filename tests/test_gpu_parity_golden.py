@@ -70,3 +70,23 @@ def test_gicp_matches_golden(ctx):
     assert abs(r["fitness"] - float(g["fitness"])) <= 1e-4 * float(g["fitness"])
     cov = ctx.gicp_covariances(of_target=True)
     assert np.abs(cov - g["cov_tgt"]).max() <= 1e-6
+
+
+def test_gicp_golden_pair_is_bit_identical_to_the_c_oracle_in_exact_mode(ctx):
+    """The tolerance pin above is against an independent restatement; THIS one is the regression pin for the kernels behind it
+    (gicp_cost / gicp_server, the double-double reduction, the mailbox, the Jacobi SVD): on the same fixture pair the GPU and
+    oracle/gicp_oracle.c in its EXACT-sum mode agree to the bit -- transform, outer iterations, correspondences -- and the
+    covariances entry by entry."""
+    import oracle
+    from icpslam_amd import GICP
+    g = _golden("gicp_1k5.npz")
+    ctx.set_params(ctx.default_params(), method=GICP)
+    ctx.set_source(g["src"])
+    ctx.set_target(g["tgt"])
+    r = ctx.align(want_fitness=True)
+    o = oracle.icp_align(g["src"], g["tgt"], oracle.default_params(method=oracle.GICP, gicp_sums=oracle.GICP_SUMS_EXACT), want_fitness=True)
+    assert np.array_equal(r["T"], o["T"]) and r["iterations"] == o["iterations"] and r["n_corr"] == o["n_corr"]
+    assert r["converged"] == o["converged"] and abs(r["fitness"] - o["fitness"]) <= 1e-12 * o["fitness"]
+    cov = ctx.gicp_covariances(of_target=True)
+    ref = oracle.gicp_covariances(g["tgt"])
+    assert cov.shape == ref.shape and np.array_equal(cov, ref)          # (n, 3, 3), both symmetric by construction
