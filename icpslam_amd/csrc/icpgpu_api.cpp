@@ -1854,11 +1854,19 @@ int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
         if (have == fp) {
           c->prof.targets_recognised += 1;
           rc = promote_internal(c);
-          if (rc == ICPGPU_OK) {
-            c->tgt_fp = fp;
-            c->tgt_fp_version = c->tgt_version;
-          }
-          return rc;
+          if (rc != ICPGPU_OK) return rc;
+          c->tgt_fp = fp;
+          c->tgt_fp_version = c->tgt_version;
+          // set_target must not take the source away (a caller may set the SAME cloud as source and target, or set the source
+          // first): the source is put back as a device-to-device copy of what is now the target -- microseconds, and the
+          // odometer's next set_source overwrites it anyway.  Its cell order / covariances moved on with the target.
+          if ((rc = ensure(c, c->src.buf, n * sizeof(float4)))) return rc;
+          HIP_TRY(c, hipMemcpyAsync(c->src.buf.ptr, c->tgt.buf.ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+          c->src.n = n;
+          c->src.set = true;
+          c->src_fp = fp;
+          c->src_fp_version = c->src_version;
+          return ICPGPU_OK;
         }
       }
       c->tgt_version++;

@@ -168,7 +168,8 @@ int icpgpu_set_target(icpgpu_ctx* ctx, const float* xyzw, size_t n);
  * whose content (size, then a 64-bit content fingerprint) is the context's current source or target and
  * keeps what it has in HBM -- the cloud, its search grid, its GICP covariances -- instead of uploading
  * and rebuilding (the promote path for the source; nothing at all for the unchanged target of a rejected
- * scan).  Call set_target BEFORE set_source when both change.  icpgpu_fingerprint is that fingerprint of
+ * scan); the source stays set (as a device-side copy) either way.  Call set_target BEFORE set_source when both change
+ * (after set_source the previous source is gone and there is nothing to recognise).  icpgpu_fingerprint is that fingerprint of
  * a host buffer (n points of 16 bytes); icpgpu_cloud_sizes reports what a context holds (the C++ shim's
  * context pool picks the context whose source has the new target's size). */
 unsigned long long icpgpu_fingerprint(const float* xyzw, size_t n);

@@ -30,7 +30,7 @@ def test_previous_source_is_recognised_and_results_do_not_change(built, method, 
         c.set_target(a.copy())                     # the previous source, in another host buffer: the promote path
         mid = c.profile()
         assert mid.targets_recognised == before.targets_recognised + 1
-        assert c.n_target == n and c.n_source == 0
+        assert c.n_target == n and c.n_source == n   # (the source stays set: a device-side copy of the cloud)
         c.set_source(c3)
         got = c.align(want_fitness=True)
         assert np.array_equal(got["T"], want["T"]) and got["iterations"] == want["iterations"]
@@ -68,3 +68,18 @@ def test_device_and_host_fingerprints_agree(built):
             base = c.profile().targets_recognised
             c.set_target(a.copy())
             assert c.profile().targets_recognised == base + 1, n
+
+
+def test_a_cloud_registered_against_itself_survives_the_recognition(built):
+    """set_source(A); set_target(A): the target is recognised as the current source -- and the source must still be there."""
+    a, _, _ = synth.make_pair(40000, 40000, seed=41)
+    with Context(0) as c:
+        c.set_params(c.default_params(), max_iterations=3)
+        c.set_source(a)
+        c.set_target(a.copy())
+        assert c.profile().targets_recognised == 1
+        r = c.align(want_fitness=True)
+        assert r["converged"] and r["n_corr"] == 40000 and r["fitness"] <= 1e-10
+        assert np.abs(r["T"] - np.eye(4, dtype=np.float32)).max() <= 1e-6
+        idx, d2 = c.nn(np.eye(4))
+        assert np.array_equal(idx, np.arange(40000)) and not d2.any()
