@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the kernel variant this script switches (ICPGPU_FLAT / ICPGPU_TWO_LEVEL / ICPGPU_SPLIT) was measured and REMOVED (DESIGN.md section 5 table,
+# profiles/r03_*): with the shipped library both settings run the same kernel.  Kept as the record of how the numbers were taken.
 # Round 3: split fused sweeps (octant stage + nn_cube16_kernel) -- parity, then per-sweep times with and without
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r3_split}; mkdir -p $O; cd $R
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_grid.py tests/test_gpu_recognition.py tests/test_gpu_sequence.py -m gpu -x -q > $O/pytest.txt 2>&1; grep -E "passed|failed|rror" $O/pytest.txt | tail -5

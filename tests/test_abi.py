@@ -128,3 +128,20 @@ def test_fingerprint_is_a_content_hash(built):
     assert fp(c) != fp(a)
     assert fp(a[:999]) != fp(a)
     assert fp(np.zeros((0, 4), np.float32)) == fp(np.zeros((0, 4), np.float32))
+
+
+def test_multi_gpu_entry_reports_codes_without_a_gpu(built):
+    """icpgpu_align_batch_multi (one process, one host thread per device): argument errors are status codes with a message, and
+    without a usable device the call fails like icpgpu_create does -- no fallback, no abort."""
+    import ctypes as C
+    lib = _lib.load()
+    res = (_lib.Result * 1)()
+    assert lib.icpgpu_align_batch_multi(None, 1, None, 0, None, None, None, None, 0, res, None, 0) == _lib.ERR_INVALID_ARG
+    assert b"device list" in lib.icpgpu_multi_last_error()
+    dev = (C.c_int * 1)(0)
+    assert lib.icpgpu_align_batch_multi(dev, 1, None, 0, None, None, None, None, 0, res, None, 7) == _lib.ERR_INVALID_ARG
+    assert b"communicator" in lib.icpgpu_multi_last_error()
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.icpgpu_align_batch_multi(dev, 1, None, 0, None, None, None, None, 0, res, None, 0)
+        assert rc == _lib.ERR_NO_DEVICE and b"no CPU fallback" in lib.icpgpu_multi_last_error()
