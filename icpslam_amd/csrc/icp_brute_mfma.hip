@@ -55,12 +55,11 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
 }
 
 // G groups of 32 sources per wave (both half-waves hold the same 32 sources; each sees 16 of a tile's 32 targets)
-template <int G>
-__global__ __launch_bounds__(MF_BLOCK) void nn_brute_mfma_kernel(const float4* __restrict__ src_sorted, int n_q,
-                                                                 const float4* __restrict__ tgt, int n_t, Xform T,
-                                                                 int tgt_per_split, int splits,
-                                                                 unsigned long long* __restrict__ keys,
-                                                                 const unsigned long long* __restrict__ seed, int debug_no_exact) {
+template <int G, bool PIPE>
+__device__ __forceinline__ void nn_brute_mfma_body(const float4* __restrict__ src_sorted, int n_q,
+                                                   const float4* __restrict__ tgt, int n_t, const Xform& T,
+                                                   int tgt_per_split, int splits, unsigned long long* __restrict__ keys,
+                                                   const unsigned long long* __restrict__ seed, int debug_no_exact) {
   // a target tile in LDS, twice: the raw points (for the exact evaluations) and the MFMA's A operands, ready to use --
   // (q'x, q'y) and (q'z, |q'|^2 - tau) -- computed ONCE per tile and workgroup instead of per wave and step (16 vector
   // instructions per step less; measured effect on the sweep: within noise -- the kernel sits at 1.55-1.6x the time its MFMAs
@@ -160,10 +159,14 @@ __global__ __launch_bounds__(MF_BLOCK) void nn_brute_mfma_kernel(const float4* _
     const int lim = min(MF_TILE, j1 - jt);
     const float* __restrict__ a01p = reinterpret_cast<const float*>(a01s) + half;
     const float* __restrict__ a23p = reinterpret_cast<const float*>(a23s) + half;
-    for (int st = 0; st < lim; st += 32) {
+    // One step = 32 targets against the wave's 32 G sources: 2 G MFMAs, then the fold of their 16 G values per lane.  The
+    // steps are SOFTWARE-PIPELINED (PIPE): the MFMAs of step k + 1 are issued into a second accumulator set before step k's
+    // values are folded, so the ~27 vector instructions of a fold run under the wave's OWN matrix work -- round 2's counters
+    // showed matrix and vector time adding up (64 % + 27 %) instead of overlapping when a wave folds right behind its MFMAs
+    // and leaves the overlap to the other waves of the SIMD.
+    auto issue = [&](floatx16 (&acc)[G], int st) {
       const float a01 = a01p[2 * (st + col)], a23 = a23p[2 * (st + col)];  // lane supplies A[m = col][k = half]
-      // all the groups' MFMAs first (the second of a pair depends on the first: interleaved, neither waits), then the tests
-      floatx16 acc[G];
+      // all the groups' first MFMAs, then the second ones (each depends on its first: interleaved, neither waits)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -171,6 +174,8 @@ __global__ __launch_bounds__(MF_BLOCK) void nn_brute_mfma_kernel(const float4* _
       }
 #pragma unroll
       for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a23, b23[g], acc[g], 0, 0, 0);
+    };
+    auto fold = [&](floatx16 (&acc)[G], int st) {
       // The folds below are v_min3_f32 by hand (fminf on MFMA outputs makes the compiler canonicalise every operand first:
       // 6 extra instructions per fold).  Inline assembly is opaque to the compiler's hazard recogniser, which is what
       // inserts the wait states between an MFMA and the first vector read of its result -- so every accumulator is first
@@ -208,6 +213,26 @@ __global__ __launch_bounds__(MF_BLOCK) void nn_brute_mfma_kernel(const float4* _
           }
         }
       }
+    };
+    if (PIPE) {
+      floatx16 acc_a[G], acc_b[G];
+      issue(acc_a, 0);
+      for (int st = 0;; st += 64) {
+        const bool more_b = st + 32 < lim;
+        if (more_b) issue(acc_b, st + 32);
+        fold(acc_a, st);
+        if (!more_b) break;
+        const bool more_a = st + 64 < lim;
+        if (more_a) issue(acc_a, st + 64);
+        fold(acc_b, st + 32);
+        if (!more_a) break;
+      }
+    } else {
+      for (int st = 0; st < lim; st += 32) {
+        floatx16 acc[G];
+        issue(acc, st);
+        fold(acc, st);
+      }
     }
   }
 
@@ -223,6 +248,23 @@ __global__ __launch_bounds__(MF_BLOCK) void nn_brute_mfma_kernel(const float4* _
       else keys[orig[g]] = k;
     }
   }
+}
+
+template <int G, bool PIPE>
+__global__ __launch_bounds__(MF_BLOCK) void nn_brute_mfma_kernel(const float4* __restrict__ src_sorted, int n_q,
+                                                                 const float4* __restrict__ tgt, int n_t, Xform T,
+                                                                 int tgt_per_split, int splits,
+                                                                 unsigned long long* __restrict__ keys,
+                                                                 const unsigned long long* __restrict__ seed, int debug_no_exact) {
+  nn_brute_mfma_body<G, PIPE>(src_sorted, n_q, tgt, n_t, T, tgt_per_split, splits, keys, seed, debug_no_exact);
+}
+
+// the pipelined body held to 128 registers (four waves per SIMD instead of three; a few spills in return) -- ICPGPU_MFMA_PIPE=2
+template <int G>
+__global__ __launch_bounds__(MF_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn_brute_mfma_capped_kernel(
+    const float4* __restrict__ src_sorted, int n_q, const float4* __restrict__ tgt, int n_t, Xform T, int tgt_per_split,
+    int splits, unsigned long long* __restrict__ keys, const unsigned long long* __restrict__ seed, int debug_no_exact) {
+  nn_brute_mfma_body<G, true>(src_sorted, n_q, tgt, n_t, T, tgt_per_split, splits, keys, seed, debug_no_exact);
 }
 
 }  // namespace
@@ -256,12 +298,19 @@ hipError_t launch_nn_brute_mfma(const float4* src_sorted, int n_q, const float4*
   int per = (n_t + splits - 1) / splits;
   per = ((per + MF_TILE - 1) / MF_TILE) * MF_TILE;
   splits = (n_t + per - 1) / per;
-  if (G == 4)
-    hipLaunchKernelGGL((nn_brute_mfma_kernel<4>), dim3(grid_x, splits), dim3(MF_BLOCK), 0, stream, src_sorted, n_q, tgt, n_t, T,
-                       per, splits, keys, seed, no_exact);
-  else
-    hipLaunchKernelGGL((nn_brute_mfma_kernel<2>), dim3(grid_x, splits), dim3(MF_BLOCK), 0, stream, src_sorted, n_q, tgt, n_t, T,
-                       per, splits, keys, seed, no_exact);
+  static const int pipe_env = [] { const char* e = getenv("ICPGPU_MFMA_PIPE"); return e ? atoi(e) : 0; }();
+#define ICPGPU_MFMA_LAUNCH(...)                                                                                         \
+  hipLaunchKernelGGL((__VA_ARGS__), dim3(grid_x, splits), dim3(MF_BLOCK), 0, stream, src_sorted, n_q, tgt, n_t, T, per, splits, \
+                     keys, seed, no_exact)
+  if (G == 4) {
+    if (pipe_env) ICPGPU_MFMA_LAUNCH(nn_brute_mfma_kernel<4, true>);
+    else ICPGPU_MFMA_LAUNCH(nn_brute_mfma_kernel<4, false>);
+  } else {
+    if (pipe_env == 2) ICPGPU_MFMA_LAUNCH(nn_brute_mfma_capped_kernel<2>);
+    else if (pipe_env) ICPGPU_MFMA_LAUNCH(nn_brute_mfma_kernel<2, true>);
+    else ICPGPU_MFMA_LAUNCH(nn_brute_mfma_kernel<2, false>);
+  }
+#undef ICPGPU_MFMA_LAUNCH
   return hipGetLastError();
 }
 

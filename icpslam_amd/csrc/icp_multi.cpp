@@ -172,7 +172,10 @@ int icpgpu_align_batch_multi(const int* devices, int n_devices, const icpgpu_par
   const bool use_rccl = communicator == ICPGPU_COMM_RCCL;
   if (use_rccl) {
     Rccl& R = rccl();
-    if (!R.ok) return multi_fail(ICPGPU_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    if (!R.ok) {
+      const char* why = dlerror();                 // (reading it clears it: once)
+      return multi_fail(ICPGPU_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", why ? why : "missing symbols");
+    }
     const std::vector<int> want(devices, devices + n_devices);
     if (S.comm_devices != want) {
       for (ncclComm_t cm : S.comms) (void)R.CommDestroy(cm);

@@ -48,6 +48,10 @@ struct Cloud {
   DeviceBuf buf;
   size_t n = 0;
   bool set = false;
+  // fingerprint of 256 sampled points, taken from the HOST buffer at upload: lets icpgpu_set_target dismiss a same-sized but
+  // different cloud (fixed-size scans!) in a microsecond instead of hashing megabytes to find out
+  unsigned long long sample_fp = 0;
+  bool sample_valid = false;
   const float4* data() const { return static_cast<const float4*>(buf.ptr); }
 };
 
@@ -281,6 +285,20 @@ float threshold_from(double r2) {
   return f;
 }
 
+unsigned long long sample_fingerprint(const float* xyzw, size_t n) {
+  unsigned long long s = 0;
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(xyzw);
+  const size_t m = n < 256 ? n : 256;
+  for (size_t k = 0; k < m; ++k) {
+    const size_t i = (k * n) / m;
+    unsigned long long w0, w1;
+    std::memcpy(&w0, b + 16 * i, 8);
+    std::memcpy(&w1, b + 16 * i + 8, 8);
+    s += fp_point(w0, w1, (unsigned long long)i);
+  }
+  return fp_finish(s, (unsigned long long)n);
+}
+
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true) {
   if (n > 0 && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
   if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
@@ -292,6 +310,8 @@ int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool s
   }
   cl.n = n;
   cl.set = true;
+  cl.sample_valid = n > 0;
+  cl.sample_fp = n > 0 ? sample_fingerprint(xyzw, n) : 0;
   return ICPGPU_OK;
 }
 
@@ -304,6 +324,7 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
   cl.buf.external = true;
   cl.n = n;
   cl.set = true;
+  cl.sample_valid = false;
   return ICPGPU_OK;
 }
 
@@ -1836,8 +1857,13 @@ static int promote_internal(icpgpu_ctx* c);
 int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
   if (recognise_enabled() && n > 0 && xyzw) {
-    const bool tgt_cand = c->tgt.set && c->tgt.n == n && !c->tgt.buf.external;
-    const bool src_cand = c->src.set && c->src.n == n && !c->src.buf.external;
+    bool tgt_cand = c->tgt.set && c->tgt.n == n && !c->tgt.buf.external;
+    bool src_cand = c->src.set && c->src.n == n && !c->src.buf.external;
+    if ((tgt_cand && c->tgt.sample_valid) || (src_cand && c->src.sample_valid)) {  // a microsecond's look before the real one
+      const unsigned long long sf = sample_fingerprint(xyzw, n);
+      if (tgt_cand && c->tgt.sample_valid && c->tgt.sample_fp != sf) tgt_cand = false;
+      if (src_cand && c->src.sample_valid && c->src.sample_fp != sf) src_cand = false;
+    }
     if (tgt_cand || src_cand) {
       const unsigned long long fp = icpgpu_fingerprint(xyzw, n);
       unsigned long long have = 0;

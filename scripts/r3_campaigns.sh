@@ -14,7 +14,7 @@ echo "## scripts/voxel_campaign.py 2000  (direct path)"
 timeout 2400 python scripts/voxel_campaign.py 2000 2>&1 | grep -v amdgpu.ids | tail -1
 echo "## ICPGPU_VOXEL_SORT=1 scripts/voxel_campaign.py 1000  (sort path: the hand-written radix sort + scans of icp_scan.hip)"
 ICPGPU_VOXEL_SORT=1 timeout 2400 python scripts/voxel_campaign.py 1000 2>&1 | grep -v amdgpu.ids | tail -1
-echo "## scripts/pipeline_campaign.py (the reference's per-scan pipeline on random raw scans, bit for bit)"
-timeout 1200 python scripts/pipeline_campaign.py 2>&1 | grep -v amdgpu.ids | tail -2
+echo "## scripts/pipeline_campaign.py 0 60 (the reference's per-scan pipeline on random raw scans, bit for bit)"
+timeout 1200 python scripts/pipeline_campaign.py 0 60 2>&1 | grep -v amdgpu.ids | tail -2
 } > $O/campaigns.txt 2>&1
 cat $O/campaigns.txt

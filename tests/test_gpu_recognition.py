@@ -42,11 +42,19 @@ def test_previous_source_is_recognised_and_results_do_not_change(built, method, 
         assert after.targets_recognised == mid.targets_recognised + 1 and after.grid_builds == c.profile().grid_builds
         again = c.align(want_fitness=True)
         assert np.array_equal(again["T"], want["T"]) and abs(again["fitness"] - want["fitness"]) <= 1e-12 * want["fitness"]
-        # same size, one bit different: NOT recognised, uploaded
+        # same size, one bit different: NOT recognised, uploaded -- in a point the 256-point sample of the quick look holds
+        # (n/2) and, below, in one only the full fingerprint sees
         a2 = a.copy()
         a2.view(np.uint32)[n // 2, 1] ^= 1
         c.set_target(a2)
         assert c.profile().targets_recognised == after.targets_recognised
+        a3 = a2.copy()
+        a3.view(np.uint32)[n // 2 + 1, 2] ^= 1
+        c.set_target(a3)
+        assert c.profile().targets_recognised == after.targets_recognised
+        c.set_target(a3.copy())
+        assert c.profile().targets_recognised == after.targets_recognised + 1
+        c.set_target(a2)
         with Context(0) as fresh2:
             fresh2.set_params(fresh2.default_params(), **kw)
             fresh2.set_source(c3)
