@@ -41,7 +41,8 @@ class Profile(C.Structure):
                 ("map_nn_launches", C.c_uint64), ("map_nn_ms", C.c_double),
                 ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64),
                 ("grid_bounded", C.c_uint64), ("gicp_eval_ms", C.c_double), ("gicp_eval_corr", C.c_uint64), ("gicp_cov_points", C.c_uint64),
-                ("targets_recognised", C.c_uint64)]
+                ("targets_recognised", C.c_uint64), ("brute_bound_violations", C.c_uint64),
+                ("brute_bound_worst", C.c_double)]
 
 
 class Pose(C.Structure):

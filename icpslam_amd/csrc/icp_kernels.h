@@ -49,6 +49,16 @@ hipError_t launch_nn_brute(const float4* src, int n_s, const float4* tgt, int n_
 hipError_t launch_nn_brute_mfma(const float4* src_sorted, int n_q, const float4* tgt, int n_t, const Xform& T, int num_cus,
                                 unsigned long long* keys, const unsigned long long* seed, hipStream_t stream);
 
+// The same keys again with the lower bound on the bf16 matrix path (icp_brute_bf16.hip: split operands, one K = 16 MFMA per
+// 32 x 32 pairs, vector work overlapped).  src_morton: launch_morton_order's output.  check (nullable): 2 x u64 zeroed by the
+// caller -- the test mode's counters (pairs whose bound was too high; worst excess as float bits in the low half of [1]).
+struct GridDesc;
+size_t morton_order_work_ints(int n);
+hipError_t launch_morton_order(const float4* sorted, int n, const GridDesc& g, int* work, float4* out, hipStream_t stream);
+hipError_t launch_nn_brute_bf16(const float4* src_morton, int n_q, const float4* tgt, int n_t, const Xform& T, int num_cus,
+                                unsigned long long* keys, const unsigned long long* seed, unsigned long long* check,
+                                hipStream_t stream);
+
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
                          float d2_threshold, double* partials, double* sums_out, unsigned long long* flags,
                          unsigned long long seq, hipStream_t stream);

@@ -64,6 +64,7 @@ struct GridIndex {
   int n_binned = 0, max_pop = 0;
   double point_population = 0.0;  // cell population seen by a random point (sum c^2 / sum c)
   DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
+  uint64_t serial = 0;       // unique per completed build (grids change hands between c->grid and c->src_grid)
 };
 
 // The neighbour every query found in the last grid sweep (nn_quad_kernel): an upper bound for the next sweep of the same
@@ -80,6 +81,15 @@ struct PrevNeighbours {
 
 // Keys of the last matrix-core brute-force sweep (icp_brute_mfma.hip): every source's neighbour, a bound for the next sweep
 // of the same source over the same target.
+// The source in Morton order of its grid cells (icp_brute_bf16.hip wants a workgroup's sources close together): cached per
+// build of the source's grid.
+struct BruteOrder {
+  DeviceBuf pts, work, check;
+  bool valid = false;
+  uint64_t grid_serial = 0;
+  int n = 0;
+};
+
 struct BruteSeed {
   DeviceBuf keys;
   bool valid = false;
@@ -147,7 +157,8 @@ struct icpgpu_ctx {
   GridIndex grid;            // acceleration structure over the current target
   GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
   PrevNeighbours prev;       // last sweep's neighbours (search bound of the next sweep)
-  BruteSeed brute_seed;      // the same for the matrix-core brute-force kernel
+  BruteSeed brute_seed;      // the same for the matrix-core brute-force kernels
+  BruteOrder brute_order;    // the source in Morton order (bf16 matrix-core kernel)
   VoxelMap map;              // the mapper's map
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
   // content fingerprints of the clouds in HBM (icpgpu_set_target's recognition of a cloud it already holds), computed on
@@ -559,6 +570,8 @@ int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
   c->prof.grid_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b.t0).count();
   G.g = b.g;
   G.usable = G.n_binned > 0 && G.max_pop <= kMaxCellPopulation;
+  static std::atomic<uint64_t> g_grid_serial{0};
+  G.serial = ++g_grid_serial;
   b.state = GridBuild::Done;
   return ICPGPU_OK;
 }
@@ -706,15 +719,17 @@ bool source_ordered(const icpgpu_ctx* c) {
 // Brute-force keys of every source point against tgt_pts (exact NN).  Large problems go to the matrix
 // cores (icp_brute_mfma.hip: an MFMA lower bound settles all but a handful of pairs, those are evaluated exactly); that
 // kernel wants its sources as neighbours in space, so the source is binned with the grid machinery first (cached per source
-// cloud; promote_source_to_target hands the same structure on as the next target's grid).  brute_variant: 0 = this choice,
-// 1 = the plain-VALU kernel whatever the size (A/B measurements; ICPGPU_NN_VARIANT picks among its variants).
+// cloud; promote_source_to_target hands the same structure on as the next target's grid) and then put in Morton order of its
+// cells.  brute_variant: 0 = this choice (the bound on the bf16 matrix path, icp_brute_bf16.hip), 2 = the bound in f32 MFMAs
+// (icp_brute_mfma.hip, round 2's kernel), 1 = the plain-VALU kernel whatever the size (A/B measurements; ICPGPU_NN_VARIANT
+// picks among its variants).  All three return the same keys, bit for bit.
 constexpr int kMfmaMinPoints = 8192;
 
 int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T, unsigned long long* keys, bool* used_mfma = nullptr) {
   const int n_s = (int)c->src.n;
   if (used_mfma) *used_mfma = false;
   if (n_s <= 0) return ICPGPU_OK;
-  if (c->params.brute_variant == 0 && c->nn_variant < 0 && n_s >= kMfmaMinPoints && n_t >= kMfmaMinPoints) {
+  if (c->params.brute_variant != 1 && c->nn_variant < 0 && n_s >= kMfmaMinPoints && n_t >= kMfmaMinPoints) {
     double cut = c->params.max_correspondence_distance;
     if (!(cut > 1e-3) || !std::isfinite(cut) || cut > 1e6) cut = 1.0;
     const float thr = threshold_from(cut * cut);
@@ -728,9 +743,44 @@ int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T,
                           S.n_s == n_s && S.n_t == n_t;
       if ((rc = ensure(c, S.keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
       HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
-      HIP_TRY(c, launch_nn_brute_mfma(static_cast<const float4*>(c->src_grid.sorted.ptr), c->src_grid.n_binned, tgt_pts, n_t, T,
-                                      c->num_cus, keys, seeded ? static_cast<const unsigned long long*>(S.keys.ptr) : nullptr,
-                                      c->stream));
+      const unsigned long long* seed_keys = seeded ? static_cast<const unsigned long long*>(S.keys.ptr) : nullptr;
+      if (c->params.brute_variant == 2) {
+        HIP_TRY(c, launch_nn_brute_mfma(static_cast<const float4*>(c->src_grid.sorted.ptr), c->src_grid.n_binned, tgt_pts, n_t, T,
+                                        c->num_cus, keys, seed_keys, c->stream));
+      } else {
+        BruteOrder& O = c->brute_order;
+        const int n_b = c->src_grid.n_binned;
+        if (!O.valid || O.grid_serial != c->src_grid.serial || O.n != n_b) {
+          if ((rc = ensure(c, O.pts, (size_t)n_b * sizeof(float4)))) return rc;
+          if ((rc = ensure(c, O.work, morton_order_work_ints(n_b) * sizeof(int)))) return rc;
+          HIP_TRY(c, launch_morton_order(static_cast<const float4*>(c->src_grid.sorted.ptr), n_b, c->src_grid.g,
+                                         static_cast<int*>(O.work.ptr), static_cast<float4*>(O.pts.ptr), c->stream));
+          O.valid = true;
+          O.grid_serial = c->src_grid.serial;
+          O.n = n_b;
+        }
+        // test mode (ICPGPU_MFMA_CHECK_BOUND=1, read per call): every pair evaluated exactly against its bound; the counters
+        // land in the profile (brute_bound_violations must stay 0)
+        const char* chk = getenv("ICPGPU_MFMA_CHECK_BOUND");
+        unsigned long long* d_check = nullptr;
+        if (chk && atoi(chk)) {
+          if ((rc = ensure(c, O.check, 2 * sizeof(unsigned long long)))) return rc;
+          d_check = static_cast<unsigned long long*>(O.check.ptr);
+          HIP_TRY(c, hipMemsetAsync(d_check, 0, 2 * sizeof(unsigned long long), c->stream));
+        }
+        HIP_TRY(c, launch_nn_brute_bf16(static_cast<const float4*>(O.pts.ptr), n_b, tgt_pts, n_t, T, c->num_cus, keys, seed_keys,
+                                        d_check, c->stream));
+        if (d_check) {
+          unsigned long long h[2] = {0, 0};
+          HIP_TRY(c, hipMemcpyAsync(h, d_check, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+          c->prof.brute_bound_violations += h[0];
+          float worst;
+          const unsigned int bits = (unsigned int)h[1];
+          std::memcpy(&worst, &bits, 4);
+          if ((double)worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = worst;
+        }
+      }
       HIP_TRY(c, hipMemcpyAsync(S.keys.ptr, keys, (size_t)n_s * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
       S.valid = true;
       S.src_version = c->src_version;
@@ -1784,6 +1834,9 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->idx);
   release(c->d2);
   release(c->brute_seed.keys);
+  release(c->brute_order.pts);
+  release(c->brute_order.work);
+  release(c->brute_order.check);
   release(c->fp_acc);
   release(c->batch_table);
   release(c->map.node_keys);
@@ -1823,7 +1876,7 @@ int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* p) {
   if (!c || !p) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   if (p->method != ICPGPU_P2P_SVD && p->method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad method");
   if (p->nn_mode < ICPGPU_NN_AUTO || p->nn_mode > ICPGPU_NN_GRID) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad nn_mode");
-  if (p->brute_variant < 0 || p->brute_variant > 1) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad brute_variant");
+  if (p->brute_variant < 0 || p->brute_variant > 2) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad brute_variant");
   c->params = *p;
   return ICPGPU_OK;
 }
@@ -2523,6 +2576,8 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;
     c->prof.gicp_eval_ms += p.gicp_eval_ms; c->prof.gicp_eval_corr += p.gicp_eval_corr; c->prof.gicp_cov_points += p.gicp_cov_points;
     c->prof.targets_recognised += p.targets_recognised;
+    c->prof.brute_bound_violations += p.brute_bound_violations;
+    if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;
     std::memset(&p, 0, sizeof(p));
   }
   for (const ThreadError& e : errors)  // the first failure in thread order (each thread stops at its first)

@@ -82,7 +82,8 @@ typedef struct {
   int32_t min_correspondences;        /* PCL default 3 (P2P) / 4 (GICP) */
   int32_t force_iterations;           /* != 0: run exactly max_iterations (benchmarking; no PCL equivalent) */
   int32_t nn_mode;                    /* icpgpu_nn_mode */
-  int32_t brute_variant;              /* brute-force search: 0 = matrix-core kernel for large clouds (default), 1 = plain-VALU kernel always */
+  int32_t brute_variant;              /* brute-force search: 0 = matrix-core kernel for large clouds (default: lower bound on the bf16
+                                       * matrix path), 1 = plain-VALU kernel always, 2 = the bound in f32 MFMAs; identical results */
 } icpgpu_params;
 
 typedef struct {
@@ -141,6 +142,8 @@ typedef struct {
   uint64_t gicp_eval_corr;    /* correspondences those evaluations reduced over, summed (88 algorithmic bytes each) */
   uint64_t gicp_cov_points;   /* points whose covariances the gicp_cov passes computed (16 B read + 48 B written each, + the 20-NN search) */
   uint64_t targets_recognised; /* icpgpu_set_target calls that found the cloud already in HBM (no upload, no rebuild) */
+  uint64_t brute_bound_violations; /* test mode ICPGPU_MFMA_CHECK_BOUND=1 of the bf16 matrix-core search: pairs whose lower bound */
+  double brute_bound_worst;        /*   exceeded what their own exact distance allows (must stay 0); worst excess / (P^2 + |v|^2) seen */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

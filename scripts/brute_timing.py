@@ -1,5 +1,5 @@
-"""Dev tool: brute-force sweep time, matrix-core kernel (brute_variant 0; unseeded first sweep / seeded later sweeps) vs
-plain-VALU kernel (1)."""
+"""Dev tool: brute-force sweep time, the matrix-core kernels (brute_variant 0: bound on the bf16 path, 2: bound in f32 MFMAs;
+unseeded first sweep / seeded later sweeps) vs the plain-VALU kernel (1).  BRUTE_VARIANTS=0,2 restricts the list."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icpslam_amd import Context, synth, NN_BRUTE
@@ -9,7 +9,9 @@ for size in (sys.argv[1:] or ["200000x200000"]):
     with Context(0) as ctx:
         ctx.profile_sampling(1)
         res = {}
-        for v, label in ((0, "matrix cores"), (1, "plain VALU")):
+        labels = {0: "matrix cores (bf16 bound)", 2: "matrix cores (f32 bound)", 1: "plain VALU"}
+        wanted = [int(x) for x in os.environ.get("BRUTE_VARIANTS", "0,2,1").split(",")]
+        for v, label in ((v, labels[v]) for v in wanted):
             t = {}
             for iters in (1, 4):
                 tot = 0.0
@@ -29,4 +31,5 @@ for size in (sys.argv[1:] or ["200000x200000"]):
             tf = lambda ms: 8.0 * ns * nt / (ms * 1e-3) / 1e12
             print(f"{size} {label}: first sweep {first:.3f} ms = {tf(first):.1f} TFLOP/s ({tf(first)/1.573:.1f} %), later sweeps "
                   f"{later:.3f} ms = {tf(later):.1f} TFLOP/s ({tf(later)/1.573:.1f} % of the f32 peak)", flush=True)
-        print("  same result:", res[0]["n_corr"] == res[1]["n_corr"] and (res[0]["T"] == res[1]["T"]).all())
+        first = res[wanted[0]]
+        print("  same result:", all(r["n_corr"] == first["n_corr"] and (r["T"] == first["T"]).all() for r in res.values()))
