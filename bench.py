@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA (32x32x16: 32768 flop per 32 cycles and SIMD)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak (packed FMA) == FP32 (f32-in) MFMA dense peak
 N_SIMDS = 256 * 4          # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md "Wave scheduling")
 CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: peak engine clock
@@ -459,8 +460,8 @@ def main():
     if rank == 0 and not a.no_extras and not batch:
         ctx.profile_sampling(1)                    # a handful of launches: time every one of them
         brute = {}
-        for name, variant in (("mfma", 0), ("valu", 1)):
-            ctx.set_params(nn_mode=NN_BRUTE, max_iterations=2, brute_variant=variant)
+        for name, variant in (("mfma", 0), ("mfma_f32", 2), ("valu", 1)):
+            ctx.set_params(nn_mode=NN_BRUTE, max_iterations=a.iters, brute_variant=variant)   # (forced: a whole alignment's sweeps)
             ctx.align()
             ctx.profile_reset()
             ctx.align()
@@ -487,11 +488,29 @@ def main():
                                 "algorithmic_bytes_per_launch": alg_bytes_keys}, "note": note}
             small = min(n_s, n_t) < 8192
             brute_roofline = brute_entry(
-                "nn_brute_kernel (plain VALU; below 8192 points the matrix-core kernel is not used)" if small else
-                "nn_brute_mfma_kernel (LDS-tiled brute force on the matrix cores: f32 MFMA lower bound + exact re-check)",
+                "nn_brute_kernel (plain VALU; below 8192 points the matrix-core kernels are not used)" if small else
+                "nn_brute_bf16_kernel (LDS-tiled brute force: certified lower bound of every distance from ONE bf16 MFMA "
+                "(K = 16, split operands) per 32 x 32 pairs + exact re-check of the few pairs it cannot settle)",
                 brute["mfma"]["avg_launch_ms"],
-                "flops = 8*Ns*Nt per launch (SURVEY.md 8(d) convention: 3 sub + 1 mul + 2 fma per pair); peak = f32 dense MFMA "
-                "peak = packed-f32 vector peak (157.3 TFLOP/s); sweeps seeded with the previous sweep's neighbours")
+                "`achieved` / `frac` = USEFUL flops by SURVEY.md 8(d)'s convention (8*Ns*Nt per launch: 3 sub + 1 mul + 2 fma per "
+                "pair) against the f32 peak the convention is priced at (157.3 TFLOP/s = f32 MFMA = packed-f32 vector peak): above "
+                "1 because the bound is computed on the bf16 matrix path, not in f32 -- `matrix_path` prices what the kernel "
+                "actually issues against THAT peak; the launches timed are the sweeps of one whole alignment: the first unseeded, the "
+                f"other {a.iters - 1} seeded with the previous sweep's neighbours")
+            if not small:
+                ms_b = brute["mfma"]["avg_launch_ms"]
+                issued = 32.0 * n_s * n_t / (ms_b * 1e-3) / 1e12       # one 32x32x16 MFMA (32768 flop) per 1024 pairs
+                brute_roofline["matrix_path"] = {
+                    "bound": "mfma", "achieved": issued, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16, issued)",
+                    "frac": issued / BF16_PEAK_TFLOPS,
+                    "note": "one v_mfma_f32_32x32x16_bf16 per 1024 pairs = 32 issued flop per pair (14 of the 16 K slots used); "
+                            "the kernel is bound by the vector folds of the MFMA's outputs (16 v_min3_f32 + 2 compares per 2048 "
+                            "pairs and wave: profiles/r03_brute_force_bf16.txt, r03_mfma_coissue.txt), not by the matrix pipe"}
+                brute_roofline["f32_mfma_kernel"] = brute_entry(
+                    "nn_brute_mfma_kernel (the same search with the bound in two f32 MFMAs per 32 x 32 pairs: round 2's kernel, "
+                    "brute_variant 2)", brute["mfma_f32"]["avg_launch_ms"],
+                    "f32 MFMAs and vector instructions of one SIMD do not overlap on gfx950 (profiles/r03_mfma_coissue.txt): "
+                    "128 MFMA cycles + ~52 vector cycles per 1024 pairs cap this kernel at ~71 % of the f32 peak")
             brute_roofline["traffic"] = traffic.get("nn_brute_hbm_bytes_per_launch")
             brute_roofline["valu_kernel"] = brute_entry(
                 "nn_brute_kernel<0,4> (plain VALU, 7 instructions per pair)", brute["valu"]["avg_launch_ms"],

@@ -217,10 +217,11 @@ __device__ __forceinline__ void nn_brute_bf16_body(const float4* __restrict__ sr
     }
     const int lim = min(TILE, j1 - jt);
     const uint4* __restrict__ arow = aop + half * TILE + col;
+    float minus_inf;  // (opaque to the compiler: a literal -inf makes it rewrite the v_med3 below as a canonicalising minimum)
+    asm volatile("v_mov_b32 %0, 0xff800000" : "=v"(minus_inf));
 
     // One step = 32 targets against the wave's 32 G sources: G MFMAs, then the fold of their 16 G values per lane.
-    auto issue = [&](floatx16 (&acc)[G], int st) {
-      const uint4 a = arow[st];  // lane supplies A[m = col][k = 8 half .. 8 half + 7]
+    auto issue = [&](floatx16 (&acc)[G], const uint4& a) {  // a: this lane's A[m = col][k = 8 half .. 8 half + 7] of the step
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -231,12 +232,14 @@ __device__ __forceinline__ void nn_brute_bf16_body(const float4* __restrict__ sr
       // The folds are v_min3_f32 by hand (fminf on MFMA outputs makes the compiler canonicalise every operand first).  Inline
       // assembly is opaque to the compiler's hazard recogniser, which is what inserts the wait states between an MFMA and the
       // first vector read of its result -- so every accumulator is first read by an instruction the compiler CAN see (it
-      // waits there), and nothing may be scheduled across.
+      // waits there), and nothing may be scheduled across.  That instruction does a fold's work too: v_med3_f32(a, b, -inf)
+      // = min(a, b); with a NaN among its operands the hardware returns their min3 = -inf, i.e. the step of a non-finite
+      // target goes through the exact path (where its NaN / inf distance never wins) instead of being dropped -- correct, and
+      // rare.
       __builtin_amdgcn_sched_barrier(0);
-      int touched = 0;
+      float tail[G];
 #pragma unroll
-      for (int g = 0; g < G; ++g) touched |= __builtin_amdgcn_readfirstlane(__float_as_int(acc[g][15]));
-      asm volatile("" ::"s"(touched));
+      for (int g = 0; g < G; ++g) tail[g] = __builtin_amdgcn_fmed3f(acc[g][14], acc[g][15], minus_inf);
       __builtin_amdgcn_sched_barrier(0);
       // d[v]: target row 8 * (v / 4) + 4 * half + (v % 4) of this step, source column col.  A NaN (a non-finite point) is
       // dropped by the minimum and fails the comparison below.
@@ -246,7 +249,7 @@ __device__ __forceinline__ void nn_brute_bf16_body(const float4* __restrict__ sr
       for (int g = 0; g < G; ++g) {
         const floatx16 d = acc[g];
         mn[g] = min3f(min3f(min3f(d[0], d[1], d[2]), min3f(d[3], d[4], d[5]), min3f(d[6], d[7], d[8])),
-                      min3f(d[9], d[10], d[11]), min3f(min3f(d[12], d[13], d[14]), d[15], d[15]));
+                      min3f(d[9], d[10], d[11]), min3f(d[12], d[13], tail[g]));
         hit |= mn[g] <= bound[g];
       }
       if (CHECK) {  // (test mode: its own instantiation) every pair exactly: does its bound allow what its own distance would need?
@@ -298,10 +301,19 @@ __device__ __forceinline__ void nn_brute_bf16_body(const float4* __restrict__ sr
         }
       }
     };
-    for (int st = 0; st < lim; st += 32) {
+    // two steps per trip; the A operands of a step are read from LDS one step ahead (the read's latency passes under the
+    // fold before it instead of in front of the MFMAs); rows up to the end of the tile always hold valid records
+    uint4 a0 = arow[0];
+    for (int st = 0; st < lim; st += 64) {
       floatx16 acc[G];
-      issue(acc, st);
+      const uint4 a1 = arow[st + 32];
+      issue(acc, a0);
       fold(acc, st);
+      a0 = arow[(st + 64) & (TILE - 1)];
+      if (st + 32 < lim) {
+        issue(acc, a1);
+        fold(acc, st + 32);
+      }
     }
   }
 

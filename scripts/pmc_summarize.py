@@ -6,7 +6,7 @@ import csv, glob, json, os, sys
 
 root, size = sys.argv[1], sys.argv[2]
 KEY = "x".join(f"{int(v) // 1000}k" for v in size.split("x"))  # bench.py workload name, e.g. 200kx200k
-KERNELS = {"grid": "nn_quad_kernel<false, true, false", "brute": "nn_brute_mfma_kernel"}  # 200k: the quad kernel; brute: the matrix-core kernel
+KERNELS = {"grid": "nn_quad_kernel<false, true, false", "brute": "nn_brute_bf16_kernel"}  # 200k: the quad kernel; brute: the matrix-core kernel (bf16 bound)
 
 
 def per_launch(mode, ctr):

@@ -70,6 +70,49 @@ __global__ __launch_bounds__(512) void probe_split(float* out, int trips, int ro
   if (s == 123.456f) out[threadIdx.x] = s;
 }
 
+// the search kernel's step in miniature: two bf16 MFMAs from zero, then 16 v_min3_f32 folding THEIR results (DEP = 1) or
+// other registers (DEP = 0), optionally one step behind (PIPE = 1: this step's folds read the other accumulator pair)
+template <int DEP, int PIPE>
+__global__ __launch_bounds__(256) void probe_step(float* out, int trips) {
+  floatx16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int k = 0; k < 16; ++k) acc[i][k] = (float)(threadIdx.x + k);
+  floatx16 other[2];
+  for (int i = 0; i < 2; ++i)
+    for (int k = 0; k < 16; ++k) other[i][k] = (float)(threadIdx.x * 3 + k);
+  shortx8 ha, hb;
+  for (int k = 0; k < 8; ++k) { ha[k] = (short)threadIdx.x; hb[k] = (short)k; }
+  float m0 = 0.f, m1 = 0.f;
+#define FOLD(A, B)                                                                                                            \
+  asm volatile("v_min3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %5, %6, %7\n\tv_min3_f32 %0, %0, %8, %9\n\tv_min3_f32 %1, %1, %10, %11\n\t"   \
+               "v_min3_f32 %0, %0, %12, %13\n\tv_min3_f32 %1, %1, %14, %15\n\tv_min3_f32 %0, %0, %16, %17\n\tv_min3_f32 %0, %0, %1, %0" \
+               : "+v"(m0), "+v"(m1)                                                                                            \
+               : "v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(A[6]), "v"(A[7]), "v"(A[8]), "v"(A[9]),   \
+                 "v"(A[10]), "v"(A[11]), "v"(A[12]), "v"(A[13]), "v"(A[14]), "v"(A[15]));                                       \
+  asm volatile("v_min3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %5, %6, %7\n\tv_min3_f32 %0, %0, %8, %9\n\tv_min3_f32 %1, %1, %10, %11\n\t"   \
+               "v_min3_f32 %0, %0, %12, %13\n\tv_min3_f32 %1, %1, %14, %15\n\tv_min3_f32 %0, %0, %16, %17\n\tv_min3_f32 %0, %0, %1, %0" \
+               : "+v"(m0), "+v"(m1)                                                                                            \
+               : "v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(B[3]), "v"(B[4]), "v"(B[5]), "v"(B[6]), "v"(B[7]), "v"(B[8]), "v"(B[9]),   \
+                 "v"(B[10]), "v"(B[11]), "v"(B[12]), "v"(B[13]), "v"(B[14]), "v"(B[15]));
+  for (int t = 0; t < trips; ++t) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %3, 0" : "=v"(acc[0]), "=v"(acc[1]) : "v"(ha), "v"(hb));
+    if (PIPE) {
+      FOLD(acc[2], acc[3])
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %3, 0" : "=v"(acc[2]), "=v"(acc[3]) : "v"(ha), "v"(hb));
+      asm volatile("s_nop 10");
+      FOLD(acc[0], acc[1])
+    } else if (DEP) {
+      asm volatile("s_nop 10");
+      FOLD(acc[0], acc[1])
+    } else {
+      FOLD(other[0], other[1])
+    }
+  }
+  float s = m0 + m1;
+  for (int i = 0; i < 4; ++i) s += acc[i][3];
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
 static float* g_buf;
 static int g_cus;
 
@@ -132,6 +175,14 @@ int main() {
   run<2, 16, 0>("4 x mfma bf16 + 16 x v_fma_f32");
   run<2, 32, 0>("4 x mfma bf16 + 32 x v_fma_f32");
   run<2, 32, 1>("4 x mfma bf16 + 32 x v_min3_f32");
+  printf("# the search kernel's step: 2 bf16 MFMAs from zero + 16 v_min3_f32 per trip (PIPE: 4 + 32 per trip)\n");
+  for (int w = 1; w <= 8; w *= 2) {
+    const double a = time_ms([&] { hipLaunchKernelGGL((probe_step<0, 0>), dim3(g_cus * w), dim3(256), 0, 0, g_buf, kTrips); });
+    const double b = time_ms([&] { hipLaunchKernelGGL((probe_step<1, 0>), dim3(g_cus * w), dim3(256), 0, 0, g_buf, kTrips); });
+    const double c = time_ms([&] { hipLaunchKernelGGL((probe_step<1, 1>), dim3(g_cus * w), dim3(256), 0, 0, g_buf, kTrips); });
+    printf("waves/SIMD %d: folds of other registers %6.1f ns per step and SIMD | folds of the MFMAs' results %6.1f | the same one step behind %6.1f\n", w,
+           a * 1e6 / (kTrips * (double)w), b * 1e6 / (kTrips * (double)w), c * 1e6 / (2.0 * kTrips * (double)w));
+  }
   printf("# separate waves of the same SIMD: one runs 4 MFMAs per trip, the other V vector instructions per trip\n");
   run_split<32, 0>("4 x mfma f32 | 32 x v_fma_f32");
   run_split<64, 0>("4 x mfma f32 | 64 x v_fma_f32");

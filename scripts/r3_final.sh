@@ -7,7 +7,7 @@ python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; head -c 400
 export TMPDIR=/tmp
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof.log 2>&1)
 for f in $O/prof/*/*kernel_stats.csv; do  # the bench process's own file (it spawns the C++ pipeline harness, traced too)
-  grep -q "nn_quad_kernel<false, true" $f && grep -q nn_brute_mfma_kernel $f && cp $f $O/kernel_stats.csv
+  grep -q "nn_quad_kernel<false, true" $f && grep -q nn_brute_bf16_kernel $f && cp $f $O/kernel_stats.csv
   grep -q "nn_quad_kernel<false, true" $f || cp $f $O/kernel_stats_shim_pipeline.csv
 done
 bash scripts/pmc_issue.sh $TAG/issue 200000x200000 50000x50000 > $O/issue.log 2>&1; tail -3 $O/issue.log
