@@ -59,6 +59,13 @@ hipError_t launch_nn_brute_bf16(const float4* src_morton, int n_q, const float4*
                                 unsigned long long* keys, const unsigned long long* seed, unsigned long long* check,
                                 hipStream_t stream);
 
+// The grid search on the matrix cores (icp_tile.hip): keys[orig source index] = exact NN within sqrt(thr) (else left empty:
+// pre-fill with kEmptyKey), found by offering every workgroup of 256 Morton-ordered sources the target points of the grid cells
+// their search balls touch, through the bf16 lower-bound filter.  seed (nullable): the previous sweep's keys.
+hipError_t launch_nn_tile_search(const float4* src_morton, int n_q, const Xform& T, const float4* sorted, const int* cell_start,
+                                 const GridDesc& g, const float4* tgt, int n_t, float thr, const unsigned long long* seed,
+                                 unsigned long long* keys, unsigned long long* stats, hipStream_t stream);
+
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
                          float d2_threshold, double* partials, double* sums_out, unsigned long long* flags,
                          unsigned long long seq, hipStream_t stream);

@@ -90,6 +90,14 @@ struct BruteOrder {
   int n = 0;
 };
 
+// Keys of the last tile-search sweep (icp_tile.hip) of this alignment: every source's neighbour, a radius for the next sweep.
+struct TileSeed {
+  DeviceBuf keys, stats;
+  bool valid = false;
+  uint64_t src_version = 0, grid_version = 0;
+  int n_s = 0;
+};
+
 struct BruteSeed {
   DeviceBuf keys;
   bool valid = false;
@@ -158,7 +166,8 @@ struct icpgpu_ctx {
   GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
   PrevNeighbours prev;       // last sweep's neighbours (search bound of the next sweep)
   BruteSeed brute_seed;      // the same for the matrix-core brute-force kernels
-  BruteOrder brute_order;    // the source in Morton order (bf16 matrix-core kernel)
+  BruteOrder brute_order;    // the source in Morton order (bf16 matrix-core kernels)
+  TileSeed tile_seed;        // the previous sweep's keys (matrix-core grid search)
   VoxelMap map;              // the mapper's map
   uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
   // content fingerprints of the clouds in HBM (icpgpu_set_target's recognition of a cloud it already holds), computed on
@@ -725,6 +734,22 @@ bool source_ordered(const icpgpu_ctx* c) {
 // picks among its variants).  All three return the same keys, bit for bit.
 constexpr int kMfmaMinPoints = 8192;
 
+// c->brute_order.pts = the source's cell-ordered copy (c->src_grid, built and usable) in Morton order of its cells
+int source_in_morton_order(icpgpu_ctx* c) {
+  BruteOrder& O = c->brute_order;
+  const int n_b = c->src_grid.n_binned;
+  if (O.valid && O.grid_serial == c->src_grid.serial && O.n == n_b) return ICPGPU_OK;
+  int rc;
+  if ((rc = ensure(c, O.pts, (size_t)n_b * sizeof(float4)))) return rc;
+  if ((rc = ensure(c, O.work, morton_order_work_ints(n_b) * sizeof(int)))) return rc;
+  HIP_TRY(c, launch_morton_order(static_cast<const float4*>(c->src_grid.sorted.ptr), n_b, c->src_grid.g,
+                                 static_cast<int*>(O.work.ptr), static_cast<float4*>(O.pts.ptr), c->stream));
+  O.valid = true;
+  O.grid_serial = c->src_grid.serial;
+  O.n = n_b;
+  return ICPGPU_OK;
+}
+
 int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T, unsigned long long* keys, bool* used_mfma = nullptr) {
   const int n_s = (int)c->src.n;
   if (used_mfma) *used_mfma = false;
@@ -750,15 +775,7 @@ int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T,
       } else {
         BruteOrder& O = c->brute_order;
         const int n_b = c->src_grid.n_binned;
-        if (!O.valid || O.grid_serial != c->src_grid.serial || O.n != n_b) {
-          if ((rc = ensure(c, O.pts, (size_t)n_b * sizeof(float4)))) return rc;
-          if ((rc = ensure(c, O.work, morton_order_work_ints(n_b) * sizeof(int)))) return rc;
-          HIP_TRY(c, launch_morton_order(static_cast<const float4*>(c->src_grid.sorted.ptr), n_b, c->src_grid.g,
-                                         static_cast<int*>(O.work.ptr), static_cast<float4*>(O.pts.ptr), c->stream));
-          O.valid = true;
-          O.grid_serial = c->src_grid.serial;
-          O.n = n_b;
-        }
+        if ((rc = source_in_morton_order(c))) return rc;
         // test mode (ICPGPU_MFMA_CHECK_BOUND=1, read per call): every pair evaluated exactly against its bound; the counters
         // land in the profile (brute_bound_violations must stay 0)
         const char* chk = getenv("ICPGPU_MFMA_CHECK_BOUND");
@@ -927,7 +944,48 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
   const float4* red_src = nullptr;
   int red_n = 0;
   volatile int* few_host = nullptr;
-  if (use_grid && !open_range) {
+  // EXPERIMENTAL (off by default, read per sweep so that a test can switch it): the grid search on the matrix cores,
+  // icp_tile.hip -- bit-identical results, faster at 50k x 50k, slower at 200k x 200k (experiments)
+  const char* tile_env = std::getenv("ICPGPU_TILE_SEARCH");
+  const int tile_search = tile_env ? std::atoi(tile_env) : 0;
+  if (use_grid && !open_range && tile_search && source_ordered(c) && n_s >= kMfmaMinPoints) {
+    // the grid search on the matrix cores (icp_tile.hip): keys, then the keys-path reduction
+    if ((rc = source_in_morton_order(c))) return rc;
+    TileSeed& S = c->tile_seed;
+    const bool seeded = S.valid && S.src_version == c->src_version && S.grid_version == c->grid.version && S.n_s == n_s;
+    if ((rc = ensure(c, S.keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+    unsigned long long* d_stats = nullptr;
+    if (tile_search > 1) {
+      if ((rc = ensure(c, S.stats, 8 * sizeof(unsigned long long)))) return rc;
+      d_stats = static_cast<unsigned long long*>(S.stats.ptr);
+      HIP_TRY(c, hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long), c->stream));
+    }
+    HIP_TRY(c, launch_fill_keys(keys, n_s, c->stream));
+    HIP_TRY(c, launch_nn_tile_search(static_cast<const float4*>(c->brute_order.pts.ptr), c->brute_order.n, T,
+                                     static_cast<const float4*>(c->grid.sorted.ptr), static_cast<const int*>(c->grid.cell_start.ptr),
+                                     c->grid.g, c->tgt.data(), n_t, thr,
+                                     seeded ? static_cast<const unsigned long long*>(S.keys.ptr) : nullptr, keys, d_stats, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S.keys.ptr, keys, (size_t)n_s * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    S.valid = true;
+    S.src_version = c->src_version;
+    S.grid_version = c->grid.version;
+    S.n_s = n_s;
+    if (d_stats) {
+      unsigned long long h[8] = {0};
+      HIP_TRY(c, hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      const double nb = (double)(h[5] ? h[5] : 1);
+      fprintf(stderr, "[icpgpu] tile search (%s): %.3f G pairs, %.0f workgroups, %.0f candidates each; cycles per workgroup: preamble %.0f, "
+                      "rows %.0f, tile fills %.0f, steps %.0f; slowest workgroup %.0f\n", seeded ? "seeded" : "cold", (double)h[0] * 1e-9, nb,
+              (double)h[6] / nb, (double)h[1] / nb, (double)h[2] / nb, (double)h[3] / nb, (double)h[4] / nb, (double)h[7]);
+    }
+    EVREC(ev[1]);
+    red_src = c->src.data();
+    red_n = n_s;
+    if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
+    partials = static_cast<double*>(c->partials.ptr);
+    HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
+  } else if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
     const bool ordered = source_ordered(c);
     const float4* src_pts = ordered ? static_cast<const float4*>(c->src_grid.sorted.ptr) : c->src.data();
@@ -1203,7 +1261,7 @@ int p2p_prepare(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, i
     if (rc) return rc;
     c->dev_ms_accum = 0.0;
     c->call_sweeps = c->call_timed = 0;
-    c->prev.valid = false;  // every alignment starts cold
+    c->prev.valid = c->tile_seed.valid = false;  // every alignment starts cold
   }
   if (guess)
     for (int i = 0; i < 16; ++i) r.final_T[i] = (double)guess[i];
@@ -1462,7 +1520,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   c->prof.aligns += 1;
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   const icpgpu_params& P = c->params;
-  c->prev.valid = false;  // every alignment starts cold
+  c->prev.valid = c->tile_seed.valid = false;  // every alignment starts cold
   float guess[16];
   if (guess_in) std::memcpy(guess, guess_in, sizeof(guess));
   else mat4f_identity(guess);
@@ -1837,6 +1895,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->brute_order.pts);
   release(c->brute_order.work);
   release(c->brute_order.check);
+  release(c->tile_seed.keys);
+  release(c->tile_seed.stats);
   release(c->fp_acc);
   release(c->batch_table);
   release(c->map.node_keys);
@@ -2303,7 +2363,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
           bool use_prev = false;
           if (!rc) rc = prev_neighbours(w, w->grid, w->src.data(), n_s, flags, sl.prev, use_prev);  // (allocates; the first sweep is cold)
           if (rc) return failed(rc, sl.pair, w);
-          w->prev.valid = false;
+          w->prev.valid = w->tile_seed.valid = false;
           sl.pack = (flags & kGridPackShortRows) != 0;
           if (!rc) rc = ensure(w, w->keys, (size_t)n_s * sizeof(unsigned long long));
           if (!rc) rc = ensure(w, w->grid.unmatched, (size_t)(n_s + 1) * sizeof(int));
