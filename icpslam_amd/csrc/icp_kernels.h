@@ -64,7 +64,8 @@ hipError_t launch_nn_brute_bf16(const float4* src_morton, int n_q, const float4*
 // their search balls touch, through the bf16 lower-bound filter.  seed (nullable): the previous sweep's keys.
 hipError_t launch_nn_tile_search(const float4* src_morton, int n_q, const Xform& T, const float4* sorted, const int* cell_start,
                                  const GridDesc& g, const float4* tgt, int n_t, float thr, const unsigned long long* seed,
-                                 unsigned long long* keys, unsigned long long* stats, hipStream_t stream);
+                                 float4* prev, bool use_prev, unsigned long long* keys, unsigned long long* stats,
+                                 hipStream_t stream);
 
 hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, const Xform& T,
                          float d2_threshold, double* partials, double* sums_out, unsigned long long* flags,

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
                                                            const int* __restrict__ cell_start, GridDesc g,
                                                            const float4* __restrict__ tgt, int n_t, float thr,
                                                            const unsigned long long* __restrict__ seed,
+                                                           float4* __restrict__ prev, int use_prev,
                                                            unsigned long long* __restrict__ keys, int splits,
                                                            unsigned long long* __restrict__ stats) {
   constexpr int G = TS_G, TILE = TS_TILE, BLOCK = TS_BLOCK;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
   unsigned long long tk0 = stats ? __builtin_amdgcn_s_memtime() : 0ull, t_pre = 0, t_rows = 0, t_fill = 0, t_steps = 0;
 
   // ---- the workgroup's sources, their radii, the box of their balls ---------------------------------------------------------
-  float px[G], py[G], pz[G], r2[G];
+  float px[G], py[G], pz[G], r2[G], bqx[G], bqy[G], bqz[G];
   int orig[G];
   bool valid[G];
   unsigned long long best[G];
@@ -104,8 +105,19 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
     orig[gi] = __float_as_int(s.w);
     valid[gi] = k < n_q && finite3(px[gi], py[gi], pz[gi]);
     best[gi] = kEmptyKey;
+    bqx[gi] = bqy[gi] = bqz[gi] = __builtin_nanf("");
     r2[gi] = thr;  // a neighbour beyond the acceptance threshold is rejected anyway
-    if (seed && valid[gi]) {
+    if ((use_prev & 1) && valid[gi]) {
+      // (one split per group) the neighbour of the previous sweep as a POINT, stored at the source's Morton position: one
+      // coalesced read instead of the key's two dependent gathers; .w = its original target index
+      const float4 t = prev[min(k, n_q - 1)];
+      const float e = dist2(t.x, t.y, t.z, px[gi], py[gi], pz[gi]);
+      if (e <= thr) {
+        best[gi] = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(t.w);
+        r2[gi] = e;
+        bqx[gi] = t.x; bqy[gi] = t.y; bqz[gi] = t.z;
+      }
+    } else if (seed && valid[gi]) {
       const unsigned int j = (unsigned int)seed[orig[gi]];
       if (j < (unsigned int)n_t) {
         const float4 t = tgt[j];
@@ -113,6 +125,7 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
         if (e <= thr) {  // the old neighbour is a target point: a candidate, and a ball the new neighbour lies in
           best[gi] = ((unsigned long long)__float_as_uint(e) << 32) | j;
           r2[gi] = e;
+          bqx[gi] = t.x; bqy[gi] = t.y; bqz[gi] = t.z;
         }
       }
     }
@@ -237,23 +250,36 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
     n_cand += (unsigned long long)(k1 - k0);
     if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_rows += t - tk0; tk0 = t; }
 
-    for (int kt = k0; kt < k1; kt += TILE) {
-      __syncthreads();  // seg_pref complete (first trip) / the previous tile is no longer read
-      const int lim = min(TILE, k1 - kt);
+    // the candidates of a tile are gathered one tile ahead (the binary search over the row list and the read of the sorted
+    // copy pass under the previous tile's steps); they wait in registers
+    float4 qn[TILE / BLOCK];
+    auto gather = [&](int kt) {
 #pragma unroll
       for (int u = 0; u < TILE / BLOCK; ++u) {
-        const int kk = u * BLOCK + threadIdx.x;
-        uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0x00007F80u, 0u);  // a row past the end: S = +inf
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kk < lim) {
-          const int k = kt + kk;
+        const int k = kt + u * BLOCK + (int)threadIdx.x;
+        qn[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < k1) {
           int a = 0, b = rows;  // the segment that holds candidate k: the last r with seg_pref[r] <= k
           while (b - a > 1) {
             const int m = (a + b) >> 1;
             if (seg_pref[m] <= k) a = m;
             else b = m;
           }
-          q = sorted[seg_start[a] + (k - seg_pref[a])];
+          qn[u] = sorted[seg_start[a] + (k - seg_pref[a])];
+        }
+      }
+    };
+    __syncthreads();  // seg_pref complete
+    if (k0 < k1) gather(k0);
+    for (int kt = k0; kt < k1; kt += TILE) {
+      __syncthreads();  // the previous tile is no longer read
+      const int lim = min(TILE, k1 - kt);
+#pragma unroll
+      for (int u = 0; u < TILE / BLOCK; ++u) {
+        const int kk = u * BLOCK + threadIdx.x;
+        uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = make_uint4(0u, 0u, 0x00007F80u, 0u);  // a row past the end: S = +inf
+        const float4 q = qn[u];
+        if (kk < lim) {
           const float vx = q.x - cx, vy = q.y - cy, vz = q.z - cz;
           const float q2 = __builtin_fmaf(vz, vz, __builtin_fmaf(vy, vy, vx * vx));
           const float scale = pmax2 + q2;
@@ -268,6 +294,7 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
         aop[TILE + kk] = r1;
       }
       __syncthreads();
+      if (kt + TILE < k1) gather(kt + TILE);
       if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_fill += t - tk0; tk0 = t; }
       const uint4* __restrict__ arow = aop + half * TILE + col;
       uint4 a0 = arow[0];
@@ -285,31 +312,41 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) tail[gi] = __builtin_amdgcn_fmed3f(acc[gi][14], acc[gi][15], minus_inf);
         __builtin_amdgcn_sched_barrier(0);
-        float mn[G];
+        // the fold keeps its five partial minima: they say which values to look at when the bound is undercut
+        float part[G][5], mn[G];
         bool hit = false;
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
           const floatx16 d = acc[gi];
-          mn[gi] = min3f(min3f(min3f(d[0], d[1], d[2]), min3f(d[3], d[4], d[5]), min3f(d[6], d[7], d[8])),
-                         min3f(d[9], d[10], d[11]), min3f(d[12], d[13], tail[gi]));
+          part[gi][0] = min3f(d[0], d[1], d[2]);
+          part[gi][1] = min3f(d[3], d[4], d[5]);
+          part[gi][2] = min3f(d[6], d[7], d[8]);
+          part[gi][3] = min3f(d[9], d[10], d[11]);
+          part[gi][4] = min3f(d[12], d[13], tail[gi]);
+          mn[gi] = min3f(min3f(part[gi][0], part[gi][1], part[gi][2]), part[gi][3], part[gi][4]);
           hit |= mn[gi] <= bound[gi];
         }
-        if (__ballot(hit)) {
+        if (!(use_prev & 2) && __ballot(hit)) {  // (bit 1: timing experiments only -- no exact path, wrong results)
 #pragma unroll
           for (int gi = 0; gi < G; ++gi) {
             if (!__ballot(mn[gi] <= bound[gi])) continue;
             const floatx16 d = acc[gi];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-              if (d[v] <= bound[gi]) {
-                const int row = 8 * (v >> 2) + 4 * half + (v & 3);
-                if (st + row < lim) {
-                  const float4 t = tile[st + row];
-                  const float e = dist2(t.x, t.y, t.z, px[gi], py[gi], pz[gi]);
-                  const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(t.w);
-                  if (e <= thr && key < best[gi]) {  // (NaN and inf distances fail the first test)
-                    best[gi] = key;
-                    bound[gi] = __builtin_fmaf(e + p2[gi], 9.5367431640625e-07f, e - p2[gi]);
+            for (int pt = 0; pt < 5; ++pt) {
+              if (!__ballot(part[gi][pt] <= bound[gi])) continue;
+#pragma unroll
+              for (int v = 3 * pt; v < (pt == 4 ? 16 : 3 * pt + 3); ++v) {
+                if (d[v] <= bound[gi]) {
+                  const int row = 8 * (v >> 2) + 4 * half + (v & 3);
+                  if (st + row < lim) {
+                    const float4 t = tile[st + row];
+                    const float e = dist2(t.x, t.y, t.z, px[gi], py[gi], pz[gi]);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(e) << 32) | __float_as_uint(t.w);
+                    if (e <= thr && key < best[gi]) {  // (NaN and inf distances fail the first test)
+                      best[gi] = key;
+                      bqx[gi] = t.x; bqy[gi] = t.y; bqz[gi] = t.z;
+                      bound[gi] = __builtin_fmaf(e + p2[gi], 9.5367431640625e-07f, e - p2[gi]);
+                    }
                   }
                 }
               }
@@ -338,6 +375,15 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
     const unsigned int olo = (unsigned int)__shfl_xor((int)(unsigned int)best[gi], 32, 64);
     const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
     const unsigned long long k = other < best[gi] ? other : best[gi];
+    if (prev && splits == 1) {  // the winner as a point, for the next sweep (the half that holds it writes)
+      const float ox = __shfl_xor(bqx[gi], 32, 64), oy = __shfl_xor(bqy[gi], 32, 64), oz = __shfl_xor(bqz[gi], 32, 64);
+      const bool mine = best[gi] <= other;
+      if (half == 0 && q0 + gi * 32 + col < n_q) {
+        const float none = __builtin_nanf("");
+        prev[q0 + gi * 32 + col] = k == kEmptyKey ? make_float4(none, none, none, 0.f)
+                                                   : make_float4(mine ? bqx[gi] : ox, mine ? bqy[gi] : oy, mine ? bqz[gi] : oz, __uint_as_float((unsigned int)k));
+      }
+    }
     if (half == 0 && q0 + gi * 32 + col < n_q && k != kEmptyKey) {
       if (splits > 1) atomicMin(&keys[orig[gi]], k);
       else keys[orig[gi]] = k;
@@ -351,17 +397,25 @@ __global__ __launch_bounds__(TS_BLOCK) void nn_tile_kernel(const float4* __restr
 // the grid's points when it lies within sqrt(thr), key = (d2 bits, original target index); empty otherwise.
 // src_morton: launch_morton_order's output (finite points, original index in .w).  tgt: the target in its original order (what
 // the seeds index).  seed (nullable): the keys of the previous sweep of the same source over the same target.
-// stats (nullable, 1 x u64, zeroed by the caller): pairs offered to the filter.
+// prev (nullable, n_q float4 at the sources' Morton positions; used with ONE split per group only): every sweep leaves the
+// neighbours it found there as points (.w = original target index), and with use_prev reads the previous sweep's instead of
+// the seed keys.  stats (nullable, 8 x u64, zeroed by the caller): pairs offered to the filter, cycles per phase.
 hipError_t launch_nn_tile_search(const float4* src_morton, int n_q, const Xform& T, const float4* sorted, const int* cell_start,
                                  const GridDesc& g, const float4* tgt, int n_t, float thr, const unsigned long long* seed,
-                                 unsigned long long* keys, unsigned long long* stats, hipStream_t stream) {
+                                 float4* prev, bool use_prev, unsigned long long* keys, unsigned long long* stats,
+                                 hipStream_t stream) {
   if (n_q <= 0 || n_t <= 0) return hipSuccess;
   static const int splits_env = [] { const char* e = getenv("ICPGPU_TILE_SPLITS"); return e ? atoi(e) : 4; }();
   const int per_block = (TS_BLOCK / 64) * 32 * TS_G;
   const int grid_x = (n_q + per_block - 1) / per_block;
   const int splits = splits_env < 1 ? 1 : splits_env > 64 ? 64 : splits_env;
+  static const int no_exact = [] {
+    if (!getenv("ICPGPU_TILE_NO_EXACT")) return 0;
+    fprintf(stderr, "[icpgpu] WARNING: ICPGPU_TILE_NO_EXACT is set -- the tile search skips its exact path, its results are WRONG (timing experiment)\n");
+    return 2;
+  }();
   hipLaunchKernelGGL(nn_tile_kernel, dim3(grid_x, splits), dim3(TS_BLOCK), 0, stream, src_morton, n_q, T, sorted, cell_start, g,
-                     tgt, n_t, thr, seed, keys, splits, stats);
+                     tgt, n_t, thr, seed, splits == 1 ? prev : nullptr, ((splits == 1 && prev && use_prev) ? 1 : 0) | no_exact, keys, splits, stats);
   return hipGetLastError();
 }
 

@@ -92,7 +92,7 @@ struct BruteOrder {
 
 // Keys of the last tile-search sweep (icp_tile.hip) of this alignment: every source's neighbour, a radius for the next sweep.
 struct TileSeed {
-  DeviceBuf keys, stats;
+  DeviceBuf keys, stats, prev;
   bool valid = false;
   uint64_t src_version = 0, grid_version = 0;
   int n_s = 0;
@@ -954,6 +954,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     TileSeed& S = c->tile_seed;
     const bool seeded = S.valid && S.src_version == c->src_version && S.grid_version == c->grid.version && S.n_s == n_s;
     if ((rc = ensure(c, S.keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+    if ((rc = ensure(c, S.prev, (size_t)c->brute_order.n * sizeof(float4)))) return rc;
     unsigned long long* d_stats = nullptr;
     if (tile_search > 1) {
       if ((rc = ensure(c, S.stats, 8 * sizeof(unsigned long long)))) return rc;
@@ -964,7 +965,8 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     HIP_TRY(c, launch_nn_tile_search(static_cast<const float4*>(c->brute_order.pts.ptr), c->brute_order.n, T,
                                      static_cast<const float4*>(c->grid.sorted.ptr), static_cast<const int*>(c->grid.cell_start.ptr),
                                      c->grid.g, c->tgt.data(), n_t, thr,
-                                     seeded ? static_cast<const unsigned long long*>(S.keys.ptr) : nullptr, keys, d_stats, c->stream));
+                                     seeded ? static_cast<const unsigned long long*>(S.keys.ptr) : nullptr,
+                                     static_cast<float4*>(S.prev.ptr), seeded, keys, d_stats, c->stream));
     HIP_TRY(c, hipMemcpyAsync(S.keys.ptr, keys, (size_t)n_s * sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
     S.valid = true;
     S.src_version = c->src_version;
@@ -1897,6 +1899,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->brute_order.check);
   release(c->tile_seed.keys);
   release(c->tile_seed.stats);
+  release(c->tile_seed.prev);
   release(c->fp_acc);
   release(c->batch_table);
   release(c->map.node_keys);
