@@ -5,18 +5,21 @@
 //
 // No data-path collective: shard r = pairs [lo_r, hi_r) is solved by icpgpu_align_batch on device r's context, by its own
 // host thread.  The gather: every shard's records (23 float64 = 184 B each, the layout of sharding.py) go to that device's
-// send buffer, padded to the largest shard; ONE ncclAllGather (RCCL, loaded with dlopen: libicpgpu.so does not link it)
-// leaves all records on every device; entry 0's copy comes back to the host, is checked (every pair id exactly once, in
-// order) and returned.  ICPGPU_COMM_HOST replaces RCCL's collective by a host-staged exchange through the same buffers
+// send buffer, padded to the largest shard; the threads are joined, and ONLY IF every entry got that far the calling thread
+// issues ONE all-gather over all devices (ncclGroupStart, one ncclAllGather per device, ncclGroupEnd; RCCL is loaded with
+// dlopen: libicpgpu.so does not link it) -- a collective is entered by every rank or by none -- and waits for each stream
+// with a deadline (ICPGPU_WAIT_TIMEOUT_MS).  All records are then on every device; entry 0's copy comes back to the host, is
+// checked (every pair id exactly once, in order) and returned.  ICPGPU_COMM_HOST replaces RCCL's collective by a host-staged exchange through the same buffers
 // (tests on a box with one GPU: several entries may name the same device then, which ncclCommInitAll refuses).
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
 
-#include <atomic>
-#include <condition_variable>
+#include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -27,7 +30,7 @@
 #include "../../include/icpgpu.h"
 
 namespace icpgpu {
-void set_host_share(int peers);  // icpgpu_api.cpp: how many batch drivers share this process's CPUs
+void set_ctx_host_share(icpgpu_ctx* ctx, int peers);  // icpgpu_api.cpp: how many batch drivers share this process's CPUs with ctx
 }
 
 namespace {
@@ -51,6 +54,7 @@ struct Rccl {
   void* lib = nullptr;
   int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*CommAbort)(ncclComm_t) = nullptr;  // optional
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
@@ -67,6 +71,7 @@ Rccl& rccl() {
     if (!r.lib) return r;
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
@@ -112,23 +117,29 @@ void shard(size_t n, int r, int world, size_t& lo, size_t& hi) {  // sharding.sh
   hi = lo + base + ((size_t)r < extra ? 1 : 0);
 }
 
-struct Barrier {  // (C++17 has no std::barrier)
-  std::mutex m;
-  std::condition_variable cv;
-  int count = 0, generation = 0, n;
-  explicit Barrier(int n_) : n(n_) {}
-  void wait() {
-    std::unique_lock<std::mutex> lk(m);
-    const int g = generation;
-    if (++count == n) {
-      count = 0;
-      ++generation;
-      cv.notify_all();
-    } else {
-      cv.wait(lk, [&] { return generation != g; });
-    }
+// The gather's deadline (ICPGPU_WAIT_TIMEOUT_MS, default 30 s -- the same switch as the solve's mailbox wait): a peer that
+// never enters the collective (a dead device, a hung kernel on its stream) must become an error code, not a hang.
+double gather_timeout_ms() {
+  static const double v = [] {
+    const char* e = std::getenv("ICPGPU_WAIT_TIMEOUT_MS");
+    const double t = e ? std::atof(e) : 0.0;
+    return t > 0.0 ? t : 30000.0;
+  }();
+  return v;
+}
+// 0: the stream drained; 1: it reported an error; 2: the deadline passed
+int wait_stream(hipStream_t s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return 1;
+    if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (first ~ms: spin, a gather is microseconds)
+    if ((spins & 63) == 63 &&
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > gather_timeout_ms())
+      return 2;
   }
-};
+}
 
 }  // namespace
 
@@ -197,27 +208,33 @@ int icpgpu_align_batch_multi(const int* devices, int n_devices, const icpgpu_par
   std::vector<std::string> msgs((size_t)n_devices);
   std::vector<double> host_all(communicator == ICPGPU_COMM_NONE ? 0 : block * (size_t)n_devices, -1.0);
   std::vector<double> gathered(communicator == ICPGPU_COMM_NONE ? 0 : block * (size_t)n_devices, -2.0);
-  Barrier barrier(n_devices);
-  icpgpu::set_host_share(n_devices);
+  auto failed = [&](int r, int code, const std::string& why) {
+    if (rcs[(size_t)r] == ICPGPU_OK) {
+      rcs[(size_t)r] = code;
+      msgs[(size_t)r] = why;
+    }
+  };
+  auto first_failure = [&]() -> int {
+    for (int r = 0; r < n_devices; ++r)
+      if (rcs[(size_t)r] != ICPGPU_OK) return multi_fail(rcs[(size_t)r], "%s", msgs[(size_t)r].c_str());
+    return ICPGPU_OK;
+  };
 
+  // ---- phase 1, one host thread per entry: solve the shard, pack its records, put them into the entry's send buffer.
+  // Nothing here waits for another entry.
   auto work = [&](int r) {
     Entry& e = *E[(size_t)r];
     size_t lo, hi;
     shard(n_pairs, r, n_devices, lo, hi);
-    auto failed = [&](int code, const std::string& why) {
-      if (rcs[(size_t)r] == ICPGPU_OK) {
-        rcs[(size_t)r] = code;
-        msgs[(size_t)r] = why;
-      }
-    };
+    icpgpu::set_ctx_host_share(e.ctx, n_devices);  // this context's batch shares the process's CPUs with n_devices - 1 others
     if (hi > lo) {
       const int rc = icpgpu_align_batch(e.ctx, hi - lo, src + lo, n_src + lo, tgt + lo, n_tgt + lo, want_fitness, results + lo);
-      if (rc != ICPGPU_OK) failed(rc, std::string("shard ") + std::to_string(r) + ": " + icpgpu_last_error(e.ctx));
+      if (rc != ICPGPU_OK) failed(r, rc, std::string("shard ") + std::to_string(r) + ": " + icpgpu_last_error(e.ctx));
     }
-    if (communicator == ICPGPU_COMM_NONE) return;
-    // ---- the result gather.  Every entry takes part whatever happened above (a collective must not be left half-entered).
+    icpgpu::set_ctx_host_share(e.ctx, 1);
+    if (communicator == ICPGPU_COMM_NONE || block == 0 || rcs[(size_t)r] != ICPGPU_OK) return;
     std::vector<double> mine(block, -1.0);
-    for (size_t k = lo; k < hi && rcs[(size_t)r] == ICPGPU_OK; ++k) {
+    for (size_t k = lo; k < hi; ++k) {
       double* rec = mine.data() + (k - lo) * kRecordLen;
       const icpgpu_result& R = results[k];
       rec[0] = (double)k;
@@ -230,42 +247,73 @@ int icpgpu_align_batch_multi(const int* devices, int n_devices, const icpgpu_par
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) rec[7 + 4 * i + j] = (double)R.T[j * 4 + i];  // column-major result -> row-major record
     }
-    bool dev_ok = hipSetDevice(devices[r]) == hipSuccess && ensure_dev(e.d_send, e.send_cap, block ? block : 1) == 0 &&
-                  ensure_dev(e.d_recv, e.recv_cap, block ? block * (size_t)n_devices : 1) == 0;
-    if (!dev_ok) failed(ICPGPU_ERR_HIP, "gather buffers on device " + std::to_string(devices[r]));
-    if (dev_ok && block && hipMemcpyAsync(e.d_send, mine.data(), block * sizeof(double), hipMemcpyHostToDevice, e.stream) != hipSuccess)
-      failed(ICPGPU_ERR_HIP, "upload of the records on device " + std::to_string(devices[r]));  // (the collective is still entered)
-    if (use_rccl) {
-      if (dev_ok && block) {
-        const int rc = rccl().AllGather(e.d_send, e.d_recv, block, kNcclFloat64, S.comms[(size_t)r], e.stream);
-        if (rc != 0) failed(ICPGPU_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(rc));
-      }
-      if (hipStreamSynchronize(e.stream) != hipSuccess) failed(ICPGPU_ERR_HIP, "stream synchronisation after the gather");
-    } else {
-      // host-staged exchange through the same device buffers: own block down, barrier, everybody's blocks up
-      if (dev_ok && block) {
-        (void)hipMemcpyAsync(host_all.data() + (size_t)r * block, e.d_send, block * sizeof(double), hipMemcpyDeviceToHost, e.stream);
-        (void)hipStreamSynchronize(e.stream);
-      }
-      barrier.wait();
-      if (dev_ok && block) {
-        (void)hipMemcpyAsync(e.d_recv, host_all.data(), block * (size_t)n_devices * sizeof(double), hipMemcpyHostToDevice, e.stream);
-        if (hipStreamSynchronize(e.stream) != hipSuccess) failed(ICPGPU_ERR_HIP, "host-staged gather");
-      }
-    }
-    if (r == 0 && dev_ok && block) {
-      if (hipMemcpy(gathered.data(), e.d_recv, block * (size_t)n_devices * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        failed(ICPGPU_ERR_HIP, "read-back of the gathered records");
-    }
+    if (hipSetDevice(devices[r]) != hipSuccess || ensure_dev(e.d_send, e.send_cap, block) != 0 ||
+        ensure_dev(e.d_recv, e.recv_cap, block * (size_t)n_devices) != 0)
+      return failed(r, ICPGPU_ERR_HIP, "gather buffers on device " + std::to_string(devices[r]));
+    if (hipMemcpyAsync(e.d_send, mine.data(), block * sizeof(double), hipMemcpyHostToDevice, e.stream) != hipSuccess ||
+        wait_stream(e.stream) != 0)   // (`mine` is pageable memory local to this thread: it must be consumed before it goes)
+      failed(r, ICPGPU_ERR_HIP, "upload of the records on device " + std::to_string(devices[r]));
   };
   std::vector<std::thread> threads;
   for (int r = 1; r < n_devices; ++r) threads.emplace_back(work, r);
   work(0);
   for (auto& t : threads) t.join();
-  icpgpu::set_host_share(1);
-  for (int r = 0; r < n_devices; ++r)
-    if (rcs[(size_t)r] != ICPGPU_OK) return multi_fail(rcs[(size_t)r], "%s", msgs[(size_t)r].c_str());
+  // ---- agreement BEFORE the collective: the join above is the barrier, rcs[] the shared verdict.  If any entry failed --
+  // its shard, its buffers, its upload -- NO entry enters the gather and the call returns that entry's error: a collective
+  // is entered by every rank or by none (until round 4 a rank without buffers skipped ncclAllGather while the others waited in it).
+  if (int rc = first_failure()) return rc;
   if (communicator == ICPGPU_COMM_NONE || n_pairs == 0) return ICPGPU_OK;
+
+  // ---- phase 2, this thread: ONE collective over all entries -- the all-gathers of every device issued between
+  // ncclGroupStart / ncclGroupEnd (RCCL's single-thread-many-devices form), then every stream waited for with a deadline.
+  if (use_rccl) {
+    Rccl& R = rccl();
+    int rc = R.GroupStart();
+    for (int r = 0; r < n_devices && rc == 0; ++r)
+      rc = R.AllGather(E[(size_t)r]->d_send, E[(size_t)r]->d_recv, block, kNcclFloat64, S.comms[(size_t)r], E[(size_t)r]->stream);
+    const int rc_end = R.GroupEnd();   // (always closed, so that a failed enqueue does not leave the group open)
+    if (rc == 0) rc = rc_end;
+    bool timed_out = false;
+    for (int r = 0; r < n_devices && rc == 0; ++r) {
+      const int w = wait_stream(E[(size_t)r]->stream);
+      if (w != 0) {
+        timed_out = w == 2;
+        failed(r, ICPGPU_ERR_HIP, timed_out ? "ncclAllGather did not complete within " + std::to_string((long long)gather_timeout_ms()) +
+                                                  " ms on device " + std::to_string(devices[r])
+                                            : "stream failure after ncclAllGather on device " + std::to_string(devices[r]));
+        break;
+      }
+    }
+    if (rc != 0) failed(0, ICPGPU_ERR_HIP, std::string("ncclAllGather: ") + R.GetErrorString(rc));
+    if (rc != 0 || timed_out || first_failure() != ICPGPU_OK) {
+      // the communicators are in an unknown state: drop them (abort if the library offers it, destroying a communicator with
+      // a collective in flight may block) and let the next call build new ones
+      for (ncclComm_t cm : S.comms)
+        if (cm) (void)(R.CommAbort ? R.CommAbort(cm) : R.CommDestroy(cm));
+      S.comms.clear();
+      S.comm_devices.clear();
+      return first_failure();
+    }
+  } else {
+    // host-staged exchange through the same device buffers: every block down, then everybody's blocks up
+    for (int r = 0; r < n_devices; ++r) {
+      Entry& e = *E[(size_t)r];
+      if (hipMemcpyAsync(host_all.data() + (size_t)r * block, e.d_send, block * sizeof(double), hipMemcpyDeviceToHost, e.stream) != hipSuccess ||
+          wait_stream(e.stream) != 0)
+        failed(r, ICPGPU_ERR_HIP, "host-staged gather (download) on device " + std::to_string(devices[r]));
+    }
+    if (int rc = first_failure()) return rc;
+    for (int r = 0; r < n_devices; ++r) {
+      Entry& e = *E[(size_t)r];
+      if (hipMemcpyAsync(e.d_recv, host_all.data(), block * (size_t)n_devices * sizeof(double), hipMemcpyHostToDevice, e.stream) != hipSuccess ||
+          wait_stream(e.stream) != 0)
+        failed(r, ICPGPU_ERR_HIP, "host-staged gather (upload) on device " + std::to_string(devices[r]));
+    }
+    if (int rc = first_failure()) return rc;
+  }
+  if (hipSetDevice(devices[0]) != hipSuccess ||
+      hipMemcpy(gathered.data(), E[0]->d_recv, block * (size_t)n_devices * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return multi_fail(ICPGPU_ERR_HIP, "read-back of the gathered records");
   // unpack: shard r's records sit at r * block; together they must name every pair exactly once, in order
   size_t k = 0;
   for (int r = 0; r < n_devices; ++r) {

@@ -228,6 +228,7 @@ struct icpgpu_ctx {
   size_t vox_pub_zeroed_cap = 0;
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   DeviceBuf batch_table;             // lock-step batch: the BatchPair table of the group this context leads
+  int host_share = 1;                // batch drivers of this process that share its CPUs with this context (icp_multi.cpp)
   std::string err;
 };
 
@@ -2138,21 +2139,23 @@ static int usable_cpus() {
 // Host threads of a batch: every one of them spins (on mailboxes, or inside a BFGS run), so there must be no more of them
 // than CPUs -- across ALL the processes of the job: one process per GPU is the deployment (LOCAL_WORLD_SIZE, set by
 // torch.distributed.run, says how many share this host's CPUs).  ICPGPU_BATCH_THREADS overrides.
-// batch drivers inside THIS process that share its CPUs (icpgpu_align_batch_multi: one per device)
-static std::atomic<int> g_host_share{1};
+// batch drivers inside THIS process that share its CPUs with this context's batch (icpgpu_align_batch_multi: one per device;
+// a property of the context, so that concurrent callers cannot overwrite each other's share)
 extern "C++" {
 namespace icpgpu {
-void set_host_share(int peers) { g_host_share.store(peers < 1 ? 1 : peers); }
+void set_ctx_host_share(icpgpu_ctx* c, int peers) {
+  if (c) c->host_share = peers < 1 ? 1 : peers;
 }
 }
-static size_t batch_threads(size_t cap) {
+}
+static size_t batch_threads(const icpgpu_ctx* c, size_t cap) {
   size_t t = 0;
   if (const char* v = std::getenv("ICPGPU_BATCH_THREADS")) t = (size_t)std::max(0, std::atoi(v));
   else if (const char* w = std::getenv("ICPGPU_BATCH_WORKERS")) t = (size_t)std::max(0, std::atoi(w));  // round-1 name
   if (t == 0) {
     int local = 1;
     if (const char* l = std::getenv("LOCAL_WORLD_SIZE")) local = std::max(1, std::atoi(l));
-    local *= g_host_share.load();
+    local *= c->host_share;
     t = (size_t)std::max(1, usable_cpus() / local);
     t = std::min(t, cap);
   }
@@ -2179,7 +2182,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   // group iterates); results are bit-identical to icpgpu_align's (same kernels' bodies, same workgroup -> point mapping).
   static const bool lockstep_on = [] { const char* e = std::getenv("ICPGPU_BATCH_LOCKSTEP"); return !e || std::atoi(e) != 0; }();
   const bool lockstep = lockstep_on && !gicp;
-  size_t n_threads = batch_threads(gicp ? 8 : 4), depth = 1;
+  size_t n_threads = batch_threads(c, gicp ? 8 : 4), depth = 1;
   if (!gicp) {
     if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
     else depth = lockstep ? 8 : std::max<size_t>(2, (8 + n_threads - 1) / n_threads);
