@@ -1,0 +1,371 @@
+// icp_ctx.h -- what the units of the C-ABI share (INTERNAL: nothing here is part of include/icpgpu.h): the context, its
+// buffers and caches, and the helpers that cross unit boundaries.  The C-ABI of libicpgpu.so is implemented by
+//   icpgpu_context.cpp  create / destroy, parameters, clouds (upload, recognition, promote), profile, stream
+//   icpgpu_index.cpp    the target's uniform grid: resumable builds, cell-size rules, the grid search's dispatch
+//   icpgpu_p2p.cpp      point-to-point ICP: sweeps (search + fused reduction), the mailbox, the resumable run, align / fitness
+//   icpgpu_gicp.cpp     GICP: covariances, the evaluation server, the BFGS outer loop
+//   icpgpu_batch.cpp    icpgpu_align_batch: lock-step groups and the round-robin scheduler
+//   icpgpu_voxel.cpp    the voxel-grid filter's host side
+//   icpgpu_map.cpp      the mapper's map and its nn cloud
+// (until round 4 all of this was one 3 200-line icpgpu_api.cpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#if defined(__linux__)
+#include <sched.h>
+#endif
+#include <atomic>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/icpgpu.h"
+#include "icp_kernels.h"
+#include "icp_gicp_solver.h"
+#include "icp_solver.h"
+
+using namespace icpgpu;
+
+struct icpgpu_ctx;
+
+namespace icpgpu_impl {
+
+
+
+struct DeviceBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;      // bytes owned (0 when external)
+  bool external = false;
+};
+
+struct Cloud {
+  DeviceBuf buf;
+  size_t n = 0;
+  bool set = false;
+  // fingerprint of 256 sampled points, taken from the HOST buffer at upload: lets icpgpu_set_target dismiss a same-sized but
+  // different cloud (fixed-size scans!) in a microsecond instead of hashing megabytes to find out
+  unsigned long long sample_fp = 0;
+  bool sample_valid = false;
+  const float4* data() const { return static_cast<const float4*>(buf.ptr); }
+};
+
+// Uniform grid over the target (icp_grid.hip), built lazily for the cutoff of the current parameters.
+struct GridIndex {
+  bool built = false, usable = false;
+  uint64_t version = 0;      // target version it was built for
+  float cutoff = 0.f;        // correspondence distance it was built for
+  GridDesc g{};
+  int n_binned = 0, max_pop = 0;
+  double point_population = 0.0;  // cell population seen by a random point (sum c^2 / sum c)
+  DeviceBuf sorted, cell_start, cell_of_point, rank, block_sums, ints, unmatched, leftover;
+  uint64_t serial = 0;       // unique per completed build (grids change hands between c->grid and c->src_grid)
+};
+
+// The neighbour every query found in the last grid sweep (nn_quad_kernel): an upper bound for the next sweep of the same
+// queries over the same target, whatever the transform (icp_grid.hip).  `valid` is cleared at the start of every
+// alignment, so an alignment never depends on the one before it.
+struct PrevNeighbours {
+  DeviceBuf buf;
+  bool valid = false;
+  const void* src = nullptr;     // query array the entries are indexed by
+  const void* sorted = nullptr;  // grid they were found in
+  int n = 0;
+  uint64_t grid_version = 0, src_version = 0;
+};
+
+// Keys of the last matrix-core brute-force sweep (icp_brute_mfma.hip): every source's neighbour, a bound for the next sweep
+// of the same source over the same target.
+// The source in Morton order of its grid cells (icp_brute_bf16.hip wants a workgroup's sources close together): cached per
+// build of the source's grid.
+struct BruteOrder {
+  DeviceBuf pts, work, check;
+  bool valid = false;
+  uint64_t grid_serial = 0;
+  int n = 0;
+};
+
+// Keys of the last tile-search sweep (icp_tile.hip) of this alignment: every source's neighbour, a radius for the next sweep.
+struct TileSeed {
+  DeviceBuf keys, stats, prev;
+  bool valid = false;
+  uint64_t src_version = 0, grid_version = 0;
+  int n_s = 0;
+};
+
+struct BruteSeed {
+  DeviceBuf keys;
+  bool valid = false;
+  uint64_t src_version = 0, tgt_version = 0;
+  const void* tgt = nullptr;
+  int n_s = 0, n_t = 0;
+};
+
+// The mapper's one-point-per-voxel map (icp_map.hip; octree_mapper.cpp:55-90).
+struct VoxelMap {
+  bool defined = false;   // resolution set by icpgpu_map_reset
+  bool anchored = false;  // lattice origin fixed by the first point ever added
+  MapDesc desc{};
+  int n = 0;              // points in the map
+  uint64_t version = 1;   // bumped whenever points are appended
+  unsigned int cap = 0;   // hash-set capacity (power of two, load <= 1/2)
+  Cloud pts;              // the map cloud (owned)
+  DeviceBuf keys, vals, first, staged, moved, slot_of, flags, rank, temp, counter, nn_keys;
+  DeviceBuf first_user, uflags, urank, uniq_index;
+  Cloud uniq;             // the distinct points of the last nn cloud (what the ICP target's grid is built from)
+  GridIndex grid;         // for the nn-cloud search
+  // PCL-faithful approxNearestSearch mode (icpgpu_map_set_search): the octree's bounding box as PCL grows it, replayed over
+  // the map points in insertion order, and the hash set of occupied octree nodes (icp_map.hip)
+  int search_mode = ICPGPU_MAP_SEARCH_EXACT;
+  bool box_defined = false;
+  ApproxBox box{};
+  int box_upto = 0;           // map points already folded into the box
+  uint64_t box_version = 0;   // bumped whenever the box grows
+  DeviceBuf node_keys, node_vals;
+  unsigned int node_cap = 0;
+  int nodes_upto = 0;         // map points whose paths are in the node set
+  uint64_t nodes_box_version = ~0ull;
+};
+
+constexpr long long kMaxGridCells = 16ll << 20; // 64 MB of cell_start at most
+constexpr int kMaxCellPopulation = 4096;        // beyond this a lane's serial cell scan is slower than brute force
+constexpr double kDenseCellPopulation = 44.0;   // shrink the cells beyond this point-weighted population (64 until round 2: a 200k scan at gate / 4 sits at 47; with cells for ~36 its alignment takes 620-645 instead of 668 us of search) ...
+constexpr double kTargetCellPopulation = 36.0;  // ... down to about this one (18 until the search was ball-pruned: 200k x 1M from identity 77 -> 65 us)
+constexpr double kSparseCellPopulation = 20.0;  // double the cells below this one (2.5 until then: 50k x 50k from identity 31 -> 27 us)
+constexpr size_t kOrderSourceMin = 100000;      // AUTO: order the source by cell from this size on (see ensure_source_order)
+constexpr int kEventRing = 64;                   // sweeps whose kernel timing may be outstanding
+constexpr int kMfmaMinPoints = 8192;             // the matrix-core brute-force kernels from this many points on (both clouds)
+constexpr size_t kGridMinTarget = 4096;         // AUTO: below this the brute-force kernel is launch-latency bound anyway
+
+
+}  // namespace icpgpu_impl
+using namespace icpgpu_impl;
+
+constexpr size_t kMaxServerWorkers = 8;
+
+inline bool gicp_server_enabled() {  // ICPGPU_GICP_SERVER=0: every GICP evaluation is its own launch
+#if defined(__x86_64__)
+  static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_SERVER"); return !e || std::atoi(e) != 0; }();
+  return v;
+#else
+  return false;  // the command protocol relies on x86 store ordering
+#endif
+}
+
+struct icpgpu_ctx {
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  icpgpu_params params{};
+  Cloud src, tgt;
+  DeviceBuf keys, partials, sums, out, idx, d2, cand_counter;
+  GridIndex grid;            // acceleration structure over the current target
+  GridIndex src_grid;        // the source in cell order (and, after promote_source_to_target, the next target's grid)
+  PrevNeighbours prev;       // last sweep's neighbours (search bound of the next sweep)
+  BruteSeed brute_seed;      // the same for the matrix-core brute-force kernels
+  BruteOrder brute_order;    // the source in Morton order (bf16 matrix-core kernels)
+  TileSeed tile_seed;        // the previous sweep's keys (matrix-core grid search)
+  VoxelMap map;              // the mapper's map
+  uint64_t tgt_version = 1;  // bumped whenever the target cloud changes
+  // content fingerprints of the clouds in HBM (icpgpu_set_target's recognition of a cloud it already holds), computed on
+  // demand and cached per version
+  unsigned long long src_fp = 0, tgt_fp = 0;
+  uint64_t src_fp_version = 0, tgt_fp_version = 0;
+  DeviceBuf fp_acc;
+  uint64_t src_version = 1;  // bumped whenever the source cloud changes
+  // GICP mode: grids used for the 20-NN covariances, per-point covariances (6 doubles), Mahalanobis matrices
+  GridIndex cov_grid_src, cov_grid_tgt;
+  DeviceBuf cov_src, cov_tgt, maha;
+  uint64_t cov_src_version = 0, cov_tgt_version = 0;
+  // Per-iteration result mailbox in pinned, mapped host memory: 17 sums + 17 sequence flags.  The final reduction
+  // stores straight into it and the host polls the flags -- no copy engine and no stream synchronisation (whose wake-up
+  // costs 20-70 us depending on how the process set up the runtime) on the iteration path.
+  double* h_sums = nullptr;
+  double* h_sums_dev = nullptr;              // device alias of h_sums
+  volatile unsigned long long* h_flags = nullptr;
+  unsigned long long* h_flags_dev = nullptr;  // device alias of h_flags
+  unsigned long long sums_seq = 0;
+  // GICP cost evaluations: per-workgroup partials (kGicpDirectBlocks x 17) + one flag per workgroup, same kind of memory
+  double* h_gicp = nullptr;
+  double* h_gicp_dev = nullptr;
+  volatile unsigned long long* h_gicp_flags = nullptr;
+  unsigned long long* h_gicp_flags_dev = nullptr;
+  // resident evaluation server (icp_gicp.hip): its command line, fine-grained device memory the host writes through the BAR
+  unsigned int* gicp_cmd = nullptr;
+  bool gicp_server_on = false;
+  bool gicp_server_allowed = true;  // align_batch with more than kMaxServerWorkers threads: single launches (below)
+  int gicp_blocks_most = kGicpDirectBlocks;
+  // ICPGPU_GICP_TIMING=1 (development): where an evaluation's microseconds go, printed when the context is destroyed
+  double gt_cmd = 0, gt_wait = 0, gt_merge = 0, gt_between = 0, gt_dev_wait = 0, gt_dev_work = 0;
+  unsigned long long gt_n = 0;
+  // ICPGPU_P2P_TIMING=1 (development): host time between a sweep's sums and the next search kernel's launch
+  double pt_wait = 0, pt_solve = 0, pt_prelaunch = 0, pt_launch = 0, pt_rest = 0;
+  unsigned long long pt_n = 0;
+  std::chrono::steady_clock::time_point pt_ready{}, pt_issue_in{};
+  std::chrono::steady_clock::time_point gt_last{};  // workgroups per cost evaluation: the whole chip, or this worker's share of it
+  // kernel timing for the profile: event triples are recorded per sweep and only read back when the align ends
+  std::vector<hipEvent_t> ev_ring;            // 3 * kEventRing events
+  struct PendingSweep { int slot; bool grid; };
+  std::vector<PendingSweep> pending;
+  double dev_ms_accum = 0.0;
+  unsigned call_sweeps = 0, call_timed = 0;  // sweeps of the current align call: all / timed
+  int timing_every = 13;      // time one sweep in 13 (coprime with the 10 / 30 iterations of the reference's aligns; 7 until round 2: an event triple costs 6-7 us)
+  unsigned sweep_counter = 0;
+  int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
+  bool have_final = false;
+  Mat4d final_T = mat4_identity();
+  icpgpu_profile prof{};
+  int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
+  DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
+  DeviceBuf vox_bins, vox_pub;   // ... of the direct (no library sort) path: self-cleaning histogram + group ranges; published counts
+  size_t vox_last_n = 0;         // points of the last icpgpu_voxel_grid result (still in vox_out)
+  void* vox_bins_zeroed = nullptr;  // the allocation (address, size) whose histogram is known to be zero
+  size_t vox_bins_zeroed_cap = 0;
+  void* vox_pub_zeroed = nullptr;
+  size_t vox_pub_zeroed_cap = 0;
+  std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
+  DeviceBuf batch_table;             // lock-step batch: the BatchPair table of the group this context leads
+  int host_share = 1;                // batch drivers of this process that share its CPUs with this context (icp_multi.cpp)
+  std::string err;
+};
+
+#define HIP_TRY(c, expr)                                                                              \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail((c), e_ == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "%s failed: %s", #expr, \
+                  hipGetErrorString(e_));                                                             \
+  } while (0)
+
+#define ENTER(c)                                                   \
+  if (!(c)) return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "null context"); \
+  HIP_TRY((c), hipSetDevice((c)->device))
+
+namespace icpgpu_impl {
+
+// (Re)build a uniform grid over `cloud` for the cutoff `cut` (see icp_grid.hip).  G.usable stays false when the grid
+// cannot help (no finite point, one cell holding > kMaxCellPopulation points).
+//
+// A build has two host round trips (the bounding box sizes the table; the occupancy statistics of the count pass may
+// change the cell size once or twice).  It is written as a resumable state machine so that the lock-step batch path
+// (icpgpu_align_batch) can take K builds through their round trips TOGETHER -- one stream synchronisation per stage for
+// the whole group instead of two or three per pair; build_grid() drives one build to the end.
+struct GridBuild {
+  enum State { Done, WaitBbox, WaitCount };
+  State state = Done;
+  const Cloud* cloud = nullptr;
+  uint64_t version = 0;
+  double cut = 0.0;
+  bool adapt = false;
+  GridIndex* G = nullptr;
+  const int* orig_index = nullptr;
+  double knn_population = 0.0;
+  double h = 0.0;
+  int attempt = 0;
+  bool shrunk = false;
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  GridDesc g{};
+  std::chrono::steady_clock::time_point t0{};
+};
+
+// One NN sweep + reduction with transform T, in three steps so that one host thread can keep several contexts busy
+// (icpgpu_align_batch): sweep_issue queues the kernels, the 17 sums land in c->h_sums when flags_ready(c->h_flags, ...,
+// ticket.seq) -- the host polls the mailbox, it never waits for the stream -- and sweep_complete finishes the rare ungated
+// sweep whose grid stage left too many points for the few-queries kernel.
+struct SweepTicket {
+  unsigned long long seq = 0;
+  volatile int* few_host = nullptr;  // ungated grid search: number of points its grid stage left unmatched
+  const float4* red_src = nullptr;   // keys path: the array the keys index
+  int red_n = 0;
+  Xform T{};
+  float thr = 0.f;
+};
+
+// A point-to-point alignment as a resumable run: begin() queues the first sweep, advance() -- called once the sweep's sums
+// have arrived -- does the host's share of an iteration (Umeyama / SVD, convergence test: icp_solver.cpp) and queues the
+// next sweep, the fitness sweep, or finishes.  icpgpu_align drives one run to the end; icpgpu_align_batch keeps several
+// contexts' runs in flight from one host thread.
+struct P2PRun {
+  enum Phase { Idle, Iterating, Fitness, Done } phase = Idle;
+  Mat4d final_T = mat4_identity();
+  ConvergenceCriteria crit{1, 0.0, 0.0, false};
+  float thr = 0.f;
+  int nr_iter = 0, state = ICPGPU_NOT_CONVERGED, want_fitness = 0;
+  bool converged = false;
+  unsigned n_corr = 0;
+  double mse = 0.0;
+  SweepTicket ticket;
+  icpgpu_result* res = nullptr;
+  float* out_xyzw = nullptr;
+  std::chrono::steady_clock::time_point t_start, t_issue;
+};
+
+// ---- helpers that cross unit boundaries -------------------------------------------------------------------------------------
+// icpgpu_context.cpp
+int fail(icpgpu_ctx* c, int code, const char* fmt, ...);
+int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes);
+void release(DeviceBuf& b);
+Xform to_xform(const Mat4d& T);
+Xform to_xform(const float* T);
+float threshold_from(double r2);
+int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
+int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
+int promote_internal(icpgpu_ctx* c);
+// icpgpu_index.cpp
+int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
+             const int* orig_index = nullptr, double knn_population = 0.0);
+int gb_advance(icpgpu_ctx* c, GridBuild& b);
+int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
+               const int* orig_index = nullptr, double knn_population = 0.0);
+int ensure_grid(icpgpu_ctx* c, float accept_thr);
+int grid_flags(const GridIndex& G, bool src_in_cell_order);
+int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, float4*& buf, bool& use);
+int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t, const Xform& T,
+                 unsigned long long* keys, int* deferred = nullptr);
+int complete_deferred_keys(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t,
+                           const Xform& T, unsigned long long* keys, int n_un);
+int source_order_mode();
+int nn_keys_grid(icpgpu_ctx* c, const Xform& T, unsigned long long* keys);
+bool grid_ready(const icpgpu_ctx* c);
+int ensure_source_order(icpgpu_ctx* c, float accept_thr);
+bool source_ordered(const icpgpu_ctx* c);
+int source_in_morton_order(icpgpu_ctx* c);
+// icpgpu_p2p.cpp
+int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T, unsigned long long* keys, bool* used_mfma = nullptr);
+int resolve_sweep_timings(icpgpu_ctx* c, bool block = true);
+double wait_timeout_ms();
+bool flags_ready(const volatile unsigned long long* pairs, int n_pairs, unsigned long long seq);
+void take_sums(icpgpu_ctx* c);
+int wait_flags(icpgpu_ctx* c, const volatile unsigned long long* flags, int n_flags, unsigned long long seq);
+int wait_sums(icpgpu_ctx* c, unsigned long long seq);
+int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, SweepTicket& tk);
+bool sweep_ready(const icpgpu_ctx* c, const SweepTicket& tk);
+int sweep_complete(icpgpu_ctx* c, SweepTicket& tk);
+int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range);
+int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw);
+void init_result(icpgpu_result* r);
+int p2p_finish(icpgpu_ctx* c, P2PRun& r);
+int p2p_prepare(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res);
+int p2p_begin(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res);
+int p2p_advance(icpgpu_ctx* c, P2PRun& r, int* deferred = nullptr);
+int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res);
+// icpgpu_voxel.cpp
+int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough);
+// icpgpu_gicp.cpp
+int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version);
+int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res);
+
+}  // namespace icpgpu_impl

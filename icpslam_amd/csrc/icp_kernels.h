@@ -237,7 +237,7 @@ hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const floa
 
 // ---- the mapper's one-point-per-voxel map (icp_map.hip), SURVEY.md 8(f4) --------------------------------------------
 struct MapDesc {
-  double ox, oy, oz;  // lattice origin = first inserted point - resolution / 2 (PCL OctreePointCloud bounding-box rule)
+  double ox, oy, oz;  // lattice origin = first inserted point - resolution (PCL OctreePointCloud: first box p +- res/2, widened to 2 voxels by getKeyBitSize)
   double res;         // voxel size (octree_resolution_, 0.5 m)
 };
 // PCL's octree geometry for the faithful approxNearestSearch mode (icp_map.hip): the bounding box as

@@ -5,7 +5,7 @@
 //   :62-69  addPointsToMap()    for every point IN ORDER: if its octree voxel is not occupied, append it to map_cloud_
 //   :72-90  approxNearestNeighbors()  for every scan point the nearest map point -> "nn cloud", the ICP target
 // The octree itself is PCL's; what the reference relies on is (i) one point per leaf voxel, the FIRST one to arrive,
-// (ii) leaf voxels of a fixed lattice: PCL anchors the lattice at (first point - resolution/2) and only ever grows the
+// (ii) leaf voxels of a fixed lattice: PCL anchors the lattice at (first point - resolution: the first box p +- res/2 widened by getKeyBitSize) and only ever grows the
 // bounding box by whole octree side lengths, so voxel membership is floor((p - origin) / resolution) evaluated in double
 // (OctreePointCloud::genOctreeKeyforPoint), (iii) a nearest-neighbour query per scan point.  (iii) is approximate in PCL
 // (approxNearestSearch descends by voxel centre); here it is EXACT, which is what SURVEY.md 8(f4) asks for.

@@ -30,7 +30,7 @@
 #include "../../include/icpgpu.h"
 
 namespace icpgpu {
-void set_ctx_host_share(icpgpu_ctx* ctx, int peers);  // icpgpu_api.cpp: how many batch drivers share this process's CPUs with ctx
+void set_ctx_host_share(icpgpu_ctx* ctx, int peers);  // icpgpu_batch.cpp: how many batch drivers share this process's CPUs with ctx
 }
 
 namespace {

@@ -1,0 +1,557 @@
+// icpgpu_batch.cpp -- icpgpu_align_batch: many independent scan pairs through one context (BASELINE configs 4 / 5).
+#include "icp_ctx.h"
+
+
+namespace icpgpu_impl {
+
+}  // namespace icpgpu_impl
+
+extern "C" {
+
+// ---- icpgpu_align_batch: independent scan pairs ----------------------------------------------------------------------------
+// CPUs this process may use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes grant 16 of 256 CPUs).
+static int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+#if defined(__linux__)
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+    char q[64];
+    long long period = 0;
+    if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+      n = std::min(n, std::max(1, (int)(std::atoll(q) / period)));
+    std::fclose(f);
+  } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+    long long quota = -1, period = 0;
+    if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+    std::fclose(g);
+    if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(h, "%lld", &period) != 1) period = 0;
+      std::fclose(h);
+    }
+    if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)(quota / period)));
+  }
+#endif
+  return n;
+}
+
+// Host threads of a batch: every one of them spins (on mailboxes, or inside a BFGS run), so there must be no more of them
+// than CPUs -- across ALL the processes of the job: one process per GPU is the deployment (LOCAL_WORLD_SIZE, set by
+// torch.distributed.run, says how many share this host's CPUs).  ICPGPU_BATCH_THREADS overrides.
+// batch drivers inside THIS process that share its CPUs with this context's batch (icpgpu_align_batch_multi: one per device;
+// a property of the context, so that concurrent callers cannot overwrite each other's share)
+extern "C++" {
+namespace icpgpu {
+void set_ctx_host_share(icpgpu_ctx* c, int peers) {
+  if (c) c->host_share = peers < 1 ? 1 : peers;
+}
+}
+}
+static size_t batch_threads(const icpgpu_ctx* c, size_t cap) {
+  size_t t = 0;
+  if (const char* v = std::getenv("ICPGPU_BATCH_THREADS")) t = (size_t)std::max(0, std::atoi(v));
+  else if (const char* w = std::getenv("ICPGPU_BATCH_WORKERS")) t = (size_t)std::max(0, std::atoi(w));  // round-1 name
+  if (t == 0) {
+    int local = 1;
+    if (const char* l = std::getenv("LOCAL_WORLD_SIZE")) local = std::max(1, std::atoi(l));
+    local *= c->host_share;
+    t = (size_t)std::max(1, usable_cpus() / local);
+    t = std::min(t, cap);
+  }
+  return std::max<size_t>(1, t);
+}
+
+// Point-to-point ICP: T host threads, each driving K worker contexts (own stream, scratch, grid, mailbox) ROUND-ROBIN --
+// it polls the mailboxes of its contexts and does the host's share of an iteration (3x3 SVD, convergence test, next launch)
+// for whichever has answered, so the kernels of K alignments are in flight per thread and nobody blocks on one result.
+// T x K = 8 alignments in flight (a 50k-point sweep fills less than half of the chip), T from the CPUs this process may
+// use: 4 x 2 on an unshared 16-CPU box, 2 x 4 when eight ranks share it.  GICP: one alignment per thread (its BFGS loop is
+// a blocking host loop), T threads.  Every pair is solved exactly as icpgpu_align would solve it.
+int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src,
+                       const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
+  ENTER(c);
+  if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (n_pairs == 0) return ICPGPU_OK;
+  const bool gicp = c->params.method == ICPGPU_GICP;
+  // Point-to-point batches run in LOCK-STEP (ICPGPU_BATCH_LOCKSTEP=0: the round-robin scheduler of round 2): a host thread
+  // leads a group of `depth` pairs on ONE stream -- their index builds go through their host round trips together, and
+  // every ICP iteration of the whole group is one search launch (pair = blockIdx.y, nn_quad_batch_kernel) + one final
+  // reduction launch (17 x K workgroups) + K host solves, instead of K x (launch + reduce + poll): ~35 launches per K
+  // pairs where there were ~35 per pair.  Two threads keep the GPU fed (one copies its next group in while the other's
+  // group iterates); results are bit-identical to icpgpu_align's (same kernels' bodies, same workgroup -> point mapping).
+  static const bool lockstep_on = [] { const char* e = std::getenv("ICPGPU_BATCH_LOCKSTEP"); return !e || std::atoi(e) != 0; }();
+  const bool lockstep = lockstep_on && !gicp;
+  size_t n_threads = batch_threads(c, gicp ? 8 : 4), depth = 1;
+  if (!gicp) {
+    if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
+    else depth = lockstep ? 8 : std::max<size_t>(2, (8 + n_threads - 1) / n_threads);
+    if (lockstep) depth = std::min<size_t>(depth, (size_t)kBatchMax);
+  }
+  n_threads = std::min(n_threads, n_pairs);
+  depth = std::min(depth, (n_pairs + n_threads - 1) / n_threads);
+  const size_t n_ctx = n_threads * depth;
+  while (c->workers.size() < n_ctx) {
+    icpgpu_ctx* w = nullptr;
+    const int rc = icpgpu_create(&w, c->device);
+    if (rc != ICPGPU_OK) return fail(c, rc, "align_batch: worker context: %s", icpgpu_last_error(nullptr));
+    c->workers.push_back(w);
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<bool> abort{false};
+  struct ThreadError {  // one slot per host thread: nothing shared is written while the threads run
+    int code = ICPGPU_OK;
+    size_t pair = 0;
+    std::string msg;
+  };
+  std::vector<ThreadError> errors(n_threads);
+  auto load_pair = [&](icpgpu_ctx* w, size_t k, bool sync = true) {  // (the caller's buffers outlive this call: sync is optional)
+    w->src_version++;
+    int rc = set_cloud_host(w, w->src, src[k], n_src[k], sync);
+    w->tgt_version++;
+    if (!rc) rc = set_cloud_host(w, w->tgt, tgt[k], n_tgt[k], sync);
+    return rc;
+  };
+  auto work = [&](size_t t) {
+    ThreadError& err = errors[t];
+    auto failed = [&](int rc, size_t k, icpgpu_ctx* w) {
+      err.code = rc;
+      err.pair = k;
+      err.msg = w->err;
+      abort.store(true);
+    };
+    if (hipSetDevice(c->device) != hipSuccess) {
+      err.code = ICPGPU_ERR_HIP;
+      err.msg = "hipSetDevice failed in a batch thread";
+      abort.store(true);
+      return;
+    }
+    icpgpu_ctx* const* ws = &c->workers[t * depth];
+    for (size_t s = 0; s < depth; ++s) {
+      ws[s]->params = c->params;
+      ws[s]->nn_variant = c->nn_variant;
+      // Every GICP worker's BFGS runs keep its workgroups resident and a host thread spinning.  8 workers fit the chip
+      // with room for everybody's searches; 16 were measured 5x SLOWER than single launches (servers wait for slots other
+      // servers hold until their 50 ms patience runs out).
+      ws[s]->gicp_server_allowed = n_threads <= kMaxServerWorkers;
+      // ... and each worker's evaluations get their share of the ~512 workgroups of that size the chip holds at once (64
+      // apiece for 8 workers, as measured in round 1; a lone alignment uses up to 256)
+      ws[s]->gicp_blocks_most = std::max(16, std::min(kGicpDirectBlocks, 512 / (int)std::max<size_t>(1, n_threads)));
+    }
+    if (gicp) {  // one blocking alignment after the other
+      icpgpu_ctx* w = ws[0];
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= n_pairs || abort.load()) return;
+        int rc = load_pair(w, k);
+        if (!rc) rc = align_gicp(w, nullptr, nullptr, want_fitness, &results[k]);
+        if (rc) return failed(rc, k, w);
+      }
+    }
+    const double timeout_ms = wait_timeout_ms();
+    if (lockstep) {
+      // ---- lock-step groups ----------------------------------------------------------------------------------------
+      struct Slot {
+        icpgpu_ctx* w = nullptr;
+        size_t pair = 0;
+        P2PRun run;
+        GridBuild gb;
+        bool lock = false;     // iterates inside the group's lock-step launches (else: the single-pair state machine)
+        bool wants = false;    // lock-step: its next gated sweep is due
+        bool wants_fit = false;  // lock-step: its ungated fitness sweep is due
+        bool waiting = false;  // lock-step: a sweep of it is in flight
+        bool pack = false;
+        float4* prev = nullptr;
+      };
+      std::vector<Slot> slots(depth);
+      icpgpu_ctx* lead = ws[0];
+      hipStream_t gstream = lead->stream;
+      std::vector<hipStream_t> own(depth);
+      for (size_t s2 = 0; s2 < depth; ++s2) {
+        slots[s2].w = ws[s2];
+        own[s2] = ws[s2]->stream;
+        ws[s2]->stream = gstream;  // one queue for the group: builds, sweeps and fitness sweeps are ordered by it
+      }
+      struct Restore {
+        std::vector<hipStream_t>& own;
+        icpgpu_ctx* const* ws;
+        hipStream_t g;
+        ~Restore() {
+          (void)hipStreamSynchronize(g);
+          for (size_t i = 0; i < own.size(); ++i) ws[i]->stream = own[i];
+        }
+      } restore{own, ws, gstream};
+      if (ensure(lead, lead->batch_table, depth * sizeof(BatchPair))) return failed(ICPGPU_ERR_OOM, 0, lead);
+      std::vector<BatchPair> table(depth);
+      auto sync_or_fail = [&](Slot& sl) {
+        const hipError_t e = hipStreamSynchronize(gstream);
+        if (e == hipSuccess) return true;
+        fail(sl.w, ICPGPU_ERR_HIP, "lock-step batch: %s", hipGetErrorString(e));
+        failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+        return false;
+      };
+      int timed_pairs = 0;          // pairs of the launch whose events are outstanding
+      unsigned step_counter = 0;
+      static const bool bt_on = [] { const char* e = std::getenv("ICPGPU_BATCH_TIMING"); return e && std::atoi(e) != 0; }();
+      double bt_fill = 0, bt_build = 0, bt_iter = 0;
+      size_t bt_groups = 0, bt_steps = 0;
+      struct BtPrint {
+        const bool& on; double &f, &b, &i; size_t &g, &st; size_t t;
+        ~BtPrint() { if (on && g) fprintf(stderr, "[icpgpu] batch thread %zu: %zu groups, %zu steps; per group: fill (H2D) %.3f ms, index builds %.3f ms, iterations + fitness %.3f ms\n", t, g, st, f / g, b / g, i / g); }
+      } bt_print{bt_on, bt_fill, bt_build, bt_iter, bt_groups, bt_steps, t};
+      for (;;) {
+        const auto bt0 = std::chrono::steady_clock::now();
+        // (1) fill the group
+        size_t n_slots = 0;
+        while (n_slots < depth && !abort.load()) {
+          const size_t k = next.fetch_add(1);
+          if (k >= n_pairs) break;
+          Slot& sl = slots[n_slots];
+          sl.pair = k;
+          sl.lock = sl.wants = sl.wants_fit = sl.waiting = false;
+          int rc = load_pair(sl.w, k, /*sync=*/false);
+          if (!rc) rc = p2p_prepare(sl.w, sl.run, nullptr, nullptr, want_fitness, &results[k]);
+          if (rc) return failed(rc, k, sl.w);
+          ++n_slots;
+        }
+        if (n_slots == 0 || abort.load()) return;
+        const auto bt1 = std::chrono::steady_clock::now();
+        // (2) the target grids, every build's host round trips shared by the group
+        for (size_t i = 0; i < n_slots; ++i) {
+          Slot& sl = slots[i];
+          sl.gb = GridBuild{};
+          if (sl.run.phase == P2PRun::Done) continue;  // empty target
+          icpgpu_ctx* w = sl.w;
+          const int mode = w->params.nn_mode;
+          const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && w->tgt.n >= kGridMinTarget);
+          const double cut = std::sqrt((double)sl.run.thr) * (1.0 + 1e-6);
+          if (!want || !(sl.run.thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
+            w->grid.usable = w->grid.built = false;
+            continue;
+          }
+          const int rc = gb_begin(w, sl.gb, w->tgt, w->tgt_version, cut, /*adapt=*/true, w->grid);
+          if (rc) return failed(rc, sl.pair, w);
+        }
+        for (;;) {
+          bool pending = false;
+          for (size_t i = 0; i < n_slots; ++i) pending = pending || slots[i].gb.state != GridBuild::Done;
+          if (!pending) break;
+          if (!sync_or_fail(slots[0])) return;
+          for (size_t i = 0; i < n_slots; ++i)
+            if (slots[i].gb.state != GridBuild::Done) {
+              const int rc = gb_advance(slots[i].w, slots[i].gb);
+              if (rc) return failed(rc, slots[i].pair, slots[i].w);
+            }
+        }
+        const auto bt2 = std::chrono::steady_clock::now();
+        // (3) who can iterate in lock-step; the others start their own first sweep
+        size_t live = 0;
+        for (size_t i = 0; i < n_slots; ++i) {
+          Slot& sl = slots[i];
+          if (sl.run.phase == P2PRun::Done) continue;
+          icpgpu_ctx* w = sl.w;
+          ++live;
+          const int n_s = (int)w->src.n;
+          const int flags = grid_flags(w->grid, false);
+          sl.lock = grid_ready(w) && n_s > 0 && w->src.n < kOrderSourceMin && source_order_mode() != 1 &&
+                    grid_search_batchable(n_s, flags) && sl.run.thr <= w->grid.cutoff * w->grid.cutoff;
+          sl.run.phase = P2PRun::Iterating;
+          sl.run.t_issue = std::chrono::steady_clock::now();
+          if (!sl.lock) {
+            int rc = ensure_source_order(w, sl.run.thr);
+            if (!rc) rc = sweep_issue(w, to_xform(sl.run.final_T), sl.run.thr, false, sl.run.ticket);
+            if (rc) return failed(rc, sl.pair, w);
+            continue;
+          }
+          if (w->src_grid.version != w->src_version) w->src_grid.built = w->src_grid.usable = false;
+          const int blocks = grid_search_blocks(n_s);
+          int rc = ensure(w, w->partials, (size_t)blocks * kReduceTerms * sizeof(double));
+          bool use_prev = false;
+          if (!rc) rc = prev_neighbours(w, w->grid, w->src.data(), n_s, flags, sl.prev, use_prev);  // (allocates; the first sweep is cold)
+          if (rc) return failed(rc, sl.pair, w);
+          w->prev.valid = w->tile_seed.valid = false;
+          sl.pack = (flags & kGridPackShortRows) != 0;
+          if (!rc) rc = ensure(w, w->keys, (size_t)n_s * sizeof(unsigned long long));
+          if (!rc) rc = ensure(w, w->grid.unmatched, (size_t)(n_s + 1) * sizeof(int));
+          if (rc) return failed(rc, sl.pair, w);
+          BatchPair& bp = table[i];
+          bp.keys = static_cast<unsigned long long*>(w->keys.ptr);
+          bp.unmatched = static_cast<int*>(w->grid.unmatched.ptr);
+          bp.unmatched_count = bp.unmatched + n_s;
+          bp.r_max_open = std::min(4 * w->grid.g.r_max, 48);
+          bp.src = w->src.data();
+          bp.sorted = static_cast<const float4*>(w->grid.sorted.ptr);
+          bp.cell_start = static_cast<const int*>(w->grid.cell_start.ptr);
+          bp.partials = static_cast<double*>(w->partials.ptr);
+          bp.prev_nn = sl.prev;
+          bp.flags = w->h_flags_dev;
+          bp.g = w->grid.g;
+          bp.accept_thr = sl.run.thr;
+          bp.n_s = n_s;
+          bp.qpw = grid_search_qpw(n_s);
+          bp.xcd_map = 0;
+          bp.blocks = blocks;
+          sl.wants = true;
+        }
+        // one row-walk variant for the whole group (the packed walk of sparse targets is a speed choice, the neighbours are the
+        // same): the majority's, so that a step is ONE launch
+        {
+          int n_lock = 0, n_pack = 0;
+          for (size_t i = 0; i < n_slots; ++i)
+            if (slots[i].lock) {
+              ++n_lock;
+              n_pack += slots[i].pack ? 1 : 0;
+            }
+          const bool group_pack = 2 * n_pack >= n_lock && n_pack > 0;
+          for (size_t i = 0; i < n_slots; ++i) slots[i].pack = group_pack;
+        }
+        if (hipMemcpyAsync(lead->batch_table.ptr, table.data(), n_slots * sizeof(BatchPair), hipMemcpyHostToDevice, gstream) != hipSuccess) {
+          fail(lead, ICPGPU_ERR_HIP, "lock-step batch: table upload");
+          return failed(ICPGPU_ERR_HIP, slots[0].pair, lead);
+        }
+        // (4) iterate: one search launch + one reduction launch per step and row-walk class for the whole group
+        unsigned idle_spins = 0;
+        while (live > 0) {
+          // a step is launched when no lock-step sweep of the group is in flight any more (the step IS the batch; pairs in
+          // their fitness sweep or on the single-pair path do not hold it up)
+          bool lock_in_flight = false;
+          for (size_t i = 0; i < n_slots; ++i) lock_in_flight = lock_in_flight || (slots[i].lock && slots[i].waiting);
+          for (int kind = 0; kind < 2 && !lock_in_flight; ++kind) {  // 0: the gated sweeps due, 1: the fitness sweeps due
+            BatchStep step;
+            int n_act = 0, max_blocks = 0;
+            bool group_pack = false;
+            step.use_prev_mask = 0u;
+            for (size_t i = 0; i < n_slots; ++i) {
+              Slot& sl = slots[i];
+              if (!sl.lock || !(kind == 0 ? sl.wants : sl.wants_fit)) continue;
+              icpgpu_ctx* w = sl.w;
+              group_pack = sl.pack;
+              bool use_prev = false;
+              float4* buf = nullptr;
+              if (prev_neighbours(w, w->grid, w->src.data(), (int)w->src.n, grid_flags(w->grid, false), buf, use_prev) || buf != sl.prev) {
+                fail(w, ICPGPU_ERR_HIP, "lock-step batch: previous-neighbour buffer moved");
+                return failed(ICPGPU_ERR_HIP, sl.pair, w);
+              }
+              step.T[n_act] = to_xform(sl.run.final_T);
+              step.seq[n_act] = ++w->sums_seq;
+              step.slot[n_act] = (unsigned char)i;
+              if (use_prev) step.use_prev_mask |= 1u << n_act;
+              max_blocks = std::max(max_blocks, table[i].blocks);
+              sl.run.ticket = SweepTicket{};
+              sl.run.ticket.seq = step.seq[n_act];
+              sl.run.t_issue = std::chrono::steady_clock::now();
+              sl.wants = sl.wants_fit = false;
+              sl.waiting = true;
+              w->call_sweeps += 1;
+              w->prof.grid_launches += 1;
+              w->prof.reduce_launches += 1;
+              w->prof.grid_bytes += 16ull * ((uint64_t)w->src.n + (uint64_t)w->tgt.n) +
+                                    (kind == 0 ? 136ull * (uint64_t)table[i].blocks : 8ull * (uint64_t)w->src.n);
+              w->prof.reduce_bytes += kind == 0 ? 136ull * (uint64_t)table[i].blocks : 40ull * (uint64_t)w->src.n + 136;
+              if (kind == 1) {  // the ungated sweep's set-up, as sweep_issue / nn_keys_grid do it for one pair
+                sl.run.ticket.few_host = reinterpret_cast<volatile int*>(w->h_sums + 20);
+                *sl.run.ticket.few_host = -1;
+                sl.run.ticket.red_src = w->src.data();
+                sl.run.ticket.red_n = (int)w->src.n;
+                sl.run.ticket.T = step.T[n_act];
+                sl.run.ticket.thr = FLT_MAX;
+                if (hipMemsetAsync(table[i].unmatched_count, 0, sizeof(int), gstream) != hipSuccess) {
+                  fail(w, ICPGPU_ERR_HIP, "lock-step batch: memset");
+                  return failed(ICPGPU_ERR_HIP, sl.pair, w);
+                }
+              }
+              ++n_act;
+            }
+            if (n_act == 0) continue;
+            bt_steps += 1;
+            // kernel timing, sampled like the single-pair path's: a launch's HIP-event time / its pairs = one pair's sweep
+            auto take_timing = [&](bool wait) {
+              if (!timed_pairs) return;
+              if (wait) (void)hipEventSynchronize(lead->ev[3]);
+              else if (hipEventQuery(lead->ev[3]) != hipSuccess) return;
+              float ms = 0.f;
+              if (hipEventElapsedTime(&ms, lead->ev[2], lead->ev[3]) == hipSuccess) {
+                lead->prof.grid_ms += (double)ms;  // (summed over the launch's pairs: grid_ms / grid_timed stays "per pair and sweep")
+                lead->prof.grid_timed += (uint64_t)timed_pairs;
+              }
+              timed_pairs = 0;
+            };
+            take_timing(false);
+            const bool timed = kind == 0 && timed_pairs == 0 && (step_counter++ % 5u) == 0;
+            if (timed) (void)hipEventRecord(lead->ev[2], gstream);
+            const BatchPair* d_table = static_cast<const BatchPair*>(lead->batch_table.ptr);
+            hipError_t e = launch_nn_grid_search_batch(d_table, step, n_act, max_blocks, group_pack, kind == 1, gstream);
+            if (timed) {
+              (void)hipEventRecord(lead->ev[3], gstream);
+              timed_pairs = n_act;
+            }
+            if (e == hipSuccess && kind == 0) e = launch_reduce_final_batch(d_table, step, n_act, gstream);
+            if (e != hipSuccess) {
+              fail(lead, ICPGPU_ERR_HIP, "lock-step batch launch: %s", hipGetErrorString(e));
+              return failed(ICPGPU_ERR_HIP, slots[step.slot[0]].pair, lead);
+            }
+            if (kind == 1) {
+              // per pair: the few points the grid left unmatched (completed on the device), then the keys-path reduction into
+              // the pair's mailbox -- three small launches each, queued without waiting
+              for (int a2 = 0; a2 < n_act; ++a2) {
+                Slot& sl = slots[step.slot[a2]];
+                icpgpu_ctx* w = sl.w;
+                const BatchPair& bp = table[step.slot[a2]];
+                hipError_t e2 = launch_nn_brute_few(w->src.data(), bp.unmatched, bp.unmatched_count, 0, w->tgt.data(), (int)w->tgt.n,
+                                                    step.T[a2], bp.keys, reinterpret_cast<int*>(w->h_sums_dev + 20), gstream);
+                int rc2 = e2 == hipSuccess ? ensure(w, w->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)) : ICPGPU_ERR_HIP;
+                if (!rc2 && launch_reduce(w->src.data(), (int)w->src.n, w->tgt.data(), bp.keys, step.T[a2], FLT_MAX,
+                                          static_cast<double*>(w->partials.ptr), w->h_sums_dev, w->h_flags_dev, step.seq[a2], gstream) != hipSuccess)
+                  rc2 = ICPGPU_ERR_HIP;
+                if (rc2) {
+                  fail(w, rc2, "lock-step batch: fitness sweep");
+                  return failed(rc2, sl.pair, w);
+                }
+              }
+            }
+          }
+          // wait for something to come back, then take everything that has
+          bool progressed = false;
+          for (size_t i = 0; i < n_slots; ++i) {
+            Slot& sl = slots[i];
+            if (sl.run.phase != P2PRun::Iterating && sl.run.phase != P2PRun::Fitness) continue;
+            if (sl.lock && !sl.waiting) continue;  // its sweep has not been launched yet
+            if (!sweep_ready(sl.w, sl.run.ticket)) continue;
+            sl.waiting = false;
+            int deferred = 0;
+            const int rc = p2p_advance(sl.w, sl.run, (sl.lock && sl.run.phase == P2PRun::Iterating) ? &deferred : nullptr);
+            if (rc) return failed(rc, sl.pair, sl.w);
+            sl.wants = deferred == 1;
+            sl.wants_fit = deferred == 2;
+            if (sl.run.phase == P2PRun::Done) --live;
+            progressed = true;
+          }
+          if (progressed) {
+            idle_spins = 0;
+            continue;
+          }
+          if ((++idle_spins & 0x3FFu) == 0) {  // nothing moved for a while: a faulted or hung kernel must not keep us here
+            const auto now = std::chrono::steady_clock::now();
+            const hipError_t q = hipStreamQuery(gstream);
+            for (size_t i = 0; i < n_slots; ++i) {
+              Slot& sl = slots[i];
+              if (sl.run.phase != P2PRun::Iterating && sl.run.phase != P2PRun::Fitness) continue;
+              if (q != hipSuccess && q != hipErrorNotReady) {
+                fail(sl.w, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+                return failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+              }
+              if (std::chrono::duration<double, std::milli>(now - sl.run.t_issue).count() > timeout_ms) {
+                fail(sl.w, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", timeout_ms);
+                return failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+              }
+            }
+          }
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+        }
+        if (timed_pairs) {  // (the group is finished: its last timed launch is, too)
+          float ms = 0.f;
+          if (hipEventSynchronize(lead->ev[3]) == hipSuccess && hipEventElapsedTime(&ms, lead->ev[2], lead->ev[3]) == hipSuccess) {
+            lead->prof.grid_ms += (double)ms;
+            lead->prof.grid_timed += (uint64_t)timed_pairs;
+          }
+          timed_pairs = 0;
+        }
+        if (bt_on) {
+          const auto bt3 = std::chrono::steady_clock::now();
+          bt_fill += std::chrono::duration<double, std::milli>(bt1 - bt0).count();
+          bt_build += std::chrono::duration<double, std::milli>(bt2 - bt1).count();
+          bt_iter += std::chrono::duration<double, std::milli>(bt3 - bt2).count();
+          bt_groups += 1;
+        }
+      }
+    }
+    std::vector<P2PRun> runs(depth);
+    std::vector<size_t> pair_of(depth, 0);
+    bool exhausted = false;
+    for (unsigned idle_spins = 0;;) {
+      bool progressed = false;
+      size_t in_flight = 0;
+      for (size_t s = 0; s < depth; ++s) {
+        P2PRun& r = runs[s];
+        icpgpu_ctx* w = ws[s];
+        if (r.phase == P2PRun::Idle || r.phase == P2PRun::Done) {
+          if (exhausted || abort.load()) continue;
+          const size_t k = next.fetch_add(1);
+          if (k >= n_pairs) {
+            exhausted = true;
+            continue;
+          }
+          pair_of[s] = k;
+          int rc = load_pair(w, k);
+          if (!rc) rc = p2p_begin(w, r, nullptr, nullptr, want_fitness, &results[k]);
+          if (rc) return failed(rc, k, w);
+          progressed = true;
+          if (r.phase != P2PRun::Done) ++in_flight;
+        } else if (sweep_ready(w, r.ticket)) {
+          const int rc = p2p_advance(w, r);
+          if (rc) return failed(rc, pair_of[s], w);
+          progressed = true;
+          if (r.phase != P2PRun::Done) ++in_flight;
+        } else {
+          ++in_flight;
+        }
+      }
+      if (in_flight == 0 && (exhausted || abort.load())) return;
+      if (progressed) {
+        idle_spins = 0;
+        continue;
+      }
+      if ((++idle_spins & 0x3FFu) == 0) {  // nothing moved for a while: a faulted or hung kernel must not keep us here
+        const auto now = std::chrono::steady_clock::now();
+        for (size_t s = 0; s < depth; ++s) {
+          P2PRun& r = runs[s];
+          if (r.phase != P2PRun::Iterating && r.phase != P2PRun::Fitness) continue;
+          const hipError_t q = hipStreamQuery(ws[s]->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) {
+            fail(ws[s], ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+            return failed(ICPGPU_ERR_HIP, pair_of[s], ws[s]);
+          }
+          if (std::chrono::duration<double, std::milli>(now - r.t_issue).count() > timeout_ms) {
+            fail(ws[s], ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", timeout_ms);
+            return failed(ICPGPU_ERR_HIP, pair_of[s], ws[s]);
+          }
+        }
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+  work(0);
+  for (auto& th : threads) th.join();
+  for (size_t i = 0; i < n_ctx; ++i) {  // fold the workers' kernel accounting into the parent's profile
+    icpgpu_profile& p = c->workers[i]->prof;
+    c->prof.nn_launches += p.nn_launches; c->prof.nn_ms += p.nn_ms; c->prof.nn_pairs += p.nn_pairs; c->prof.nn_bytes += p.nn_bytes;
+    c->prof.reduce_launches += p.reduce_launches; c->prof.reduce_ms += p.reduce_ms; c->prof.reduce_bytes += p.reduce_bytes;
+    c->prof.transform_launches += p.transform_launches; c->prof.transform_ms += p.transform_ms; c->prof.transform_bytes += p.transform_bytes;
+    c->prof.iterations += p.iterations; c->prof.aligns += p.aligns;
+    c->prof.grid_launches += p.grid_launches; c->prof.grid_ms += p.grid_ms; c->prof.grid_bytes += p.grid_bytes;
+    c->prof.nn_timed += p.nn_timed; c->prof.grid_timed += p.grid_timed; c->prof.reduce_timed += p.reduce_timed;
+    c->prof.grid_bounded += p.grid_bounded;
+    c->prof.grid_builds += p.grid_builds; c->prof.grid_build_ms += p.grid_build_ms; c->prof.grid_fallback_points += p.grid_fallback_points;
+    c->prof.voxel_launches += p.voxel_launches; c->prof.voxel_ms += p.voxel_ms; c->prof.voxel_bytes += p.voxel_bytes;
+    c->prof.gicp_cov_launches += p.gicp_cov_launches; c->prof.gicp_cov_ms += p.gicp_cov_ms; c->prof.gicp_cost_launches += p.gicp_cost_launches;
+    c->prof.gicp_eval_ms += p.gicp_eval_ms; c->prof.gicp_eval_corr += p.gicp_eval_corr; c->prof.gicp_cov_points += p.gicp_cov_points;
+    c->prof.targets_recognised += p.targets_recognised;
+    c->prof.brute_bound_violations += p.brute_bound_violations;
+    if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;
+    std::memset(&p, 0, sizeof(p));
+  }
+  for (const ThreadError& e : errors)  // the first failure in thread order (each thread stops at its first)
+    if (e.code != ICPGPU_OK) {
+      c->err = "align_batch pair " + std::to_string(e.pair) + ": " + e.msg;
+      return e.code;
+    }
+  return ICPGPU_OK;
+}
+
+}  // extern "C"

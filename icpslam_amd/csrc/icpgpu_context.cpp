@@ -1,0 +1,557 @@
+// icpgpu_context.cpp -- the C-ABI of libicpgpu.so (include/icpgpu.h): context life cycle, parameters, clouds, profile.
+//
+// Host side of the hot path behind the PCL Registration protocol used at
+//   /root/reference/src/icpslam/icp_odometer.cpp:188-201 and src/icpslam/octree_mapper.cpp:104-117.
+// There is deliberately no CPU fallback: if HIP or the device is unusable every entry point fails loudly.
+#include "icp_ctx.h"
+
+
+namespace icpgpu_impl {
+
+thread_local std::string g_create_error;  // icpgpu_create failures (no context to carry the message yet)
+
+int fail(icpgpu_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+
+int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes) {
+  if (b.external) {
+    b.ptr = nullptr;
+    b.cap = 0;
+    b.external = false;
+  }
+  if (bytes <= b.cap) return ICPGPU_OK;
+  if (b.ptr) HIP_TRY(c, hipFree(b.ptr));
+  b.ptr = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4;  // amortise growth across scans of slightly different size
+  if (want < 256) want = 256;
+  HIP_TRY(c, hipMalloc(&b.ptr, want));
+  b.cap = want;
+  return ICPGPU_OK;
+}
+
+void release(DeviceBuf& b) {
+  if (b.ptr && !b.external) (void)hipFree(b.ptr);
+  b = DeviceBuf{};
+}
+
+Xform to_xform(const Mat4d& T) {
+  float f[16];
+  mat4_to_float(T, f);
+  Xform x;
+  for (int r = 0; r < 3; ++r) {
+    x.m[4 * r + 0] = f[0 * 4 + r];
+    x.m[4 * r + 1] = f[1 * 4 + r];
+    x.m[4 * r + 2] = f[2 * 4 + r];
+    x.m[4 * r + 3] = f[3 * 4 + r];
+  }
+  return x;
+}
+
+Xform to_xform(const float* T) {
+  Mat4d m;
+  for (int i = 0; i < 16; ++i) m[i] = T ? (double)T[i] : (i % 5 == 0 ? 1.0 : 0.0);
+  return to_xform(m);
+}
+
+// largest float f with (double)f <= r2, so that the device's float compare equals PCL's double compare
+float threshold_from(double r2) {
+  if (std::isnan(r2)) return NAN;
+  if (r2 >= (double)FLT_MAX) return FLT_MAX;
+  if (r2 < 0.0) return -1.0f;
+  float f = (float)r2;
+  if ((double)f > r2) f = std::nextafterf(f, -INFINITY);
+  return f;
+}
+
+unsigned long long sample_fingerprint(const float* xyzw, size_t n) {
+  unsigned long long s = 0;
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(xyzw);
+  const size_t m = n < 256 ? n : 256;
+  for (size_t k = 0; k < m; ++k) {
+    const size_t i = (k * n) / m;
+    unsigned long long w0, w1;
+    std::memcpy(&w0, b + 16 * i, 8);
+    std::memcpy(&w1, b + 16 * i + 8, 8);
+    s += fp_point(w0, w1, (unsigned long long)i);
+  }
+  return fp_finish(s, (unsigned long long)n);
+}
+
+int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync) {
+  if (n > 0 && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  int rc = ensure(c, cl.buf, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) {
+    HIP_TRY(c, hipMemcpyAsync(cl.buf.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (sync) HIP_TRY(c, hipStreamSynchronize(c->stream));  // the caller may free xyzw as soon as we return
+  }
+  cl.n = n;
+  cl.set = true;
+  cl.sample_valid = n > 0;
+  cl.sample_fp = n > 0 ? sample_fingerprint(xyzw, n) : 0;
+  return ICPGPU_OK;
+}
+
+int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
+  if (n > 0 && !d_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null device pointer with n = %zu", n);
+  if (((uintptr_t)d_xyzw & 15u) != 0) return fail(c, ICPGPU_ERR_INVALID_ARG, "device cloud must be 16-byte aligned");
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  release(cl.buf);
+  cl.buf.ptr = const_cast<void*>(d_xyzw);
+  cl.buf.external = true;
+  cl.n = n;
+  cl.set = true;
+  cl.sample_valid = false;
+  return ICPGPU_OK;
+}
+
+// ICPGPU_RECOGNISE=0: icpgpu_set_target always uploads (A/B measurements)
+static bool recognise_enabled() {
+  static const bool v = [] { const char* e = std::getenv("ICPGPU_RECOGNISE"); return !e || std::atoi(e) != 0; }();
+  return v;
+}
+
+// fingerprint of a cloud in HBM (cached per version): one small kernel + an 8-byte read-back
+int device_fingerprint(icpgpu_ctx* c, const Cloud& cl, uint64_t version, unsigned long long& cache, uint64_t& cache_version,
+                       unsigned long long* out) {
+  if (cache_version != version) {
+    int rc = ensure(c, c->fp_acc, sizeof(unsigned long long));
+    if (rc) return rc;
+    auto* d_acc = static_cast<unsigned long long*>(c->fp_acc.ptr);
+    HIP_TRY(c, launch_fingerprint(cl.data(), (int)cl.n, d_acc, c->stream));
+    unsigned long long sum = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_acc, sizeof sum, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(&sum, c->h_ints, sizeof sum);
+    cache = fp_finish(sum, (unsigned long long)cl.n);
+    cache_version = version;
+  }
+  *out = cache;
+  return ICPGPU_OK;
+}
+
+}  // namespace icpgpu_impl
+
+extern "C" {
+
+int icpgpu_version(void) { return ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR; }
+
+void icpgpu_default_params(icpgpu_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->method = ICPGPU_P2P_SVD;
+  p->max_iterations = 10;                    // icp_odometer.h:65
+  p->transformation_epsilon = 1e-6;          // icp_odometer.h:64
+  p->max_correspondence_distance = 1.0;      // icp_odometer.h:63
+  p->euclidean_fitness_epsilon = -DBL_MAX;   // PCL default
+  p->min_correspondences = 3;                // PCL default
+  p->force_iterations = 0;
+  p->nn_mode = ICPGPU_NN_AUTO;
+  p->brute_variant = 0;
+}
+
+int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
+  if (!out_ctx) return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "out_ctx is null");
+  *out_ctx = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "no HIP device available (%s); libicpgpu has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device_id < 0 || device_id >= count)
+    return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "device_id %d out of range [0, %d)", device_id, count);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device_id);
+  if (e != hipSuccess) return fail(nullptr, ICPGPU_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "device %d is %s; libicpgpu is built for gfx950 (MI355X) only", device_id,
+                prop.gcnArchName);
+
+  icpgpu_ctx* c = new (std::nothrow) icpgpu_ctx();
+  if (!c) return fail(nullptr, ICPGPU_ERR_OOM, "out of host memory");
+  c->device = device_id;
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  icpgpu_default_params(&c->params);
+  if (const char* v = std::getenv("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
+
+  auto bail = [&](const char* what, hipError_t err) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+    icpgpu_destroy(c);
+    return fail(nullptr, err == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "%s", msg.c_str());
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  for (auto& ev : c->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  // mailbox: 24 doubles the host keeps the current sums (and a few spare slots) in, then the 17 {sum, number} pairs the
+  // device writes (reduce_final_kernel)
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + 2 * kReduceTerms) * sizeof(double),
+                         hipHostMallocMapped | hipHostMallocCoherent)) !=  // fine-grained: the polled flags must become visible without a sync
+      hipSuccess)
+    return bail("hipHostMalloc", e);
+  std::memset(c->h_sums, 0, (24 + 2 * kReduceTerms) * sizeof(double));
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_sums_dev), c->h_sums, 0)) != hipSuccess)
+    return bail("hipHostGetDevicePointer", e);
+  c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
+  c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
+  {
+    const size_t n_flags_end = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8 + kGicpDirectBlocks;  // partials, gap, flags
+    const size_t cmd_off = (n_flags_end + 7) & ~(size_t)7;                                        // 64-byte aligned
+    const size_t n_d = cmd_off + 8;                                                              // + the server's command line
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_gicp), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
+        hipSuccess)
+      return bail("hipHostMalloc", e);
+    std::memset(c->h_gicp, 0, n_d * sizeof(double));
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_gicp_dev), c->h_gicp, 0)) != hipSuccess)
+      return bail("hipHostGetDevicePointer", e);
+    const size_t off = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8;
+    c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
+    c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
+    (void)cmd_off;
+  }
+  if (gicp_server_enabled()) {  // no such memory (no large BAR): the evaluations stay single launches
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_cmd), 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      c->gicp_cmd = nullptr;
+    } else if ((e = hipMemset(c->gicp_cmd, 0, 4096)) != hipSuccess) {
+      return bail("hipMemset", e);
+    }
+  }
+  c->ev_ring.assign((size_t)kEventRing * 3, nullptr);
+  for (auto& ev : c->ev_ring)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  c->pending.reserve(kEventRing);
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_ints), 16 * sizeof(int), hipHostMallocDefault)) != hipSuccess)
+    return bail("hipHostMalloc", e);
+  if ((e = hipMalloc(&c->partials.ptr, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double))) != hipSuccess)
+    return bail("hipMalloc(partials)", e);
+  c->partials.cap = (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double);
+  if ((e = hipMalloc(&c->sums.ptr, kReduceTerms * sizeof(double))) != hipSuccess) return bail("hipMalloc(sums)", e);
+  c->sums.cap = kReduceTerms * sizeof(double);
+  *out_ctx = c;
+  return ICPGPU_OK;
+}
+
+int icpgpu_destroy(icpgpu_ctx* c) {
+  if (c && c->pt_n)
+    fprintf(stderr, "[icpgpu] point-to-point sweeps waited for: %llu; per sweep: waiting for the sums %.2f us, sums -> sweep_issue (take, solve, "
+                    "convergence) %.2f us, sweep_issue up to the search launch %.2f us, the launch call %.2f us, the rest of sweep_issue "
+                    "(final-reduction launch, events) %.2f us\n",
+            c->pt_n, c->pt_wait / c->pt_n, c->pt_solve / c->pt_n, c->pt_prelaunch / c->pt_n, c->pt_launch / c->pt_n, c->pt_rest / c->pt_n);
+  if (c && c->gt_n)
+    fprintf(stderr, "[icpgpu] GICP evaluations through the server: %llu; per evaluation: command write %.2f us, wait for the flags %.2f us "
+                    "(device: polling %.2f us, work %.2f us), merge %.2f us, solver between evaluations %.2f us\n",
+            c->gt_n, c->gt_cmd / c->gt_n, c->gt_wait / c->gt_n, c->gt_dev_wait / c->gt_n, c->gt_dev_work / c->gt_n, c->gt_merge / c->gt_n,
+            c->gt_between / c->gt_n);
+  if (!c) return ICPGPU_OK;
+  for (icpgpu_ctx* w : c->workers) icpgpu_destroy(w);
+  c->workers.clear();
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  release(c->src.buf);
+  release(c->tgt.buf);
+  release(c->keys);
+  release(c->partials);
+  release(c->sums);
+  release(c->out);
+  for (GridIndex* G : {&c->cov_grid_src, &c->cov_grid_tgt}) {
+    release(G->sorted);
+    release(G->cell_start);
+    release(G->cell_of_point);
+    release(G->rank);
+    release(G->block_sums);
+    release(G->ints);
+    release(G->unmatched);
+    release(G->leftover);
+  }
+  release(c->cov_src);
+  release(c->cov_tgt);
+  release(c->maha);
+  release(c->vox_in);
+  release(c->vox_out);
+  release(c->vox_keys);
+  release(c->vox_vals);
+  release(c->vox_flags);
+  release(c->vox_slots);
+  release(c->vox_temp);
+  release(c->vox_ints);
+  release(c->vox_bins);
+  release(c->vox_pub);
+  release(c->idx);
+  release(c->d2);
+  release(c->brute_seed.keys);
+  release(c->brute_order.pts);
+  release(c->brute_order.work);
+  release(c->brute_order.check);
+  release(c->tile_seed.keys);
+  release(c->tile_seed.stats);
+  release(c->tile_seed.prev);
+  release(c->fp_acc);
+  release(c->batch_table);
+  release(c->map.node_keys);
+  release(c->map.node_vals);
+  if (c->cand_counter.ptr) grid_count_candidates(nullptr);
+  release(c->cand_counter);
+  for (DeviceBuf* b : {&c->map.pts.buf, &c->map.keys, &c->map.vals, &c->map.first, &c->map.staged, &c->map.moved, &c->map.slot_of,
+                       &c->map.flags, &c->map.rank, &c->map.temp, &c->map.counter, &c->map.nn_keys, &c->map.first_user,
+                       &c->map.uflags, &c->map.urank, &c->map.uniq_index, &c->map.uniq.buf})
+    release(*b);
+  for (GridIndex* G : {&c->grid, &c->src_grid, &c->map.grid}) {
+    release(G->sorted);
+    release(G->cell_start);
+    release(G->cell_of_point);
+    release(G->rank);
+    release(G->block_sums);
+    release(G->ints);
+    release(G->unmatched);
+    release(G->leftover);
+  }
+  if (c->h_sums) (void)hipHostFree(c->h_sums);
+  if (c->h_gicp) (void)hipHostFree(c->h_gicp);
+  if (c->gicp_cmd) (void)hipFree(c->gicp_cmd);
+  if (c->h_ints) (void)hipHostFree(c->h_ints);
+  for (auto& ev : c->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_ring)
+    if (ev) (void)hipEventDestroy(ev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ICPGPU_OK;
+}
+
+const char* icpgpu_last_error(const icpgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* p) {
+  if (!c || !p) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (p->method != ICPGPU_P2P_SVD && p->method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad method");
+  if (p->nn_mode < ICPGPU_NN_AUTO || p->nn_mode > ICPGPU_NN_GRID) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad nn_mode");
+  if (p->brute_variant < 0 || p->brute_variant > 2) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad brute_variant");
+  c->params = *p;
+  return ICPGPU_OK;
+}
+
+int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
+  if (!c || !p) return ICPGPU_ERR_INVALID_ARG;
+  *p = c->params;
+  return ICPGPU_OK;
+}
+
+
+int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
+  ENTER(c);
+  c->src_version++;
+  return set_cloud_host(c, c->src, xyzw, n);
+}
+
+// setInputTarget from a host buffer.  The reference's odometer hands over, as the target of scan k, the cloud it handed
+// over as the source of scan k - 1 (`*prev_cloud_ = *curr_cloud_`, icp_odometer.cpp:209, then :194 on the next scan) -- a
+// fresh registration object cannot know that, the context can: when the buffer has the size of a cloud it already holds
+// it compares content fingerprints (one pass over the host buffer, ~0.1 ms per MB, + one 8-byte read-back) and
+//   * keeps the current target with its grid and GICP covariances when the content is the same (a rejected scan keeps
+//     prev_cloud_: icp_odometer.cpp:201-210), or
+//   * takes the promote path when it is the current SOURCE's content (no upload, grid and covariances carried over).
+// Results are identical either way: the target cloud in HBM holds the same bits.  External (zero-copy) buffers never take
+// part.  Callers that replace the source in the same step must set the target FIRST (the C++ shim does).
+int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
+  ENTER(c);
+  if (recognise_enabled() && n > 0 && xyzw) {
+    bool tgt_cand = c->tgt.set && c->tgt.n == n && !c->tgt.buf.external;
+    bool src_cand = c->src.set && c->src.n == n && !c->src.buf.external;
+    if ((tgt_cand && c->tgt.sample_valid) || (src_cand && c->src.sample_valid)) {  // a microsecond's look before the real one
+      const unsigned long long sf = sample_fingerprint(xyzw, n);
+      if (tgt_cand && c->tgt.sample_valid && c->tgt.sample_fp != sf) tgt_cand = false;
+      if (src_cand && c->src.sample_valid && c->src.sample_fp != sf) src_cand = false;
+    }
+    if (tgt_cand || src_cand) {
+      const unsigned long long fp = icpgpu_fingerprint(xyzw, n);
+      unsigned long long have = 0;
+      int rc;
+      if (tgt_cand) {
+        if ((rc = device_fingerprint(c, c->tgt, c->tgt_version, c->tgt_fp, c->tgt_fp_version, &have))) return rc;
+        if (have == fp) {
+          c->prof.targets_recognised += 1;
+          return ICPGPU_OK;
+        }
+      }
+      if (src_cand) {
+        if ((rc = device_fingerprint(c, c->src, c->src_version, c->src_fp, c->src_fp_version, &have))) return rc;
+        if (have == fp) {
+          c->prof.targets_recognised += 1;
+          rc = promote_internal(c);
+          if (rc != ICPGPU_OK) return rc;
+          c->tgt_fp = fp;
+          c->tgt_fp_version = c->tgt_version;
+          // set_target must not take the source away (a caller may set the SAME cloud as source and target, or set the source
+          // first): the source is put back as a device-to-device copy of what is now the target -- microseconds, and the
+          // odometer's next set_source overwrites it anyway.  Its cell order / covariances moved on with the target.
+          if ((rc = ensure(c, c->src.buf, n * sizeof(float4)))) return rc;
+          HIP_TRY(c, hipMemcpyAsync(c->src.buf.ptr, c->tgt.buf.ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+          c->src.n = n;
+          c->src.set = true;
+          c->src.sample_fp = c->tgt.sample_fp;  // the copy IS the target's content
+          c->src.sample_valid = c->tgt.sample_valid;
+          c->src_fp = fp;
+          c->src_fp_version = c->src_version;
+          return ICPGPU_OK;
+        }
+      }
+      c->tgt_version++;
+      rc = set_cloud_host(c, c->tgt, xyzw, n);
+      if (rc == ICPGPU_OK) {  // what was just uploaded has the fingerprint just computed
+        c->tgt_fp = fp;
+        c->tgt_fp_version = c->tgt_version;
+      }
+      return rc;
+    }
+  }
+  c->tgt_version++;
+  return set_cloud_host(c, c->tgt, xyzw, n);
+}
+int icpgpu_set_source_device(icpgpu_ctx* c, const void* d, size_t n) {
+  ENTER(c);
+  c->src_version++;
+  return set_cloud_device(c, c->src, d, n);
+}
+int icpgpu_set_target_device(icpgpu_ctx* c, const void* d, size_t n) {
+  ENTER(c);
+  c->tgt_version++;
+  return set_cloud_device(c, c->tgt, d, n);
+}
+
+int icpgpu_promote_source_to_target(icpgpu_ctx* c) {
+  ENTER(c);
+  return promote_internal(c);
+}
+
+unsigned long long icpgpu_fingerprint(const float* xyzw, size_t n) {
+  unsigned long long s0 = 0, s1 = 0;
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(xyzw);
+  for (size_t i = 0; i < n; ++i) {  // (two independent multiply chains per point: ~5 GB/s on one core)
+    unsigned long long w0, w1;
+    std::memcpy(&w0, b + 16 * i, 8);
+    std::memcpy(&w1, b + 16 * i + 8, 8);
+    s0 += fp_mix(w0 + 0x9e3779b97f4a7c15ull * (2ull * i + 1ull));
+    s1 += fp_mix(w1 ^ (0xd6e8feb86659fd93ull * (2ull * i + 2ull)));
+  }
+  return fp_finish(s0 + s1, (unsigned long long)n);
+}
+
+int icpgpu_cloud_sizes(const icpgpu_ctx* c, size_t* n_source, size_t* n_target) {
+  if (!c) return ICPGPU_ERR_INVALID_ARG;
+  if (n_source) *n_source = c->src.set ? c->src.n : 0;
+  if (n_target) *n_target = c->tgt.set ? c->tgt.n : 0;
+  return ICPGPU_OK;
+}
+
+}  // extern "C"
+namespace icpgpu_impl {
+int promote_internal(icpgpu_ctx* c) {
+  if (!c->src.set) return fail(c, ICPGPU_ERR_NO_INPUT, "promote_source_to_target: no source set");
+  std::swap(c->src, c->tgt);
+  c->tgt_fp = c->src_fp;  // (versions are re-stamped below)
+  const bool fp_follows = c->src_fp_version == c->src_version;
+  // the source's GICP covariances stay valid for the cloud that is now the target
+  std::swap(c->cov_src, c->cov_tgt);
+  std::swap(c->cov_grid_src, c->cov_grid_tgt);
+  // ... and so does its cell order: it is the new target's grid
+  std::swap(c->grid, c->src_grid);
+  const bool grid_follows = c->grid.built && c->grid.version == c->src_version;
+  c->tgt_version++;
+  c->tgt_fp_version = fp_follows ? c->tgt_version : 0;
+  c->src_fp_version = 0;
+  if (grid_follows) c->grid.version = c->tgt_version;
+  else c->grid.built = c->grid.usable = false;
+  c->src_grid.built = c->src_grid.usable = false;
+  c->cov_tgt_version = (c->cov_src_version == c->src_version) ? c->tgt_version : 0;
+  c->cov_src_version = 0;
+  c->src_version++;
+  c->src.n = 0;
+  c->src.set = false;
+  c->src.sample_valid = false;  // (the swap left the old target's sample here)
+  if (c->src.buf.external) c->src.buf = DeviceBuf{};
+  c->have_final = false;
+  return ICPGPU_OK;
+}
+}  // namespace icpgpu_impl
+extern "C" {
+
+int icpgpu_profile_reset(icpgpu_ctx* c) {
+  if (!c) return ICPGPU_ERR_INVALID_ARG;
+  (void)resolve_sweep_timings(c);
+  std::memset(&c->prof, 0, sizeof(c->prof));
+  return ICPGPU_OK;
+}
+
+int icpgpu_profile_set_sampling(icpgpu_ctx* c, int every) {
+  if (!c || every < 1) return ICPGPU_ERR_INVALID_ARG;
+  c->timing_every = every;
+  c->sweep_counter = 0;
+  for (icpgpu_ctx* w : c->workers) {
+    w->timing_every = every;
+    w->sweep_counter = 0;
+  }
+  return ICPGPU_OK;
+}
+
+int icpgpu_profile_get(icpgpu_ctx* c, icpgpu_profile* out) {
+  if (!c || !out) return ICPGPU_ERR_INVALID_ARG;
+  int rc = resolve_sweep_timings(c);
+  if (rc) return rc;
+  *out = c->prof;
+  return ICPGPU_OK;
+}
+
+int icpgpu_get_stream(icpgpu_ctx* c, void** out_stream) {
+  if (!c || !out_stream) return ICPGPU_ERR_INVALID_ARG;
+  *out_stream = static_cast<void*>(c->stream);
+  return ICPGPU_OK;
+}
+
+int icpgpu_synchronize(icpgpu_ctx* c) {
+  ENTER(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ICPGPU_OK;
+}
+
+int icpgpu_count_candidates(icpgpu_ctx* c, int enable) {
+  ENTER(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (enable) {
+    int rc = ensure(c, c->cand_counter, sizeof(unsigned long long));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->cand_counter.ptr, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    grid_count_candidates(static_cast<unsigned long long*>(c->cand_counter.ptr));
+  } else {
+    grid_count_candidates(nullptr);
+  }
+  return ICPGPU_OK;
+}
+
+int icpgpu_count_candidates_read(icpgpu_ctx* c, uint64_t* out) {
+  ENTER(c);
+  if (!out) return fail(c, ICPGPU_ERR_INVALID_ARG, "out is null");
+  if (!c->cand_counter.ptr) return fail(c, ICPGPU_ERR_NO_INPUT, "count_candidates_read: counting was never enabled on this context");
+  unsigned long long v = 0;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(&v, c->cand_counter.ptr, sizeof(v), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemset(c->cand_counter.ptr, 0, sizeof(v)));
+  *out = (uint64_t)v;
+  return ICPGPU_OK;
+}
+
+
+}  // extern "C"

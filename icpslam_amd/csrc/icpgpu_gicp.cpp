@@ -1,0 +1,399 @@
+// icpgpu_gicp.cpp -- GICP mode behind icpgpu_align (pcl::GeneralizedIterativeClosestPoint, what the reference instantiates at
+// icp_odometer.cpp:188 and octree_mapper.cpp:104; kernels: icp_gicp.hip, solver: icp_gicp_solver.cpp).
+#include "icp_ctx.h"
+
+
+namespace icpgpu_impl {
+
+// ---- GICP mode: pcl::GeneralizedIterativeClosestPoint::computeTransformation ----------------------
+void mat4f_identity(float m[16]) {
+  for (int i = 0; i < 16; ++i) m[i] = (i % 5 == 0) ? 1.f : 0.f;
+}
+void mat4f_mul(const float a[16], const float b[16], float out[16]) {  // column-major, float accumulate (Eigen Matrix4f)
+  float r[16];
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 4; ++row) {
+      float s = 0.f;
+      for (int k = 0; k < 4; ++k) s += a[k * 4 + row] * b[col * 4 + k];
+      r[col * 4 + row] = s;
+    }
+  std::memcpy(out, r, sizeof(r));
+}
+Xform xform_from_f16(const float f[16]) {
+  Xform x;
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 4; ++cc) x.m[4 * r + cc] = f[cc * 4 + r];
+  return x;
+}
+
+// per-point covariances of `cloud` (20-NN in its own grid); cached per cloud version
+int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version) {
+  if (cov_version == version && cov.ptr) return ICPGPU_OK;
+  // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
+  const double cut = std::max(1e-3, c->params.max_correspondence_distance);
+  static const double knn_pop = [] { const char* e = std::getenv("ICPGPU_KNN_POP"); return e ? std::atof(e) : 8.0; }();
+  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G, nullptr, knn_pop);
+  if (rc) return rc;
+  if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
+  if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_gicp_covariances(cloud.data(), (int)cloud.n, static_cast<const float4*>(G.sorted.ptr),
+                                     static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+  c->prof.gicp_cov_launches += 1;
+  c->prof.gicp_cov_ms += ms;
+  c->prof.gicp_cov_points += (uint64_t)cloud.n;
+  cov_version = version;
+  return ICPGPU_OK;
+}
+
+// (hi, lo) += (bh, bl): the cascaded double-double merge of icp_gicp.hip (TwoSum on the high parts, the small parts in
+// plain float64)
+static inline void gicp_dd_add(double& hi, double& lo, double bh, double bl) {
+  const double s = hi + bh;
+  const double bb = s - hi;
+  const double e = (hi - (s - bb)) + (bh - bb);
+  hi = s;
+  lo = (lo + bl) + e;
+}
+
+// ---- the resident evaluation server of a BFGS run (gicp_server_kernel) ---------------------------------------------
+// A command is four 16-byte chunks {3 floats of T, sequence number}; each chunk is ONE aligned 16-byte store, so the
+// device never sees half a chunk, and it acts once all four carry the number it waits for.
+static void gicp_server_command(icpgpu_ctx* c, unsigned int seq, const Xform& T) {
+#if defined(__x86_64__)
+  // T first, the number last, a store fence in between and behind: posted writes reach the device in that order
+  volatile unsigned int* line = c->gicp_cmd;
+  for (int k = 0; k < 12; ++k) {
+    unsigned int w;
+    std::memcpy(&w, &T.m[k], sizeof w);
+    line[k] = w;
+  }
+  _mm_sfence();
+  line[12] = seq;
+  _mm_sfence();
+#else
+  (void)c; (void)seq; (void)T;
+#endif
+}
+
+// Start the server for the evaluations numbered sums_seq + 1, + 2, ... (queued behind whatever the stream still holds).
+static int gicp_server_start(icpgpu_ctx* c, int n_s, const unsigned long long* keys, float thr, const Xform& base,
+                             const double* maha) {
+  c->gicp_server_on = false;
+  if (!c->gicp_cmd || !c->gicp_server_allowed) return ICPGPU_OK;
+  unsigned int next = (unsigned int)(c->sums_seq + 1);
+  if (next == kGicpServerExit || next == 0u) {  // keep the two reserved numbers out of the run's first command
+    c->sums_seq += 2;
+    next = (unsigned int)(c->sums_seq + 1);
+  }
+  Xform none{};
+  gicp_server_command(c, next - 1u, none);  // a number the server does not wait for: the line may still hold an old exit
+  HIP_TRY(c, launch_gicp_server(gicp_direct_blocks(n_s, c->gicp_blocks_most), c->src.data(), n_s, c->tgt.data(), keys, thr, base, maha, c->h_gicp_dev, c->h_gicp_flags_dev,
+                                c->gicp_cmd, next, (unsigned int)((c->sums_seq + 1) >> 32), c->stream));
+  c->gicp_server_on = true;
+  return ICPGPU_OK;
+}
+
+static void gicp_server_stop(icpgpu_ctx* c) {
+  if (!c->gicp_server_on) return;
+  Xform none{};
+  gicp_server_command(c, kGicpServerExit, none);
+  c->gicp_server_on = false;
+  // wait for the poller's acknowledgement (a few microseconds): the command line is about to be reused
+  for (unsigned spins = 1; c->h_gicp_flags[0] != ~0ull; ++spins) {
+    if ((spins & 0x3FFu) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) break;  // gone already (or an error: the caller's next call reports it)
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+}
+
+// 0: the flags arrived; 1: the stream went idle without them (the server gave up waiting); < 0: error
+// The entries a block publishes (icp_kernels.h: {value, tag} pairs): m, the 13 sums' high parts, sum d2, their low parts.
+static const int kGicpEntries[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
+static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
+  const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(mailbox);
+  bool all = true;
+  for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
+    for (int e : kGicpEntries) all = all && (w[2 * e + 1] == seq);
+  return all;
+}
+// 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
+static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, bool server) {
+  std::chrono::steady_clock::time_point t0;
+  for (unsigned spins = 1;; ++spins) {
+    if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) break;
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) break;
+        if (server) return 1;
+        return fail(c, ICPGPU_ERR_HIP, "GICP evaluation finished without publishing its result");
+      }
+      if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a GICP evaluation: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a GICP evaluation (hung kernel?)", wait_timeout_ms());
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
+int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+  struct ServerGuard {  // whatever way this function is left, no server stays behind
+    icpgpu_ctx* c;
+    ~ServerGuard() { gicp_server_stop(c); }
+  } server_guard{c};
+  const auto t_start = std::chrono::steady_clock::now();
+  init_result(res);
+  c->prof.aligns += 1;
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  const icpgpu_params& P = c->params;
+  c->prev.valid = c->tile_seed.valid = false;  // every alignment starts cold
+  float guess[16];
+  if (guess_in) std::memcpy(guess, guess_in, sizeof(guess));
+  else mat4f_identity(guess);
+
+  auto finish_early = [&]() {  // empty target / clouds smaller than k_correspondences_: PCL leaves converged_ = false, T = I
+    c->final_T = mat4_identity();
+    c->have_final = true;
+    int rc = write_output_cloud(c, to_xform(c->final_T), out_xyzw);
+    res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    return rc;
+  };
+  if (n_t == 0 || n_s < kGicpK || n_t < kGicpK) return finish_early();
+
+  int rc;
+  if ((rc = ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version))) return rc;
+  if ((rc = ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version))) return rc;
+  // GICP keeps d2 < r^2 (strict): the largest float below r^2
+  const double r2 = P.max_correspondence_distance * P.max_correspondence_distance;
+  float thr = threshold_from(r2);
+  if ((double)thr >= r2) thr = std::nextafterf(thr, -INFINITY);
+  const float thr_excl = std::nextafterf(thr, INFINITY);  // d2 < thr_excl  <=>  d2 <= thr
+  if ((rc = ensure_grid(c, thr))) return rc;
+  if ((rc = ensure(c, c->keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(c, c->maha, (size_t)n_s * 6 * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  auto* maha = static_cast<double*>(c->maha.ptr);
+  const Xform base = xform_from_f16(guess);
+
+  float transformation[16], previous[16];
+  mat4f_identity(transformation);
+  mat4f_identity(previous);
+  int nr = 0, state = ICPGPU_NOT_CONVERGED;
+  bool converged = false;
+  unsigned n_corr = 0;
+  double mse = 0.0, dev_ms = 0.0;
+  const double rot_eps = 2e-3;  // PCL rotation_epsilon_ (never set by the reference)
+
+  while (!converged) {
+    float TG[16];
+    mat4f_mul(transformation, guess, TG);
+    const Xform Tq = xform_from_f16(TG);
+    Rot3d R;
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) {
+        double s = 0.0;
+        for (int k = 0; k < 4; ++k) s += (double)transformation[k * 4 + r] * (double)guess[cc * 4 + k];
+        R.m[3 * r + cc] = s;
+      }
+    // correspondences: exact NN keys (only those with d2 < r^2 are used, so the grid's cutoff search is complete)
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (grid_ready(c)) {
+      float4* prev = nullptr;  // each outer iteration's neighbours bound the next one's search
+      bool use_prev = false;
+      int prc = prev_neighbours(c, c->grid, c->src.data(), n_s, grid_flags(c->grid, false), prev, use_prev);
+      if (prc) return prc;
+      HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, grid_flags(c->grid, false), Tq, static_cast<const float4*>(c->grid.sorted.ptr),
+                                       static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, keys, nullptr, nullptr,
+                                       nullptr, c->stream, prev, use_prev));
+    } else {
+      if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
+    }
+    HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                       static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+
+    // rigid_transformation_estimation_: BFGS over x = (t, roll, pitch, yaw), every evaluation one reduction on the device
+    double m_count = 0.0;
+    auto eval = [&](const Vec6& x, bool want_gradient, GicpEval& out) -> bool {
+      float T[16];
+      std::memcpy(T, guess, sizeof(T));
+      gicp_apply_state(T, x);
+      // ~300 evaluations per align, each a dependent launch: ONE kernel of a few workgroups whose partial sums land in the
+      // polled host mailbox; the host adds them in workgroup order (deterministic)
+      const auto t_eval0 = std::chrono::steady_clock::now();
+      unsigned long long seq = ++c->sums_seq;
+      if ((unsigned int)seq == kGicpServerExit) seq = (c->sums_seq += 2);  // (never a command number; the server skips it too)
+      const int nblk = gicp_direct_blocks(n_s, c->gicp_blocks_most);
+      bool have = false;
+      static const bool timing = [] { const char* e = std::getenv("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
+      std::chrono::steady_clock::time_point tq0, tq1, tq2;
+      if (timing) {
+        tq0 = std::chrono::steady_clock::now();
+        if (c->gt_n && c->gicp_server_on) c->gt_between += std::chrono::duration<double, std::micro>(tq0 - c->gt_last).count();
+      }
+      if (c->gicp_server_on) {  // the resident server evaluates; no launch
+        gicp_server_command(c, (unsigned int)seq, xform_from_f16(T));
+        if (timing) tq1 = std::chrono::steady_clock::now();
+        const int w = wait_gicp_tags(c, nblk, seq, /*server=*/true);
+        if (timing) tq2 = std::chrono::steady_clock::now();
+        if (w < 0) return false;
+        have = w == 0;
+        if (!have) c->gicp_server_on = false;  // it gave up (50 ms without a command): single launches from here on
+        if (!have && std::getenv("ICPGPU_DEBUG")) fprintf(stderr, "[icpgpu] gicp server gave up at evaluation %llu\n", seq);
+      }
+      if (!have) {
+        if (launch_gicp_cost_direct(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
+                                    c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
+          return false;
+        if (wait_gicp_tags(c, nblk, seq, /*server=*/false) != 0) return false;
+      }
+      {  // workgroup by workgroup, in double-double like the kernel (icp_gicp.hip): the 13 sums are rounded once, here
+        double m = 0.0, d2 = 0.0, hi[13] = {}, lo[13] = {};
+        const double* part = c->h_gicp;
+        for (int b = 0; b < nblk; ++b, part += kGicpPartialStride) {  // (entry e = doubles [2e] value, [2e + 1] tag)
+          m += part[0];
+          d2 += part[2 * 14];
+          for (int k = 0; k < 13; ++k) gicp_dd_add(hi[k], lo[k], part[2 * (1 + k)], part[2 * (16 + k)]);
+        }
+        c->h_sums[0] = m;
+        c->h_sums[14] = d2;
+        for (int k = 0; k < 13; ++k) c->h_sums[1 + k] = hi[k] + lo[k];
+      }
+      if (timing && have) {
+        const auto tq3 = std::chrono::steady_clock::now();
+        c->gt_cmd += std::chrono::duration<double, std::micro>(tq1 - tq0).count();
+        c->gt_wait += std::chrono::duration<double, std::micro>(tq2 - tq1).count();
+        c->gt_merge += std::chrono::duration<double, std::micro>(tq3 - tq2).count();
+        c->gt_dev_wait += c->h_gicp[2 * 30];   // block 0's stamps (icp_gicp.hip): polling, then work, in microseconds
+        c->gt_dev_work += c->h_gicp[2 * 31];
+        c->gt_n += 1;
+        c->gt_last = tq3;
+      }
+      c->prof.gicp_cost_launches += 1;
+      c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_eval0).count();
+      const double* s = c->h_sums;
+      c->prof.gicp_eval_corr += (uint64_t)s[0];
+      m_count = s[0];
+      mse = s[0] > 0 ? s[14] / s[0] : 0.0;
+      if (!(s[0] >= 1.0)) {
+        out.f = 0.0;
+        out.g.fill(0.0);
+        return true;
+      }
+      out.f = s[1] / s[0];
+      if (want_gradient) {
+        const double sc = 2.0 / s[0];
+        double Rm[9];
+        for (int k = 0; k < 3; ++k) out.g[k] = s[2 + k] * sc;
+        for (int k = 0; k < 9; ++k) Rm[k] = s[5 + k] * sc;
+        gicp_rotation_gradient(x, Rm, out.g);
+      }
+      return true;
+    };
+    // the ~35 dependent evaluations of this outer iteration go to a resident kernel (queued behind the two kernels above)
+    if ((rc = gicp_server_start(c, n_s, keys, thr_excl, base, maha))) return rc;
+    // number of correspondences (one evaluation at the current state; it is also the BFGS start, cached by the solver)
+    Vec6 x = gicp_state_from_matrix(transformation);
+    GicpEval probe;
+    if (!eval(x, true, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+    n_corr = (unsigned)m_count;
+    std::memcpy(previous, transformation, sizeof(previous));
+    if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+      state = ICPGPU_CONV_NO_CORRESPONDENCES;
+      break;
+    }
+    const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
+    gicp_server_stop(c);
+    if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+    if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
+      state = ICPGPU_NOT_CONVERGED;
+      break;
+    }
+    mat4f_identity(transformation);
+    gicp_apply_state(transformation, x);
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    dev_ms += ms;
+    c->prof.grid_launches += grid_ready(c) ? 1 : 0;
+    c->prof.grid_ms += grid_ready(c) ? ms : 0.0;
+    double delta = 0.0;
+    for (int k = 0; k < 4; ++k)
+      for (int l = 0; l < 4; ++l) {
+        const double ratio = (k < 3 && l < 3) ? 1.0 / rot_eps : 1.0 / P.transformation_epsilon;
+        delta = std::max(delta, ratio * std::fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]));
+      }
+    ++nr;
+    c->prof.iterations += 1;
+    if (nr >= P.max_iterations || (delta < 1 && !P.force_iterations)) {
+      converged = true;
+      state = nr >= P.max_iterations ? ICPGPU_CONV_ITERATIONS : ICPGPU_CONV_TRANSFORM;
+      std::memcpy(previous, transformation, sizeof(previous));
+    }
+  }
+  // PCL's own composition of the result: R = previous.R * guess.R, t = previous.t + guess.t
+  float fin[16];
+  mat4f_identity(fin);
+  for (int r = 0; r < 3; ++r) {
+    for (int cc = 0; cc < 3; ++cc) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += previous[k * 4 + r] * guess[cc * 4 + k];
+      fin[cc * 4 + r] = s;
+    }
+    fin[12 + r] = previous[12 + r] + guess[12 + r];
+  }
+  std::memcpy(res->T, fin, sizeof(fin));
+  for (int i = 0; i < 16; ++i) c->final_T[i] = (double)fin[i];
+  c->have_final = true;
+  res->converged = converged ? 1 : 0;
+  res->iterations = nr;
+  res->convergence_state = state;
+  res->n_correspondences = n_corr;
+  res->mse_last = mse;
+  const Xform Tf = xform_from_f16(fin);
+  if (want_fitness) {
+    if ((rc = resolve_sweep_timings(c))) return rc;
+    c->dev_ms_accum = 0.0;
+    if ((rc = nn_and_reduce(c, Tf, FLT_MAX, true))) return rc;
+    if ((rc = resolve_sweep_timings(c))) return rc;
+    dev_ms += c->dev_ms_accum;  // 0 when this sweep was not a timed one
+    res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
+  }
+  if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
+  res->t_device_ms = dev_ms;
+  res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+  return ICPGPU_OK;
+}
+
+}  // namespace icpgpu_impl
+
+extern "C" {
+
+int icpgpu_gicp_covariances(icpgpu_ctx* c, int of_target, double* out6) {
+  ENTER(c);
+  Cloud& cl = of_target ? c->tgt : c->src;
+  if (!cl.set) return fail(c, ICPGPU_ERR_NO_INPUT, "gicp_covariances: cloud not set");
+  if (cl.n && !out6) return fail(c, ICPGPU_ERR_INVALID_ARG, "null output");
+  if (cl.n < (size_t)kGicpK) return fail(c, ICPGPU_ERR_INVALID_ARG, "GICP needs at least %d points per cloud", kGicpK);
+  int rc = of_target ? ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version)
+                     : ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version);
+  if (rc) return rc;
+  const DeviceBuf& cov = of_target ? c->cov_tgt : c->cov_src;
+  HIP_TRY(c, hipMemcpyAsync(out6, cov.ptr, cl.n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ICPGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// icpgpu_voxel.cpp -- host side of the voxel-grid filter (pcl::VoxelGrid as called at icp_odometer.cpp:96-101; kernels: icp_voxel.hip).
+#include "icp_ctx.h"
+
+
+namespace icpgpu_impl {
+
+// pcl::VoxelGrid<PointXYZ>::filter on a device-resident cloud (icp_odometer.cpp:96-101). out receives *n_out points
+// (ascending cell index). *passthrough = PCL's "leaf size too small for the input dataset" case: input returned as is.
+int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough) {
+  *n_out = 0;
+  *passthrough = false;
+  if (!(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel filter: leaf size must be positive");
+  if (n <= 0) return ICPGPU_OK;
+  int rc = ensure(c, c->vox_ints, 16 * sizeof(int));
+  if (rc) return rc;
+  int* d_ints = static_cast<int*>(c->vox_ints.ptr);
+  HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float lo[3], hi[3];
+  decode_bbox(c->h_ints, lo, hi);
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
+  const float inv = 1.0f / leaf;  // PCL: inverse_leaf_size_ = 1 / leaf_size_ in float
+  int minb[3], divb[3];
+  long long d[3];
+  for (int a = 0; a < 3; ++a) {
+    d[a] = (long long)((hi[a] - lo[a]) * inv) + 1;
+    minb[a] = (int)std::floor(lo[a] * inv);
+    divb[a] = (int)std::floor(hi[a] * inv) - minb[a] + 1;
+  }
+  if ((rc = ensure(c, out, (size_t)n * sizeof(float4)))) return rc;
+  if (d[0] * d[1] * d[2] > (long long)INT32_MAX) {  // PCL warns and returns the input unchanged
+    HIP_TRY(c, hipMemcpyAsync(out.ptr, d_in, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    *passthrough = true;
+    return ICPGPU_OK;
+  }
+  if ((rc = ensure(c, c->vox_keys, (size_t)2 * n * sizeof(int)))) return rc;
+  if ((rc = ensure(c, c->vox_vals, (size_t)2 * n * sizeof(int)))) return rc;
+  float ms = 0.f;
+  // the direct path (one distribution pass + a sort in LDS): every cloud up to 2M points; it reports the rare cloud it cannot
+  // take (thousands of points in one voxel) through `status`, and the library-sort path runs instead
+  static const bool force_sort = [] { const char* e = std::getenv("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
+  bool done = false;
+  // (PCL's overflow test uses the float extents, its cell index the integer ones: when these are one cell wider the index of
+  // the topmost cells can wrap in int32 and PCL -- and the sort path, on signed keys -- puts them first.  The direct path's
+  // buckets assume keys in [0, number of cells): leave that corner to the sort path.)
+  const bool keys_may_wrap = (long long)divb[0] * divb[1] * divb[2] > (long long)INT32_MAX;
+  if (!force_sort && !keys_may_wrap && n <= (1 << 21)) {
+    if ((rc = ensure(c, c->vox_bins, voxel_direct_scratch_ints(n) * sizeof(int)))) return rc;
+    if (c->vox_bins_zeroed != c->vox_bins.ptr || c->vox_bins_zeroed_cap != c->vox_bins.cap) {
+      HIP_TRY(c, hipMemsetAsync(c->vox_bins.ptr, 0, c->vox_bins.cap, c->stream));
+      c->vox_bins_zeroed = c->vox_bins.ptr;
+      c->vox_bins_zeroed_cap = c->vox_bins.cap;
+    }
+    if ((rc = ensure(c, c->vox_pub, (size_t)voxel_direct_groups(n) * sizeof(unsigned long long)))) return rc;
+    if (c->vox_pub_zeroed != c->vox_pub.ptr || c->vox_pub_zeroed_cap != c->vox_pub.cap) {
+      HIP_TRY(c, hipMemsetAsync(c->vox_pub.ptr, 0, c->vox_pub.cap, c->stream));
+      c->vox_pub_zeroed = c->vox_pub.ptr;
+      c->vox_pub_zeroed_cap = c->vox_pub.cap;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
+                                             static_cast<unsigned long long*>(c->vox_pub.ptr),
+                                             static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
+                                             static_cast<unsigned long long*>(c->vox_vals.ptr), static_cast<float4*>(out.ptr),
+                                             d_ints + 6, d_ints + 8, c->stream);
+    if (le != hipSuccess) {
+      c->vox_bins_zeroed = nullptr;
+      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (se != hipSuccess) {
+      c->vox_bins_zeroed = nullptr;
+      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(se));
+    }
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    done = c->h_ints[8] == 0;
+  }
+  if (!done) {
+    const size_t tb = voxel_temp_bytes(n);
+    if ((rc = ensure(c, c->vox_flags, (size_t)n * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->vox_slots, (size_t)n * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->vox_temp, tb))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(c, launch_voxel_grid(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_vals.ptr),
+                                 static_cast<int*>(c->vox_flags.ptr), static_cast<int*>(c->vox_slots.ptr), c->vox_temp.ptr, tb,
+                                 static_cast<float4*>(out.ptr), d_ints + 6, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms2 = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms2, c->ev[0], c->ev[1]));
+    ms += ms2;
+  }
+  *n_out = c->h_ints[6] + c->h_ints[7];
+  if (*n_out < 0 || *n_out > n) {
+    const int got = *n_out;
+    *n_out = 0;
+    return fail(c, ICPGPU_ERR_HIP, "voxel filter: %d cells from %d points (internal error)", got, n);
+  }
+  c->prof.voxel_launches += 1;
+  c->prof.voxel_ms += ms;
+  c->prof.voxel_bytes += 16ull * (uint64_t)n + 16ull * (uint64_t)*n_out;
+  return ICPGPU_OK;
+}
+
+}  // namespace icpgpu_impl
+
+extern "C" {
+
+int icpgpu_voxel_grid(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, float* out_xyzw, size_t* n_out) {
+  ENTER(c);
+  if (!n_out || (n && !xyzw)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  *n_out = 0;
+  c->vox_last_n = 0;
+  int rc = ensure(c, c->vox_in, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  int m = 0;
+  bool pass = false;
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass))) return rc;
+  if (m && out_xyzw) {
+    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  c->vox_last_n = (size_t)m;  // out_xyzw == NULL: the filtered cloud waits in HBM for icpgpu_voxel_grid_fetch
+  *n_out = (size_t)m;
+  return ICPGPU_OK;
+}
+
+int icpgpu_voxel_grid_fetch(icpgpu_ctx* c, float* out_xyzw, size_t capacity, size_t* n_out) {
+  ENTER(c);
+  const size_t m = c->vox_last_n;
+  if (n_out) *n_out = m;
+  if (m > capacity) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel_grid_fetch: %zu points, room for %zu", m, capacity);
+  if (m && !out_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (m) {
+    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return ICPGPU_OK;
+}
+
+int icpgpu_set_source_voxel_filtered(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, size_t* n_out) {
+  ENTER(c);
+  if (n && !xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null cloud pointer with n = %zu", n);
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  int rc = ensure(c, c->vox_in, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  int m = 0;
+  bool pass = false;
+  if (c->src.buf.external) c->src.buf = DeviceBuf{};
+  c->src_version++;
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->src.buf, &m, &pass))) return rc;
+  c->src.n = (size_t)m;
+  c->src.set = true;
+  c->src.sample_valid = false;  // written on the device: no host sample to compare with
+  if (n_out) *n_out = (size_t)m;
+  return ICPGPU_OK;
+}
+
+}  // extern "C"

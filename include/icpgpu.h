@@ -174,7 +174,10 @@ int icpgpu_set_target(icpgpu_ctx* ctx, const float* xyzw, size_t n);
  * scan); the source stays set (as a device-side copy) either way.  Call set_target BEFORE set_source when both change
  * (after set_source the previous source is gone and there is nothing to recognise).  icpgpu_fingerprint is that fingerprint of
  * a host buffer (n points of 16 bytes); icpgpu_cloud_sizes reports what a context holds (the C++ shim's
- * context pool picks the context whose source has the new target's size). */
+ * context pool picks the context whose source has the new target's size).
+ * ASSUMPTION: recognition compares sizes and the 64-bit fingerprint (an additive, non-cryptographic mix of every point's bits
+ * and index), not the bytes: two different clouds of equal size collide with probability ~2^-64 per comparison, and an
+ * adversarial cloud could be constructed.  ICPGPU_RECOGNISE=0 in the environment makes icpgpu_set_target always upload. */
 unsigned long long icpgpu_fingerprint(const float* xyzw, size_t n);
 int icpgpu_cloud_sizes(const icpgpu_ctx* ctx, size_t* n_source, size_t* n_target);
 /* same, for clouds already resident in this device's HBM (zero copy; must stay valid and
@@ -261,8 +264,8 @@ int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t 
  *   add_points   addPointsToMap(transformCloudToPoseFrame(cloud, pose)): p = pose * x (float, the a6
  *                contract); going through the points IN ORDER, p is appended to the map iff its voxel
  *                holds no point yet.  Voxels are the cells floor((p - origin) / resolution) (double) of
- *                the lattice whose origin is (first point ever added) - resolution / 2 -- PCL's octree
- *                bounding-box rule.  Non-finite points are skipped.  pose NULL = identity.
+ *                the lattice whose origin is (first point ever added) - resolution -- PCL's octree
+ *                bounding-box rule (first box p +- resolution / 2, widened to 2 voxels by getKeyBitSize).  Non-finite points are skipped.  pose NULL = identity.
  *   add_source   the same for the context's current source cloud (already in HBM).
  *   nn_target    approxNearestNeighbors + transformCloudToPoseFrame(.., raw_pose.inverse()) + setInputTarget:
  *                for every source point s (in order) the map point nearest to pose * s -- EXACT, lowest map
@@ -275,7 +278,9 @@ int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t 
  *                PCL's octree (bounding box grown point by point as adoptBoundingBoxToPoint does) to the existing child
  *                whose voxel centre is nearest to the query (float squared distance, first child on ties), down to a leaf,
  *                whose point is returned -- a heuristic that misses the true neighbour for ~40 % of a scan's points.
- *                The exact search gives the better registration; this one gives the reference's nn cloud. */
+ *                The exact search gives the better registration; this one restates the reference's own search (octree
+ *                geometry per PCL 1.8's adoptBoundingBoxToPoint + getKeyBitSize; like every PCL restatement here it is
+ *                unpinned against a PCL build). */
 enum { ICPGPU_MAP_SEARCH_EXACT = 0, ICPGPU_MAP_SEARCH_PCL_APPROX = 1 };
 int icpgpu_map_set_search(icpgpu_ctx* ctx, int mode);
 int icpgpu_map_reset(icpgpu_ctx* ctx, double resolution);

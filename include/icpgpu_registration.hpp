@@ -143,9 +143,11 @@ inline ContextPtr rebind_for_target(const ContextPtr& have, std::size_t n_target
   }
   return ContextPtr(s, give_back);
 }
-// the context of the OctreeMap that last built an nn cloud on this thread (setInputTargetFromMap() without an argument)
-inline ContextPtr& last_map_context() {
-  static thread_local ContextPtr p;
+// the context of the OctreeMap that last built an nn cloud on this thread (setInputTargetFromMap() without an argument).
+// A WEAK reference: it neither keeps the map's lease alive (the context goes back to the pool when the map dies, on whatever
+// thread) nor can it hand a dead map's context to a registration object (lock() fails once the lease is over).
+inline std::weak_ptr<Slot>& last_map_context() {
+  static thread_local std::weak_ptr<Slot> p;
   return p;
 }
 
@@ -200,9 +202,12 @@ class IterativeClosestPoint {
   }
   // the target is the nn cloud OctreeMap::approxNearestNeighbors just left in HBM (skips one host round trip): this
   // object then works on the MAP's context -- the one given, or the one of the map that last built an nn cloud on this thread
-  void setInputTargetFromMap() { setInputTargetFromMap(detail::last_map_context()); }
+  // (no live map on this thread / a null context: there is no target -- align() then leaves hasConverged() false, like PCL's
+  // initCompute() without a target)
+  void setInputTargetFromMap() { setInputTargetFromMap(detail::last_map_context().lock()); }
   void setInputTargetFromMap(const detail::ContextPtr& map_context) {
-    target_from_map_ = true;
+    target_ = nullptr;
+    target_from_map_ = static_cast<bool>(map_context);
     if (map_context) {
       ctx_holder_ = map_context;
       ctx_ = ctx_holder_->ctx;
@@ -365,10 +370,18 @@ class OctreeMap {
   explicit OctreeMap(double resolution, int device = 0)
       : ctx_holder_(detail::acquire_context(device)), ctx_(ctx_holder_->ctx), resolution_(resolution) { resetMap(); }
   const detail::ContextPtr& context() const { return ctx_holder_; }  // for IterativeClosestPoint::setInputTargetFromMap(map.context())
-  void resetMap() { icpgpu_map_reset(ctx_, resolution_); }                                     // :55-59
-  // which neighbour approxNearestNeighbors collects: false (default) = the EXACT nearest map point; true = PCL's
-  // approxNearestSearch heuristic, i.e. the nn cloud the reference itself would see (icpgpu.h: icpgpu_map_set_search)
-  void setPclApproximateSearch(bool on) { icpgpu_map_set_search(ctx_, on ? ICPGPU_MAP_SEARCH_PCL_APPROX : ICPGPU_MAP_SEARCH_EXACT); }
+  // :55-59.  The context comes from the pool and may have served another map before: the search mode is THIS object's
+  // (exact unless setPclApproximateSearch(true) was called on it), re-applied with every reset.
+  void resetMap() {
+    icpgpu_map_reset(ctx_, resolution_);
+    icpgpu_map_set_search(ctx_, pcl_approx_ ? ICPGPU_MAP_SEARCH_PCL_APPROX : ICPGPU_MAP_SEARCH_EXACT);
+  }
+  // which neighbour approxNearestNeighbors collects: false (default) = the EXACT nearest map point; true = a restatement of
+  // PCL's approxNearestSearch heuristic (icpgpu.h: icpgpu_map_set_search; unpinned against a PCL build like the rest)
+  void setPclApproximateSearch(bool on) {
+    pcl_approx_ = on;
+    icpgpu_map_set_search(ctx_, on ? ICPGPU_MAP_SEARCH_PCL_APPROX : ICPGPU_MAP_SEARCH_EXACT);
+  }
   std::size_t addPointsToMap(const CloudT& cloud, const Matrix4& pose) {                         // :62-69 (+ :135, :152)
     std::size_t added = 0;
     const std::size_t n = cloud.points.size();
@@ -408,6 +421,7 @@ class OctreeMap {
   detail::ContextPtr ctx_holder_;
   icpgpu_ctx* ctx_;
   double resolution_;
+  bool pcl_approx_ = false;
 };
 
 }  // namespace icpgpu

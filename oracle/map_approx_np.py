@@ -6,8 +6,10 @@
        octree_search.hpp as published: adoptBoundingBoxToPoint, genOctreeKeyforPoint, approxNearestSearchRecursive)
 
 What PCL does:
-  * the bounding box starts as the first point +- resolution / 2 and doubles (all three axes at once) whenever a point falls
-    outside, towards the side the point is on; the lattice of leaf voxels never moves (the minimum moves by whole side lengths);
+  * the bounding box starts as the first point +- resolution / 2, which getKeyBitSize() at once turns into a tree ONE level
+    deep (max_voxels = max(ceil(extent / resolution), 2)) whose 2-voxel side is centred on that box: first point +- resolution;
+    it then doubles (all three axes at once) whenever a point falls outside, towards the side the point is on; the lattice of
+    leaf voxels never moves (the minimum moves by whole side lengths);
   * one point per leaf here (octree_mapper.cpp:62-69 only adds a point whose leaf is empty);
   * approxNearestSearch descends from the root: at every level it goes to the EXISTING child whose voxel centre is nearest to
     the query (float squared distance, first child on ties in child-index order x*4 + y*2 + z), and returns the point of the
@@ -39,7 +41,7 @@ class ApproxOctreeMap:
             if not self.defined:
                 self.min = p.astype(np.float64) - self.res / 2
                 self.max = p.astype(np.float64) + self.res / 2
-                self.depth = 0
+                self._key_bit_size()
                 self.defined = True
                 continue
             lower = p < self.min
@@ -55,6 +57,18 @@ class ApproxOctreeMap:
             self.min = self.min - shift
             self.depth += 1
             self.max = self.min + (float(1 << self.depth) * self.res - eps)
+
+    # OctreePointCloud::getKeyBitSize on an octree without leaves (the only call the mapper's usage reaches)
+    def _key_bit_size(self):
+        eps = float(np.finfo(f32).eps)
+        max_key = int(np.ceil((self.max - self.min - eps) / self.res).max())
+        max_voxels = max(max_key, 2)
+        self.depth = int(np.ceil(np.log(float(max_voxels)) / np.log(2.0) - eps))
+        side = float(1 << self.depth) * self.res
+        oversize = (side - (self.max - self.min)) / 2.0
+        grow = oversize > eps
+        self.min = np.where(grow, self.min - oversize, self.min)
+        self.max = np.where(grow, self.max + oversize, self.max)
 
     def _key(self, p):
         return tuple(((p.astype(np.float64) - self.min) / self.res).astype(np.int64))     # genOctreeKeyforPoint (truncation)

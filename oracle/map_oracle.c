@@ -7,9 +7,11 @@
  *   /root/reference/src/icpslam/octree_mapper.cpp:62-69   addPointsToMap: "if (!isVoxelOccupiedAtPoint(p)) addPointToCloud(p)"
  *   /root/reference/src/icpslam/octree_mapper.cpp:72-90   approxNearestNeighbors -> nn cloud
  * as a plain sequential loop: points are visited in order; a point is appended iff its voxel is empty; a voxel is
- * floor((p - origin) / resolution) per axis in double, origin = first point ever added - resolution / 2 (PCL
- * OctreePointCloud::adoptBoundingBoxToPoint + genOctreeKeyforPoint: the box only grows by whole octree side lengths, so
- * the lattice never moves).  The nearest-neighbour query is EXACT (orc_nn), where PCL's approxNearestSearch is a
+ * floor((p - origin) / resolution) per axis in double, origin = the minimum corner of the octree's first bounding box = first
+ * point ever added - resolution (PCL OctreePointCloud::adoptBoundingBoxToPoint sets the box to p +- resolution / 2 and calls
+ * getKeyBitSize(), which -- max_voxels = max(ceil(extent / resolution), 2) -- makes the tree one level deep, 2 voxels wide, and
+ * splits the oversize evenly: p +- resolution; genOctreeKeyforPoint indexes from that minimum; the box only grows by whole
+ * octree side lengths afterwards, so the lattice never moves).  Until round 4 this file stopped at p - resolution / 2.  The nearest-neighbour query is EXACT (orc_nn), where PCL's approxNearestSearch is a
  * heuristic descent -- SURVEY.md 8(f4) asks for the exact one.
  *
  * The voxel set is a sorted array + binary search rebuilt per batch: deliberately nothing like the GPU's hash set.
@@ -37,6 +39,33 @@ static int point_key(const orc_map* m, const float* p, int64_t* key) {
   if (!(fabs(fx) <= lim && fabs(fy) <= lim && fabs(fz) <= lim)) return 0;
   *key = pack_key((int64_t)fx, (int64_t)fy, (int64_t)fz);
   return 1;
+}
+
+/* adoptBoundingBoxToPoint on an empty octree followed by getKeyBitSize(), operation for operation (PCL 1.8
+ * octree_pointcloud.hpp): returns the box's minimum corner, the lattice origin */
+static void orc_octree_first_box(const float* p, double res, double* ox, double* oy, double* oz) {
+  const float min_value = 1.1920928955078125e-7f; /* std::numeric_limits<float>::epsilon() */
+  double mn[3], mx[3];
+  unsigned int max_key = 0;
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = (double)p[a] - res / 2;
+    mx[a] = (double)p[a] + res / 2;
+    const unsigned int k = (unsigned int)ceil((mx[a] - mn[a] - min_value) / res);
+    if (k > max_key) max_key = k;
+  }
+  const unsigned int max_voxels = max_key > 2u ? max_key : 2u;
+  const unsigned int depth = (unsigned int)ceil(log((double)max_voxels) / log(2.0) - min_value);
+  const double side = (double)(1u << depth) * res;
+  for (int a = 0; a < 3; ++a) {
+    const double oversize = (side - (mx[a] - mn[a])) / 2.0;
+    if (oversize > min_value) {
+      mn[a] -= oversize;
+      mx[a] += oversize;
+    }
+  }
+  *ox = mn[0];
+  *oy = mn[1];
+  *oz = mn[2];
 }
 
 orc_map* orc_map_create(double resolution) {
@@ -79,9 +108,7 @@ long orc_map_add_points(orc_map* m, const float* in_xyzw, size_t n, const float 
     const float* p = moved + 4 * i;
     if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
     if (!m->anchored) {
-      m->ox = (double)p[0] - m->res / 2.0;
-      m->oy = (double)p[1] - m->res / 2.0;
-      m->oz = (double)p[2] - m->res / 2.0;
+      orc_octree_first_box(p, m->res, &m->ox, &m->oy, &m->oz);
       m->anchored = 1;
     }
     int64_t key;

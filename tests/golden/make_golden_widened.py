@@ -61,8 +61,16 @@ def voxel_grid_np(cloud, leaf):
     return np.array(out, f32)
 
 
+def first_box_min(p, res):
+    """PCL's first octree box (adoptBoundingBoxToPoint on an empty octree, then getKeyBitSize): p +- res / 2 becomes a one-level
+    tree, 2 voxels wide, centred on it.  Returns the minimum corner = the lattice origin (double)."""
+    lo, hi = p.astype(np.float64) - res / 2, p.astype(np.float64) + res / 2
+    side = 2.0 * res                                  # max(ceil(extent / res), 2) voxels = 2 -> depth 1
+    return lo - (side - (hi - lo)) / 2.0
+
+
 class MapNp:
-    """First point per voxel of the lattice anchored at (first point - res / 2); insertion order."""
+    """First point per voxel of the lattice anchored at the octree's first box minimum (first point - res: PCL's getKeyBitSize); insertion order."""
 
     def __init__(self, res):
         self.res, self.origin, self.vox, self.pts = float(res), None, set(), []
@@ -74,7 +82,7 @@ class MapNp:
             if not np.isfinite(p[:3]).all():
                 continue
             if self.origin is None:
-                self.origin = p[:3].astype(np.float64) - self.res / 2.0
+                self.origin = first_box_min(p[:3], self.res)
             k = tuple(np.floor((p[:3].astype(np.float64) - self.origin) / self.res).astype(np.int64))
             if k not in self.vox:
                 self.vox.add(k)

@@ -132,7 +132,7 @@ def test_promote_source_to_target_sequence(ctx):
 
 
 def test_cell_ordered_source_same_answer_and_grid_follows_promote(ctx):
-    """>= 100k-point sources are iterated in cell order (icpgpu_api.cpp ensure_source_order): the transform must not
+    """>= 100k-point sources are iterated in cell order (icpgpu_index.cpp ensure_source_order): the transform must not
     depend on it, non-finite source points must stay harmless, and after promote_source_to_target the source's grid
     serves as the target's (each cloud is binned once)."""
     src, tgt, _ = synth.make_pair(120000, 120000, seed=21)

@@ -6,12 +6,13 @@ from icpslam_amd import synth
 
 
 def _brute_map(points, res):
-    """Independent restatement in NumPy: first point per voxel of the lattice anchored at (first point - res / 2)."""
+    """Independent restatement in NumPy: first point per voxel of the lattice anchored at the octree's first box minimum (first point - res: PCL's getKeyBitSize)."""
     pts = np.asarray(points, np.float32)
     fin = np.isfinite(pts[:, :3]).all(1)
     if not fin.any():
         return np.zeros((0, 4), np.float32)
-    origin = pts[fin][0, :3].astype(np.float64) - res / 2.0
+    p0 = pts[fin][0, :3].astype(np.float64)
+    origin = (p0 - res / 2.0) - (2.0 * res - ((p0 + res / 2.0) - (p0 - res / 2.0))) / 2.0   # box p0 +- res/2 -> 2-voxel tree
     out, seen = [], set()
     for p in pts[fin]:
         k = tuple(np.floor((p[:3].astype(np.float64) - origin) / res).astype(np.int64))
@@ -32,12 +33,14 @@ def test_first_point_per_voxel_in_input_order():
     assert m.add_points(a) == 0 and m.add_points(b) == 0          # every voxel is taken now
 
 
-def test_lattice_is_anchored_at_first_point_minus_half_a_voxel():
+def test_lattice_is_anchored_at_first_point_minus_one_voxel():
+    """PCL's first box is p +- res (getKeyBitSize makes the tree 2 voxels wide), so the first point sits on a lattice CORNER."""
     m = oracle.VoxelMap(1.0)
-    # anchor (10, 10, 10) -> voxel [9.5, 10.5)^3; 10.4 shares it, 10.6 does not, 9.4 is the voxel below
-    pts = np.array([[10, 10, 10, 1], [10.4, 10.4, 10.4, 1], [10.6, 10, 10, 1], [9.4, 10, 10, 1], [9.6, 10.2, 9.9, 1]], np.float32)
+    # anchor (10, 10, 10) -> voxels [9, 10) and [10, 11) per axis; 10.4 and 10.6 share the first point's voxel, 9.4 and 9.6 the one below
+    pts = np.array([[10, 10, 10, 1], [10.4, 10.4, 10.4, 1], [10.6, 10, 10, 1], [9.4, 10, 10, 1], [9.6, 10.2, 10.9, 1],
+                    [11.0, 10, 10, 1]], np.float32)
     assert m.add_points(pts) == 3
-    assert np.array_equal(m.points(), pts[[0, 2, 3]])
+    assert np.array_equal(m.points(), pts[[0, 3, 5]])
 
 
 def test_pose_is_applied_with_the_transform_contract_and_nonfinite_points_are_skipped():
