@@ -6,7 +6,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicpgpu.so")
+# ICPGPU_FLAVOUR=dev: the development flavour (libicpgpu_dev.so, built with -DICPGPU_DEV_SWITCHES: kernel variants, tuning
+# constants and test modes behind environment switches -- icpslam_amd/csrc/icp_env.h).  A process loads ONE flavour; the
+# tests of the development modes run in sub-processes (tests/test_gpu_dev_flavour.py).  Default: the release library.
+FLAVOUR = "dev" if os.environ.get("ICPGPU_FLAVOUR", "") == "dev" else "release"
+LIB_PATH = os.path.join(_HERE, "libicpgpu_dev.so" if FLAVOUR == "dev" else "libicpgpu.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_NO_INPUT, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 P2P_SVD, GICP = 0, 1
@@ -42,7 +46,7 @@ class Profile(C.Structure):
                 ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64),
                 ("grid_bounded", C.c_uint64), ("gicp_eval_ms", C.c_double), ("gicp_eval_corr", C.c_uint64), ("gicp_cov_points", C.c_uint64),
                 ("targets_recognised", C.c_uint64), ("brute_bound_violations", C.c_uint64),
-                ("brute_bound_worst", C.c_double)]
+                ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64)]
 
 
 class Pose(C.Structure):

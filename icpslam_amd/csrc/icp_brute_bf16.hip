@@ -32,6 +32,8 @@
 //   (s + tau - truth) / (P^2 + |v|^2) seen (tests/test_gpu_brute_bf16.py and a campaign of 4000 random clouds: 1.8e-5 = 2^-15.8 at worst against tau = 2^-13).
 #include <hip/hip_runtime.h>
 
+#include "icp_env.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <math.h>
@@ -406,12 +408,12 @@ hipError_t launch_nn_brute_bf16(const float4* src_sorted, int n_q, const float4*
   if (n_q <= 0 || n_t <= 0) return hipSuccess;
   // experiments: ICPGPU_BF16_G (sources per wave / 32: 2 or 4), ICPGPU_BF16_TILE (512 / 1024), ICPGPU_BF16_BLOCK (256 / 512),
   // ICPGPU_MFMA_WAVES (target waves per SIMD the splits aim at), ICPGPU_MFMA_NO_EXACT (timing only: results are wrong)
-  static const int g_env = [] { const char* e = getenv("ICPGPU_BF16_G"); return e ? atoi(e) : 2; }();
-  static const int tile_env = [] { const char* e = getenv("ICPGPU_BF16_TILE"); return e ? atoi(e) : 1024; }();
-  static const int block_env = [] { const char* e = getenv("ICPGPU_BF16_BLOCK"); return e ? atoi(e) : 512; }();
-  static const int waves_env = [] { const char* e = getenv("ICPGPU_MFMA_WAVES"); return e ? atoi(e) : 32; }();
+  static const int g_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BF16_G"); return e ? atoi(e) : 2; }();
+  static const int tile_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BF16_TILE"); return e ? atoi(e) : 1024; }();
+  static const int block_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BF16_BLOCK"); return e ? atoi(e) : 512; }();
+  static const int waves_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_MFMA_WAVES"); return e ? atoi(e) : 32; }();
   static const int no_exact = [] {
-    if (!getenv("ICPGPU_MFMA_NO_EXACT")) return 0;
+    if (!ICPGPU_DEV_ENV("ICPGPU_MFMA_NO_EXACT")) return 0;
     fprintf(stderr, "[icpgpu] WARNING: ICPGPU_MFMA_NO_EXACT is set -- the matrix-core search skips its exact path, every brute-force result "
                     "of this process is WRONG (a timing experiment's switch, never a production setting)\n");
     return 1;

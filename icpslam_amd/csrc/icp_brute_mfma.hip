@@ -31,6 +31,8 @@
 // oracle bit for bit (ties, duplicates, NaN / inf points, far outliers, 200k x 200k and 200k x 1M).
 #include <hip/hip_runtime.h>
 
+#include "icp_env.h"
+
 #include <cstdio>
 #include <math.h>
 
@@ -278,10 +280,10 @@ hipError_t launch_nn_brute_mfma(const float4* src_sorted, int n_q, const float4*
   if (n_q <= 0 || n_t <= 0) return hipSuccess;
   // experiments: ICPGPU_MFMA_G (sources per wave / 32: 2 or 4), ICPGPU_MFMA_WAVES (target waves per SIMD the splits aim at),
   // ICPGPU_MFMA_NO_EXACT (timing only: the exact path is skipped, results are wrong)
-  static const int g_env = [] { const char* e = getenv("ICPGPU_MFMA_G"); return e ? atoi(e) : 2; }();
-  static const int waves_env = [] { const char* e = getenv("ICPGPU_MFMA_WAVES"); return e ? atoi(e) : 32; }();
+  static const int g_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_MFMA_G"); return e ? atoi(e) : 2; }();
+  static const int waves_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_MFMA_WAVES"); return e ? atoi(e) : 32; }();
   static const int no_exact = [] {
-    if (!getenv("ICPGPU_MFMA_NO_EXACT")) return 0;
+    if (!ICPGPU_DEV_ENV("ICPGPU_MFMA_NO_EXACT")) return 0;
     fprintf(stderr, "[icpgpu] WARNING: ICPGPU_MFMA_NO_EXACT is set -- the matrix-core search skips its exact path, every brute-force result "
                     "of this process is WRONG (a timing experiment's switch, never a production setting)\n");
     return 1;
@@ -298,7 +300,7 @@ hipError_t launch_nn_brute_mfma(const float4* src_sorted, int n_q, const float4*
   int per = (n_t + splits - 1) / splits;
   per = ((per + MF_TILE - 1) / MF_TILE) * MF_TILE;
   splits = (n_t + per - 1) / per;
-  static const int pipe_env = [] { const char* e = getenv("ICPGPU_MFMA_PIPE"); return e ? atoi(e) : 0; }();
+  static const int pipe_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_MFMA_PIPE"); return e ? atoi(e) : 0; }();
 #define ICPGPU_MFMA_LAUNCH(...)                                                                                         \
   hipLaunchKernelGGL((__VA_ARGS__), dim3(grid_x, splits), dim3(MF_BLOCK), 0, stream, src_sorted, n_q, tgt, n_t, T, per, splits, \
                      keys, seed, no_exact)

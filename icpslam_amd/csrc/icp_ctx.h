@@ -36,6 +36,7 @@
 #include "icp_kernels.h"
 #include "icp_gicp_solver.h"
 #include "icp_solver.h"
+#include "icp_env.h"
 
 using namespace icpgpu;
 
@@ -131,6 +132,8 @@ struct VoxelMap {
   int search_mode = ICPGPU_MAP_SEARCH_EXACT;
   bool box_defined = false;
   ApproxBox box{};
+  ApproxHistory box_hist{};   // every version of the box with the map index it is in force from (PCL keys are never recomputed)
+  long long box_shift[3] = {0, 0, 0};  // voxels the minimum has moved since the first box
   int box_upto = 0;           // map points already folded into the box
   uint64_t box_version = 0;   // bumped whenever the box grows
   DeviceBuf node_keys, node_vals;
@@ -155,6 +158,11 @@ using namespace icpgpu_impl;
 
 constexpr size_t kMaxServerWorkers = 8;
 
+// ICPGPU_GICP_DEVICE=0: GICP's inner BFGS stays on the host (evaluation server or single launches)
+inline bool gicp_device_solver_enabled() {
+  static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_DEVICE"); return !e || std::atoi(e) != 0; }();
+  return v;
+}
 inline bool gicp_server_enabled() {  // ICPGPU_GICP_SERVER=0: every GICP evaluation is its own launch
 #if defined(__x86_64__)
   static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_SERVER"); return !e || std::atoi(e) != 0; }();
@@ -205,6 +213,13 @@ struct icpgpu_ctx {
   unsigned long long* h_gicp_flags_dev = nullptr;
   // resident evaluation server (icp_gicp.hip): its command line, fine-grained device memory the host writes through the BAR
   unsigned int* gicp_cmd = nullptr;
+  // the device solver (icp_gicp.hip: gicp_solve_kernel): the workgroups' partial-sum slots (fine-grained device memory), the
+  // result granules (host, mapped), the number the next run's granules carry, and whether the path is (still) in use
+  unsigned long long* gicp_slots = nullptr;
+  volatile unsigned long long* h_solve = nullptr;
+  unsigned long long* h_solve_dev = nullptr;
+  unsigned long long gicp_solve_seq = 0;
+  bool gicp_device_ok = false;
   bool gicp_server_on = false;
   bool gicp_server_allowed = true;  // align_batch with more than kMaxServerWorkers threads: single launches (below)
   int gicp_blocks_most = kGicpDirectBlocks;

@@ -19,6 +19,20 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float px, f
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// {a, b} as ONE 16-byte store written through to system memory (sc0 sc1): a reader never sees half a pair (observed on gfx950,
+// not architecturally promised: the tags the callers put into b are self-validating where it matters).
+//
+// The s_nop behind the store is REQUIRED.  gfx950 reads the data (and address) VGPRs of a store wider than 64 bits a few cycles
+// after issue; the compiler inserts the wait states for its own stores, but an inline-asm store is opaque to its hazard
+// recogniser, and the very next VALU instruction may overwrite those registers.  Measured (round 4, scripts/probes/
+// granule_probe.cpp): two such stores in a row, the second one's value computed between them -- lane 12's low 8 bytes of the
+// FIRST store arrive stale on every round; with four wait states behind each store: never, in 10^6 granules.
+__device__ __forceinline__ void store_pair_system(void* p, unsigned long long a, unsigned long long b) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = {(unsigned int)a, (unsigned int)(a >> 32), (unsigned int)b, (unsigned int)(b >> 32)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 3" ::"v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -1,0 +1,25 @@
+// icp_env.h -- environment switches of libicpgpu.so, in two classes.
+//
+// PRODUCTION switches are read by every build (std::getenv directly, documented in include/icpgpu.h):
+//   ICPGPU_WAIT_TIMEOUT_MS   deadline of every host wait for the device (mailbox, gather); default 30 000
+//   ICPGPU_BATCH_THREADS / ICPGPU_BATCH_DEPTH   host threads of icpgpu_align_batch and alignments each drives
+//   ICPGPU_RECOGNISE=0       icpgpu_set_target always uploads (no content recognition)
+//   ICPGPU_GICP_SERVER=0     every GICP cost evaluation is its own kernel launch (no resident server)
+//   ICPGPU_GICP_DEVICE=0     GICP's inner BFGS runs on the host (evaluation server or single launches), not in the device solver
+//   ICPGPU_MAILBOX=pairs|release   how results reach the host (default: self-test at context creation picks it)
+//   ICPGPU_DEBUG=1           diagnostics on stderr
+//   LOCAL_WORLD_SIZE         (torch.distributed.run) processes sharing this host's CPUs
+// None of them changes a result.
+//
+// DEVELOPMENT switches -- kernel variants, tuning constants, test modes that evaluate every pair, and a few that deliberately
+// produce WRONG results to price a stage (ICPGPU_SKIP_UNCERT, *_NO_EXACT) -- exist only in the flavour compiled with
+// -DICPGPU_DEV_SWITCHES (libicpgpu_dev.so, `make dev`; the tests of those modes load that flavour).  In the release
+// library ICPGPU_DEV_ENV(name) is a constant null pointer: the switch, its getenv and its name are not in the binary.
+#pragma once
+#include <cstdlib>
+
+#if defined(ICPGPU_DEV_SWITCHES)
+#define ICPGPU_DEV_ENV(name) (std::getenv(name))
+#else
+#define ICPGPU_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif

@@ -11,7 +11,12 @@
 //                     (base p)(M r)^T with r = T(x) p - q -- 14 float64 terms, fixed-order two-stage reduction.
 //                     HBM-bound: 16 B source + 8 B key + 16 B gathered target + 48 B M per correspondence.
 #include <math.h>
+#include <string.h>
 
+#include <cstring>
+
+#include "icp_env.h"
+#include "icp_gicp_solver_impl.h"
 #include "icp_device.h"
 #include "icp_kernels.h"
 
@@ -476,11 +481,7 @@ __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __re
 __device__ __forceinline__ void gicp_store_tagged(double* __restrict__ out, int entry, double value, unsigned long long tag) {
   // ONE 16-byte store, written through to system memory (sc0 sc1): the server kernel never ends, nothing else would push
   // a cached line out, and a release fence is exactly what this protocol is there to avoid
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(value);
-  const u32x4 v = {(unsigned int)bits, (unsigned int)(bits >> 32), (unsigned int)tag, (unsigned int)(tag >> 32)};
-  double* p = out + 2 * entry;
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  store_pair_system(out + 2 * entry, (unsigned long long)__double_as_longlong(value), tag);
 }
 __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, double* __restrict__ partials, unsigned long long tag) {
   __shared__ DD s_lane[kGicpSums][16][17];  // [sum][lane % 16][lane / 16], rows padded: neither the writes (a lane per
@@ -616,6 +617,329 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
   }
 }
 
+
+// ---- the device solver (round 4) --------------------------------------------------------------------------------------------
+// What the reference runs per scan (icp_odometer.cpp:188-198) is ~5 outer iterations of ~35 DEPENDENT cost evaluations each; with
+// the BFGS on the host every one of them was a host <-> device round trip (7.6 us wall for 1.4 us of device work: 1.3 of the
+// pipeline's 2.2 ms per scan).  gicp_solve_kernel runs the WHOLE inner minimisation of an outer iteration on the device: the
+// host queues it behind the search and the Mahalanobis kernels and polls ONE result.
+//
+//   * Every workgroup holds its share of the correspondences in registers (RESIDENT; streamed from memory when the share is
+//     larger than one quad per lane) and runs the SAME solver redundantly -- icp_gicp_solver_impl.h, the source the host
+//     fallback instantiates: same operations, same order, correctly rounded sines and cosines (icp_trig.h), so every lane of
+//     every workgroup takes the same decisions and the bits equal the host path's and the oracle's.
+//   * One evaluation = one hop: each workgroup reduces its share (double-double, two LDS stages), PUBLISHES 28 granules --
+//     {value, tag}, one 16-byte write-through store each, tag = evaluation number and a checksum of the value's bits, so a
+//     granule is valid or recognisably not, whatever the order its halves become visible in -- into its slot of a fine-grained
+//     device buffer, and wave 0 of EVERY workgroup GATHERS all slots (4 lanes per sum, every load of a round in flight at
+//     once), merges them in double-double (order-independent to ~1e-30) and hands the 15 numbers to the workgroup through LDS.
+//     There is no master and no command hop: the next state is computed everywhere at once.
+//   * Slots are double-buffered by the evaluation number's parity: a workgroup can run at most one evaluation ahead of the
+//     slowest one (it needs everybody's partials of evaluation k to start k + 1).
+//   * Nobody waits for ever: 50 ms without a granule ends the run with kDeviceError everywhere (the host falls back to its own
+//     solver); the workgroups are co-resident by construction (one per CU, at most the context's share of the chip).
+constexpr int kSolveGranules = 28;  // per workgroup and parity: 13 sums' high parts, their low parts, m, sum d2
+constexpr int kSolveOut = 20;       // host granules: status, x[6], m, sum d2, f, evaluations, inner iterations done
+
+__device__ __forceinline__ unsigned long long granule_tag(unsigned long long seq, unsigned long long bits) {
+  return (seq << 24) | ((bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull);
+}
+__device__ __forceinline__ void granule_store(unsigned long long* g, double value, unsigned long long seq) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(value);
+  store_pair_system(g, bits, granule_tag(seq, bits));
+}
+struct GicpSolveArgs {
+  const float4* src;
+  int n_s;
+  const float4* tgt;
+  const unsigned long long* keys;
+  float thr;
+  Xform base;
+  float guess[16];
+  const double* maha6;
+  double x0[6];
+  unsigned long long* slots;     // [2][gridDim.x][kSolveGranules] granules (2 words each), fine-grained device memory
+  unsigned long long* host_out;  // kSolveOut granules in the host mailbox
+  unsigned long long seq0;       // evaluation e of this run carries the number seq0 + e; the result carries seq0
+  int max_inner;
+  double gradient_tol;
+};
+
+// The six sine / cosine pairs of a state, six lanes at a time: lane l (mod 8) evaluates argument l, the results come back through
+// v_readlane (every group of eight lanes computes the same six, so lanes 0..5 of the wave serve everybody).  Same function, same
+// bits as the host's one-after-the-other loop (gicp::trig6), a sixth of the instructions on the critical path.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {  // lane: a compile-time constant
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ gicp::Trig6 trig6_lanes(const gicp::V6& x, const double (*table)[4]) {
+  double a[6];
+  gicp::trig6_arguments(x, a);
+  const int l = (int)threadIdx.x & 7;
+  double arg = a[0];
+  arg = l == 1 ? a[1] : arg;
+  arg = l == 2 ? a[2] : arg;
+  arg = l == 3 ? a[3] : arg;
+  arg = l == 4 ? a[4] : arg;
+  arg = l >= 5 ? a[5] : arg;
+  double sv, cv;
+  trig::sincos_cr_with(table, arg, &sv, &cv);
+  double s6[6], c6[6];
+  s6[0] = readlane_f64(sv, 0); c6[0] = readlane_f64(cv, 0);
+  s6[1] = readlane_f64(sv, 1); c6[1] = readlane_f64(cv, 1);
+  s6[2] = readlane_f64(sv, 2); c6[2] = readlane_f64(cv, 2);
+  s6[3] = readlane_f64(sv, 3); c6[3] = readlane_f64(cv, 3);
+  s6[4] = readlane_f64(sv, 4); c6[4] = readlane_f64(cv, 4);
+  s6[5] = readlane_f64(sv, 5); c6[5] = readlane_f64(cv, 5);
+  gicp::Trig6 t;
+  gicp::trig6_from(s6, c6, t);
+  return t;
+}
+
+template <bool RESIDENT>
+struct DeviceEval {
+  const GicpSolveArgs& A;
+  const GicpQuad& mine;
+  double* s_sums;      // LDS: the 15 numbers of an evaluation
+  int* s_ok;           // LDS: the gather's verdict
+  const double (*s_table)[4];  // LDS: icp_trig.h's table
+  unsigned long long n_eval = 0;
+  double m = 0.0, d2 = 0.0;
+  double dbg_raw[4] = {0, 0, 0, 0};
+  long long t_apply = 0, t_acc = 0, t_pub = 0, t_gather = 0, t_grad = 0;  // phase times (100 MHz ticks), development
+  double dbg = 0.0;    // on a gather timeout: evaluation * 1e6 + the first missing workgroup * 1e3 + quantity (host_out granule 11)
+
+  __device__ __forceinline__ bool operator()(const gicp::V6& x, gicp::Eval& out) {
+    const long long c0 = (long long)wall_clock64();
+    const gicp::Trig6 tr = trig6_lanes(x, s_table);
+    float T[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = A.guess[i];
+    gicp::apply_state(T, x, tr);
+    Xform Tx;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Tx.m[4 * r + c] = T[c * 4 + r];
+    const long long c1 = (long long)wall_clock64();
+    GicpAcc acc;
+    if constexpr (RESIDENT) {
+      gicp_clear(acc);
+      gicp_add_quad(acc, mine, Tx, A.base);
+    } else {
+      gicp_accumulate(acc, A.src, A.n_s, A.tgt, A.keys, A.thr, Tx, A.base, A.maha6);
+    }
+    const long long c2 = (long long)wall_clock64();
+    ++n_eval;
+    const unsigned long long seq = A.seq0 + n_eval;
+    const int B = (int)gridDim.x;
+    unsigned long long* parity = A.slots + (size_t)(n_eval & 1ull) * (size_t)B * kSolveGranules * 2;
+    publish(acc, parity + (size_t)blockIdx.x * kSolveGranules * 2, seq);
+    const long long c3 = (long long)wall_clock64();
+    gather(parity, B, seq);
+    __syncthreads();
+    const long long c4 = (long long)wall_clock64();
+    const bool ok = *s_ok != 0;
+    double s[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) s[k] = s_sums[k];
+    __syncthreads();  // (the LDS words are rewritten by the next evaluation)
+    if (!ok) return false;
+    m = s[0];
+    d2 = s[14];
+    gicp::eval_from_sums(tr, s, out);
+    const long long c5 = (long long)wall_clock64();
+    t_apply += c1 - c0;
+    t_acc += c2 - c1;
+    t_pub += c3 - c2;
+    t_gather += c4 - c3;
+    t_grad += c5 - c4;
+    return true;
+  }
+
+  // workgroup reduction of the lanes' accumulators (the two LDS stages of gicp_block_reduce_store), then 28 granules
+  __device__ __forceinline__ void publish(const GicpAcc& acc, unsigned long long* slot, unsigned long long seq) {
+    __shared__ DD s_lane[kGicpSums][16][17];
+    __shared__ DD s_chunk[kGicpSums][16];
+    __shared__ double s_md[2][4];
+#pragma unroll
+    for (int k = 0; k < kGicpSums; ++k) s_lane[k][threadIdx.x & 15][threadIdx.x >> 4] = acc.s[k];
+    const double wm = wave_sum(acc.m), wd = wave_sum(acc.d2);
+    if ((threadIdx.x & 63) == 0) {
+      s_md[0][threadIdx.x >> 6] = wm;
+      s_md[1][threadIdx.x >> 6] = wd;
+    }
+    __syncthreads();
+    if (threadIdx.x < kGicpSums * 16) {
+      const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+      DD x[16];
+#pragma unroll
+      for (int l = 0; l < 16; ++l) x[l] = s_lane[k][l][c];
+      DD v = x[0];
+#pragma unroll
+      for (int l = 1; l < 16; ++l) v = dd_add(v, x[l]);
+      s_chunk[k][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kGicpSums) {
+      DD x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
+      DD v = x[0];
+#pragma unroll
+      for (int c = 1; c < 16; ++c) v = dd_add(v, x[c]);
+      granule_store(slot + 2 * threadIdx.x, v.hi, seq);
+      granule_store(slot + 2 * (kGicpSums + threadIdx.x), v.lo, seq);
+    } else if (threadIdx.x == kGicpSums) {
+      granule_store(slot + 2 * 26, (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]), seq);
+      granule_store(slot + 2 * 27, (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]), seq);
+    }
+  }
+
+  // wave 0: lane = (quantity q = lane / 4, part p = lane % 4) merges the workgroups p, p + 4, ... of quantity q, then the four
+  // parts are combined by two exchanges; quantities 0..12 are the double-double sums, 13 = m, 14 = sum d2 (plain sums of
+  // integers / of floats: exact in float64 at these sizes).  s_sums[0] = m, [1..13] = the sums rounded once, [14] = sum d2.
+  __device__ __forceinline__ void gather(const unsigned long long* parity, int B, unsigned long long seq) {
+    if (threadIdx.x >= 64) return;
+    const int q = (int)threadIdx.x >> 2, p = (int)threadIdx.x & 3;
+    const bool active = q < 15;
+    const int g_hi = q < kGicpSums ? q : (q == 13 ? 26 : 27);
+    const bool two = q < kGicpSums;
+    const int g_lo = two ? kGicpSums + q : g_hi;  // (quantities without a low part read their one granule twice)
+    DD v{0.0, 0.0};
+    bool failed = false;
+    const long long patience = 5000000;  // 50 ms of the 100 MHz wall clock
+    constexpr int R = 8;                 // workgroups per lane and round: 2 R loads in flight
+    for (int b0 = p; b0 < B && !failed; b0 += 4 * R) {
+      double hi[R], lo[R];
+      unsigned int have = 0u, want = 0u;
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        hi[u] = lo[u] = 0.0;
+        if (active && b0 + 4 * u < B) want |= 1u << u;
+      }
+      const long long t0 = (long long)wall_clock64();
+      while (have != want) {
+        // every load of the round is issued before any is looked at (addresses clamped to the last workgroup: no branches
+        // between the loads), then the granules are validated; what is not there yet is read again
+        unsigned long long hb[R], ht[R], lb[R], lt[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const int b = min(b0 + 4 * u, B - 1);
+          const unsigned long long* slot = parity + (size_t)b * kSolveGranules * 2;
+          hb[u] = __hip_atomic_load(slot + 2 * g_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          ht[u] = __hip_atomic_load(slot + 2 * g_hi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          lb[u] = __hip_atomic_load(slot + 2 * g_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          lt[u] = __hip_atomic_load(slot + 2 * g_lo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const bool ok = ht[u] == granule_tag(seq, hb[u]) && (!two || lt[u] == granule_tag(seq, lb[u]));
+          if (ok && (((want & ~have) >> u) & 1u)) {
+            hi[u] = __longlong_as_double((long long)hb[u]);
+            lo[u] = two ? __longlong_as_double((long long)lb[u]) : 0.0;
+            have |= 1u << u;
+          }
+        }
+        if (have != want && (long long)wall_clock64() - t0 > patience) {
+          failed = true;
+          int miss = 0;
+#pragma unroll
+          for (int u = R - 1; u >= 0; --u)
+            if (((want & ~have) >> u) & 1u) miss = b0 + 4 * u;
+          dbg = (double)n_eval * 1e6 + (double)miss * 1e3 + (double)q;
+          break;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u)
+        if ((want >> u) & 1u) v = dd_add(v, DD{hi[u], lo[u]});
+    }
+    // combine the four parts (TwoSum is symmetric in its arguments: all four lanes end with the same bits)
+#pragma unroll
+    for (int d = 1; d <= 2; d <<= 1) {
+      DD o;
+      o.hi = __shfl_xor(v.hi, d, 64);
+      o.lo = __shfl_xor(v.lo, d, 64);
+      v = dd_add(v, o);
+    }
+    const bool any_failed = __any(failed ? 1 : 0) != 0;
+    if (any_failed) {  // the lowest failing lane's record to lane 0
+      const unsigned long long mask = __ballot(failed ? 1 : 0);
+      const int src_lane = __ffsll((long long)mask) - 1;
+      dbg = __shfl(dbg, src_lane, 64);
+      for (int k = 0; k < 4; ++k) dbg_raw[k] = __shfl(dbg_raw[k], src_lane, 64);
+    }
+    if (active && p == 0) s_sums[q < kGicpSums ? 1 + q : (q == 13 ? 0 : 14)] = v.hi + v.lo;
+    if (threadIdx.x == 0) *s_ok = any_failed ? 0 : 1;
+  }
+};
+
+template <bool RESIDENT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gicp_solve_kernel(GicpSolveArgs A) {
+  __shared__ double s_sums[16];
+  __shared__ int s_ok;
+  __shared__ double s_table[128][4];
+  const long long t_kernel0 = (long long)wall_clock64();
+  {
+    const double (*src_table)[4] = trig::trig_table();
+    for (int i = threadIdx.x; i < 512; i += 256) s_table[i >> 2][i & 3] = src_table[i >> 2][i & 3];
+    __syncthreads();
+  }
+  GicpQuad mine;
+  if constexpr (RESIDENT)
+    gicp_load_quad(mine, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, A.src, A.n_s, A.tgt, A.keys, A.thr, A.maha6);
+  DeviceEval<RESIDENT> ev{A, mine, s_sums, &s_ok, s_table};
+  gicp::V6 x;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = A.x0[i];
+  gicp::Eval probe;
+  int status;
+  double f_last = 0.0;
+  if (!ev(x, probe)) {
+    status = gicp::kDeviceError;
+  } else if (!(ev.m >= 4.0)) {
+    status = gicp::kNotEnoughPoints;  // PCL: NotEnoughPointsException (fewer than 4 correspondences)
+  } else {
+    const double m0 = ev.m, d20 = ev.d2;
+    status = (int)gicp::minimize(ev, x, A.max_inner, A.gradient_tol, &probe);
+    ev.m = m0;  // (the correspondences do not change during a run: every evaluation counts the same m and sum d2)
+    ev.d2 = d20;
+  }
+  f_last = probe.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long* o = A.host_out;
+    granule_store(o + 2 * 1, x[0], A.seq0);
+    granule_store(o + 2 * 2, x[1], A.seq0);
+    granule_store(o + 2 * 3, x[2], A.seq0);
+    granule_store(o + 2 * 4, x[3], A.seq0);
+    granule_store(o + 2 * 5, x[4], A.seq0);
+    granule_store(o + 2 * 6, x[5], A.seq0);
+    granule_store(o + 2 * 7, ev.m, A.seq0);
+    granule_store(o + 2 * 8, ev.d2, A.seq0);
+    granule_store(o + 2 * 9, f_last, A.seq0);
+    granule_store(o + 2 * 10, (double)ev.n_eval, A.seq0);
+    granule_store(o + 2 * 11, ev.dbg, A.seq0);
+    if (ev.dbg != 0.0) {
+      for (int k = 0; k < 4; ++k) granule_store(o + 2 * (12 + k), ev.dbg_raw[k], A.seq0);
+      for (int k = 16; k < 18; ++k) granule_store(o + 2 * k, 0.0, A.seq0);
+    } else {  // development: phase times in microseconds, packed two to a granule (apply | accumulate, publish | gather, gradient | total)
+      const long long t_all = (long long)wall_clock64() - t_kernel0;
+      granule_store(o + 2 * 12, (double)ev.t_apply * 0.01, A.seq0);
+      granule_store(o + 2 * 13, (double)ev.t_acc * 0.01, A.seq0);
+      granule_store(o + 2 * 14, (double)ev.t_pub * 0.01, A.seq0);
+      granule_store(o + 2 * 15, (double)ev.t_gather * 0.01, A.seq0);
+      granule_store(o + 2 * 16, (double)ev.t_grad * 0.01, A.seq0);
+      granule_store(o + 2 * 17, (double)t_all * 0.01, A.seq0);
+    }
+    granule_store(o + 2 * 18, 0.0, A.seq0);
+    granule_store(o + 2 * 19, 0.0, A.seq0);
+    granule_store(o + 2 * 0, (double)status, A.seq0);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
@@ -640,12 +964,12 @@ int gicp_direct_blocks(int n_s, int most) {
   // correspondences in registers for the whole run of the server (gicp_server_kernel<true>) takes another 9-11 % off at
   // every size (launch_gicp_server picks it whenever a lane's share is one quad).
   static const int cap = [] {
-    const char* e = std::getenv("ICPGPU_GICP_BLOCKS");
+    const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_BLOCKS");
     const int v = e ? std::atoi(e) : kGicpDirectBlocks;
     return v < 1 ? 1 : (v > kGicpDirectBlocks ? kGicpDirectBlocks : v);
   }();
   static const int per_block = [] {  // ICPGPU_GICP_PER_BLOCK (tuning): correspondences per workgroup of 256 lanes
-    const char* e = std::getenv("ICPGPU_GICP_PER_BLOCK");
+    const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_PER_BLOCK");
     const int v = e ? std::atoi(e) : 1024;
     return v < 256 ? 256 : (v > 4096 ? 4096 : v);
   }();
@@ -668,7 +992,7 @@ hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const floa
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
                               unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream) {
   // every lane's share fits one quad: up to 256 workgroups x 1024 points (ICPGPU_GICP_RESIDENT_MAX: tuning switch; 0 = never)
-  static const int resident_max = [] { const char* e = std::getenv("ICPGPU_GICP_RESIDENT_MAX"); return e ? std::atoi(e) : 262144; }();
+  static const int resident_max = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_RESIDENT_MAX"); return e ? std::atoi(e) : 262144; }();
   if ((long long)blocks * 1024 >= n_s && n_s <= resident_max)
     hipLaunchKernelGGL(gicp_server_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
                        host_partials, host_flags, cmd, first_seq, seq_hi);
@@ -676,6 +1000,44 @@ hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const floa
     hipLaunchKernelGGL(gicp_server_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
                        host_partials, host_flags, cmd, first_seq, seq_hi);
   return hipGetLastError();
+}
+
+
+// The device solver: one resident kernel per outer iteration (see gicp_solve_kernel).  `blocks` workgroups of 256 lanes, all
+// co-resident; RESIDENT when every lane's share of the correspondences is one quad.
+size_t gicp_solve_slot_bytes(int blocks) { return (size_t)2 * (size_t)blocks * kSolveGranules * 2 * sizeof(unsigned long long); }
+int gicp_solve_out_granules() { return kSolveOut; }
+hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                             const Xform& base, const float guess[16], const double* maha6, const double x0[6],
+                             unsigned long long* slots, unsigned long long* host_out, unsigned long long seq0, int max_inner,
+                             double gradient_tol, hipStream_t stream) {
+  GicpSolveArgs A;
+  A.src = src;
+  A.n_s = n_s;
+  A.tgt = tgt;
+  A.keys = keys;
+  A.thr = thr;
+  A.base = base;
+  for (int i = 0; i < 16; ++i) A.guess[i] = guess[i];
+  A.maha6 = maha6;
+  for (int i = 0; i < 6; ++i) A.x0[i] = x0[i];
+  A.slots = slots;
+  A.host_out = host_out;
+  A.seq0 = seq0;
+  A.max_inner = max_inner;
+  A.gradient_tol = gradient_tol;
+  if ((long long)blocks * 1024 >= n_s)
+    hipLaunchKernelGGL(gicp_solve_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
+  else
+    hipLaunchKernelGGL(gicp_solve_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
+  return hipGetLastError();
+}
+// host side of a granule: true and the value if it carries number `seq` and its own checksum
+bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value) {
+  const unsigned long long bits = g[0], tag = g[1];
+  if (tag != ((seq << 24) | ((bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull))) return false;
+  std::memcpy(value, &bits, sizeof bits);
+  return true;
 }
 
 }  // namespace icpgpu

@@ -1,16 +1,18 @@
 // icp_gicp_solver.h -- host side of the GICP mode (internal): the 6-parameter state <-> matrix maps and the BFGS
 // minimiser PCL runs inside every outer iteration (pcl::GeneralizedIterativeClosestPoint::estimateRigidTransformationBFGS,
 // reached from /root/reference/src/icpslam/icp_odometer.cpp:198 and src/icpslam/octree_mapper.cpp:114).  PCL's BFGS class
-// (pcl/registration/bfgs.h) is a port of GSL's vector_bfgs2 with Fletcher's line search; restated here from that
-// published algorithm (PCL itself is not in /root/reference).
+// (pcl/registration/bfgs.h) is a port of GSL's vector_bfgs2 with Fletcher's line search; restated from that published
+// algorithm in icp_gicp_solver_impl.h (PCL itself is not in /root/reference), which the device solver instantiates as well.
 #pragma once
 
-#include <array>
 #include <functional>
+
+#include "icp_gicp_solver_impl.h"
 
 namespace icpgpu {
 
-using Vec6 = std::array<double, 6>;  // tx, ty, tz, roll (about x), pitch (about y), yaw (about z)
+using Vec6 = gicp::V6;  // tx, ty, tz, roll (about x), pitch (about y), yaw (about z)
+using GicpEval = gicp::Eval;
 
 // t <- Rz(yaw) Ry(pitch) Rx(roll) * t.R ;  t.translation += (tx, ty, tz).  float, column-major 4x4 (PCL's applyState).
 void gicp_apply_state(float t[16], const Vec6& x);
@@ -19,12 +21,8 @@ Vec6 gicp_state_from_matrix(const float t[16]);
 // g[3..5] from the 3x3 sum R (row-major) through dR/d(roll, pitch, yaw) (PCL's computeRDerivative).
 void gicp_rotation_gradient(const Vec6& x, const double R[9], Vec6& g);
 
-struct GicpEval {
-  double f;
-  Vec6 g;
-};
-// evaluates cost (and gradient when want_gradient) at x; returns false on a device error
-using GicpEvalFn = std::function<bool(const Vec6& x, bool want_gradient, GicpEval& out)>;
+// evaluates cost and gradient at x; returns false on a device error
+using GicpEvalFn = std::function<bool(const Vec6& x, GicpEval& out)>;
 
 enum class GicpSolve { Ok, NotEnoughPoints, DidNotConverge, DeviceError };
 // runs <= max_inner BFGS steps from x (gradient tolerance 1e-2, PCL's line-search constants); x is updated in place

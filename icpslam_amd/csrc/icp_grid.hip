@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "icp_env.h"
 #include "icp_device.h"
 #include "icp_grid_device.h"
 #include "icp_kernels.h"
@@ -654,7 +655,7 @@ hipError_t launch_grid_finish(const float4* pts, int n, const GridDesc& g, const
 // nn_quad_kernel takes over from nn_wave_kernel at 32k points (measured: 5k 12.1 vs 9.6 us, 10k 17.2 vs 13.8, 20k-30k equal,
 // 50k 25 vs 28, 200k 58 vs 71): below that the chip is filled by giving every wave a single point.
 static bool quad_enabled() {
-  static const bool v = [] { const char* e = getenv("ICPGPU_QUAD"); return !e || atoi(e) != 0; }();  // 0: nn_wave_kernel
+  static const bool v = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_QUAD"); return !e || atoi(e) != 0; }();  // 0: nn_wave_kernel
   return v;
 }
 // counting runs: a device counter every nn_quad_kernel launch adds its evaluated target points to (grid_count_candidates)
@@ -662,7 +663,7 @@ static unsigned long long* g_count_candidates = nullptr;
 // timing experiments only: ICPGPU_SKIP_UNCERT (uncertified points are dropped -- wrong results, the octant stage's time alone)
 static int quad_debug_bits() {
   static const int v = [] {
-    if (!getenv("ICPGPU_SKIP_UNCERT")) return 0;
+    if (!ICPGPU_DEV_ENV("ICPGPU_SKIP_UNCERT")) return 0;
     fprintf(stderr, "[icpgpu] WARNING: ICPGPU_SKIP_UNCERT is set -- uncertified points are DROPPED, every result of this process is WRONG "
                     "(a timing experiment's switch, never a production setting)\n");
     return 2;
@@ -673,8 +674,8 @@ static int quad_debug_bits() {
 // (ICPGPU_CUBE_START=0: at 1); bits 8..15: cap of the start radius in sweeps without one (ICPGPU_CUBE_COLD_CAP, default 1).
 static int cube_start_mask() {
   static const int v = [] {
-    const char* e = getenv("ICPGPU_CUBE_START");
-    const char* c = getenv("ICPGPU_CUBE_COLD_CAP");
+    const char* e = ICPGPU_DEV_ENV("ICPGPU_CUBE_START");
+    const char* c = ICPGPU_DEV_ENV("ICPGPU_CUBE_COLD_CAP");
     const int warm = e ? (atoi(e) & 1) : 1, cold = c ? atoi(c) : 1;
     return warm | ((cold < 1 ? 1 : cold > 255 ? 255 : cold) << 8);
   }();
@@ -684,7 +685,7 @@ static bool use_quad(int n_s) { return quad_enabled() && n_s >= 4 * 8192; }
 
 // points per wave: up to 16 for large clouds, fewer when that would leave most of the 256 CUs x 8 waves/SIMD idle
 static int queries_per_wave(int n_s) {
-  static const int forced = [] { const char* e = getenv("ICPGPU_QPW"); return e ? atoi(e) : 0; }();  // experiments: 4, 8, 12, 16
+  static const int forced = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_QPW"); return e ? atoi(e) : 0; }();  // experiments: 4, 8, 12, 16
   if (forced >= 4 && forced <= WQ_MAX_QPW && use_quad(n_s)) return forced & ~3;
   int q = n_s / 8192;
   if (use_quad(n_s)) q = (q + 3) & ~3;  // four points per pass

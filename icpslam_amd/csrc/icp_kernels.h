@@ -230,6 +230,17 @@ hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const
 // memory the host writes through the BAR (cmd: 12 floats of T, then the sequence number), evaluates, answers through
 // host_partials / host_flags like the direct kernel (flag = seq_hi << 32 | sequence number) and leaves on sequence number
 // kGicpServerExit (acknowledged by host_flags[0] = ~0) or after 50 ms without a command.
+// The device solver (icp_gicp.hip: gicp_solve_kernel): the whole BFGS run of an outer iteration inside one resident kernel.
+// slots: gicp_solve_slot_bytes(blocks) of FINE-GRAINED device memory; host_out: gicp_solve_out_granules() granules (16 B each) of
+// the host mailbox -- granule 0 the status (gicp::Status), 1..6 the state, 7 m, 8 sum d2, 9 f at the start, 10 evaluations --
+// each carrying number seq0 and a checksum (gicp_granule_read).  Evaluation e of the run uses number seq0 + e.
+size_t gicp_solve_slot_bytes(int blocks);
+int gicp_solve_out_granules();
+hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                             const Xform& base, const float guess[16], const double* maha6, const double x0[6],
+                             unsigned long long* slots, unsigned long long* host_out, unsigned long long seq0, int max_inner,
+                             double gradient_tol, hipStream_t stream);
+bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value);
 static constexpr unsigned int kGicpServerExit = 0xFFFFFFFFu;
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
@@ -247,10 +258,22 @@ struct ApproxBox {
   double res;
   int depth;
 };
+// PCL assigns a point's leaf key ONCE, from the bounding box of the moment it is added (genOctreeKeyforPoint), and re-roots the
+// tree when the box doubles -- a stored key then moves by whole voxels with the minimum; it is never recomputed from the new
+// minimum (which could round the other way for a point on a voxel border: the FIRST point sits on one by construction, the
+// first box being centred on it).  The history of the box: version v is in force from map index first[v] on; a point added
+// under it has key trunc((p - min[v]) / res) + (shift_now - shift[v]), shifts in voxels.
+constexpr int kApproxMaxVersions = 24;
+struct ApproxHistory {
+  int n;
+  int first[kApproxMaxVersions];
+  double min[kApproxMaxVersions][3];
+  long long shift[kApproxMaxVersions][3];
+};
 hipError_t launch_approx_first_outside(const float4* pts, int n, const ApproxBox& b, int* d_first, hipStream_t stream);
 hipError_t launch_approx_fill(unsigned long long* keys, int* vals, unsigned int cap, hipStream_t stream);
-hipError_t launch_approx_insert(const float4* pts, int lo, int hi, const ApproxBox& b, unsigned long long* keys, int* vals,
-                                unsigned int cap, hipStream_t stream);
+hipError_t launch_approx_insert(const float4* pts, int lo, int hi, const ApproxBox& b, const ApproxHistory& h, unsigned long long* keys,
+                                int* vals, unsigned int cap, hipStream_t stream);
 hipError_t launch_approx_descend(const float4* queries, int n, const Xform& T, const ApproxBox& b, const unsigned long long* keys,
                                  const int* vals, unsigned int cap, unsigned long long* out, hipStream_t stream);
 int approx_max_depth();

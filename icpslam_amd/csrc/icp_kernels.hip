@@ -336,11 +336,7 @@ __device__ __forceinline__ void reduce_final_body(const double* __restrict__ par
       // the host mailbox: {sum, seq} as ONE 16-byte store written through to system memory -- a pair is never seen
       // half-written, so the host needs no flag behind a system-scope release (a write-back + a wait for the sum's
       // acknowledgement before the flag may leave: ~1 us of every ICP iteration)
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(sum);
-      const u32x4 v = {(unsigned int)bits, (unsigned int)(bits >> 32), (unsigned int)seq, (unsigned int)(seq >> 32)};
-      unsigned long long* p = flags + 2 * k;
-      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+      store_pair_system(flags + 2 * k, (unsigned long long)__double_as_longlong(sum), seq);
     } else {
       sums[k] = sum;
     }

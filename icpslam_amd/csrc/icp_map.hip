@@ -203,13 +203,6 @@ constexpr int kApproxMaxDepth = 19;  // 19 bits per axis + 5 bits of level in a 
 __device__ __forceinline__ unsigned long long node_key(int level, long long kx, long long ky, long long kz) {
   return ((unsigned long long)level << 57) | ((unsigned long long)kx << 38) | ((unsigned long long)ky << 19) | (unsigned long long)kz;
 }
-// genOctreeKeyforPoint: truncation of (p - min) / resolution, double
-__device__ __forceinline__ void approx_leaf_key(const ApproxBox& b, const float4& p, long long& kx, long long& ky, long long& kz) {
-  kx = (long long)(((double)p.x - b.min[0]) / b.res);
-  ky = (long long)(((double)p.y - b.min[1]) / b.res);
-  kz = (long long)(((double)p.z - b.min[2]) / b.res);
-}
-
 // first map point of pts[0..n) (index order) that lies outside the box: *first = min index (INT_MAX: none)
 __global__ __launch_bounds__(256) void approx_first_outside_kernel(const float4* __restrict__ pts, int n, ApproxBox b,
                                                                    int* __restrict__ first) {
@@ -234,12 +227,20 @@ __global__ __launch_bounds__(256) void approx_fill_kernel(unsigned long long* __
 
 // the nodes on the path root -> leaf of map points [lo, hi)
 __global__ __launch_bounds__(256) void approx_insert_kernel(const float4* __restrict__ pts, int lo, int hi, ApproxBox b,
-                                                            unsigned long long* __restrict__ keys, int* __restrict__ vals,
-                                                            unsigned int mask) {
+                                                            ApproxHistory h, unsigned long long* __restrict__ keys,
+                                                            int* __restrict__ vals, unsigned int mask) {
   const int i = lo + blockIdx.x * 256 + threadIdx.x;
   if (i >= hi) return;
-  long long kx, ky, kz;
-  approx_leaf_key(b, pts[i], kx, ky, kz);
+  // the key PCL gave the point when it was added (box version v = the last one whose first index is <= i), moved by the
+  // whole voxels the minimum has moved since
+  int v = 0;
+  for (int k = 1; k < h.n; ++k)
+    if (h.first[k] <= i) v = k;
+  const float4 p = pts[i];
+  const int cur = h.n - 1;
+  const long long kx = (long long)(((double)p.x - h.min[v][0]) / b.res) + (h.shift[cur][0] - h.shift[v][0]);
+  const long long ky = (long long)(((double)p.y - h.min[v][1]) / b.res) + (h.shift[cur][1] - h.shift[v][1]);
+  const long long kz = (long long)(((double)p.z - h.min[v][2]) / b.res) + (h.shift[cur][2] - h.shift[v][2]);
   for (int d = 1; d <= b.depth; ++d) {
     const int sh = b.depth - d;
     const int s = find_or_claim(keys, mask, node_key(d, kx >> sh, ky >> sh, kz >> sh));
@@ -380,10 +381,10 @@ hipError_t launch_approx_fill(unsigned long long* keys, int* vals, unsigned int 
   hipLaunchKernelGGL(approx_fill_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, keys, vals, cap);
   return hipGetLastError();
 }
-hipError_t launch_approx_insert(const float4* pts, int lo, int hi, const ApproxBox& b, unsigned long long* keys, int* vals,
-                                unsigned int cap, hipStream_t stream) {
-  if (hi <= lo || b.depth == 0) return hipSuccess;
-  hipLaunchKernelGGL(approx_insert_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, stream, pts, lo, hi, b, keys, vals, cap - 1);
+hipError_t launch_approx_insert(const float4* pts, int lo, int hi, const ApproxBox& b, const ApproxHistory& h, unsigned long long* keys,
+                                int* vals, unsigned int cap, hipStream_t stream) {
+  if (hi <= lo || b.depth == 0 || h.n < 1) return hipSuccess;
+  hipLaunchKernelGGL(approx_insert_kernel, dim3((hi - lo + 255) / 256), dim3(256), 0, stream, pts, lo, hi, b, h, keys, vals, cap - 1);
   return hipGetLastError();
 }
 hipError_t launch_approx_descend(const float4* queries, int n, const Xform& T, const ApproxBox& b, const unsigned long long* keys,

@@ -23,6 +23,8 @@
 // arithmetic with the lowest original index among ties -- what nn_quad_kernel returns -- and empty otherwise.
 #include <hip/hip_runtime.h>
 
+#include "icp_env.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <math.h>
@@ -405,12 +407,12 @@ hipError_t launch_nn_tile_search(const float4* src_morton, int n_q, const Xform&
                                  float4* prev, bool use_prev, unsigned long long* keys, unsigned long long* stats,
                                  hipStream_t stream) {
   if (n_q <= 0 || n_t <= 0) return hipSuccess;
-  static const int splits_env = [] { const char* e = getenv("ICPGPU_TILE_SPLITS"); return e ? atoi(e) : 4; }();
+  static const int splits_env = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_TILE_SPLITS"); return e ? atoi(e) : 4; }();
   const int per_block = (TS_BLOCK / 64) * 32 * TS_G;
   const int grid_x = (n_q + per_block - 1) / per_block;
   const int splits = splits_env < 1 ? 1 : splits_env > 64 ? 64 : splits_env;
   static const int no_exact = [] {
-    if (!getenv("ICPGPU_TILE_NO_EXACT")) return 0;
+    if (!ICPGPU_DEV_ENV("ICPGPU_TILE_NO_EXACT")) return 0;
     fprintf(stderr, "[icpgpu] WARNING: ICPGPU_TILE_NO_EXACT is set -- the tile search skips its exact path, its results are WRONG (timing experiment)\n");
     return 2;
   }();

@@ -12,6 +12,8 @@
 //     over (a voxel bucket beyond its LDS capacity, wrapped indices, clouds over 2M points).
 #include <hip/hip_runtime.h>
 
+#include "icp_env.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -656,13 +658,13 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   hipLaunchKernelGGL(voxel_scatter_kernel, dim3(blocks), dim3(VX_BLOCK), 0, stream, keys, relpos, n, cpb, nbins, hist, groups,
                      group_range, status, comp);
   // ICPGPU_VOXEL_DEBUG=1 (development): phase time stamps of every group, the slowest ones printed
-  static const bool debug = [] { const char* e = std::getenv("ICPGPU_VOXEL_DEBUG"); return e && std::atoi(e) != 0; }();
+  static const bool debug = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_DEBUG"); return e && std::atoi(e) != 0; }();
   long long* dbg = nullptr;
   if (debug && hipMalloc(reinterpret_cast<void**>(&dbg), (size_t)groups * 8 * sizeof(long long)) == hipSuccess)
     (void)hipMemsetAsync(dbg, 0, (size_t)groups * 8 * sizeof(long long), stream);
   // ICPGPU_VOXEL_TEST_STALL=1 (tests): the first group publishes 30 ms late -- the others give up, the sort path takes over
   static const int test_stall = [] {
-    const char* e = std::getenv("ICPGPU_VOXEL_TEST_STALL");
+    const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_TEST_STALL");
     const int v = e ? std::atoi(e) : 0;
     if (v) std::fprintf(stderr, "[icpgpu] WARNING: ICPGPU_VOXEL_TEST_STALL is set -- every voxel-filter call stalls 30 ms and falls back to the "
                                 "sort path (results unchanged; a test's switch, never a production setting)\n");

@@ -51,7 +51,7 @@ void set_ctx_host_share(icpgpu_ctx* c, int peers) {
 static size_t batch_threads(const icpgpu_ctx* c, size_t cap) {
   size_t t = 0;
   if (const char* v = std::getenv("ICPGPU_BATCH_THREADS")) t = (size_t)std::max(0, std::atoi(v));
-  else if (const char* w = std::getenv("ICPGPU_BATCH_WORKERS")) t = (size_t)std::max(0, std::atoi(w));  // round-1 name
+  else if (const char* w = ICPGPU_DEV_ENV("ICPGPU_BATCH_WORKERS")) t = (size_t)std::max(0, std::atoi(w));  // round-1 name
   if (t == 0) {
     int local = 1;
     if (const char* l = std::getenv("LOCAL_WORLD_SIZE")) local = std::max(1, std::atoi(l));
@@ -80,7 +80,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   // reduction launch (17 x K workgroups) + K host solves, instead of K x (launch + reduce + poll): ~35 launches per K
   // pairs where there were ~35 per pair.  Two threads keep the GPU fed (one copies its next group in while the other's
   // group iterates); results are bit-identical to icpgpu_align's (same kernels' bodies, same workgroup -> point mapping).
-  static const bool lockstep_on = [] { const char* e = std::getenv("ICPGPU_BATCH_LOCKSTEP"); return !e || std::atoi(e) != 0; }();
+  static const bool lockstep_on = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_LOCKSTEP"); return !e || std::atoi(e) != 0; }();
   const bool lockstep = lockstep_on && !gicp;
   size_t n_threads = batch_threads(c, gicp ? 8 : 4), depth = 1;
   if (!gicp) {
@@ -192,7 +192,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       };
       int timed_pairs = 0;          // pairs of the launch whose events are outstanding
       unsigned step_counter = 0;
-      static const bool bt_on = [] { const char* e = std::getenv("ICPGPU_BATCH_TIMING"); return e && std::atoi(e) != 0; }();
+      static const bool bt_on = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_TIMING"); return e && std::atoi(e) != 0; }();
       double bt_fill = 0, bt_build = 0, bt_iter = 0;
       size_t bt_groups = 0, bt_steps = 0;
       struct BtPrint {
@@ -543,6 +543,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.gicp_eval_ms += p.gicp_eval_ms; c->prof.gicp_eval_corr += p.gicp_eval_corr; c->prof.gicp_cov_points += p.gicp_cov_points;
     c->prof.targets_recognised += p.targets_recognised;
     c->prof.brute_bound_violations += p.brute_bound_violations;
+    c->prof.gicp_device_solves += p.gicp_device_solves;
     if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;
     std::memset(&p, 0, sizeof(p));
   }

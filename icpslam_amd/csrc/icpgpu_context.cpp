@@ -185,7 +185,7 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   c->device = device_id;
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   icpgpu_default_params(&c->params);
-  if (const char* v = std::getenv("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
+  if (const char* v = ICPGPU_DEV_ENV("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
 
   auto bail = [&](const char* what, hipError_t err) {
     std::string msg = std::string(what) + ": " + hipGetErrorString(err);
@@ -221,6 +221,18 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
     c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
     c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
     (void)cmd_off;
+  }
+  if (gicp_device_solver_enabled()) {  // the device solver's slots and result granules; without them GICP solves on the host
+    const size_t slot_bytes = gicp_solve_slot_bytes(kGicpDirectBlocks);
+    void* h = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_slots), slot_bytes, hipDeviceMallocFinegrained) == hipSuccess &&
+        hipMemset(c->gicp_slots, 0, slot_bytes) == hipSuccess &&
+        hipHostMalloc(&h, 512, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      std::memset(h, 0, 512);
+      c->h_solve = static_cast<volatile unsigned long long*>(h);
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_solve_dev), h, 0) == hipSuccess) c->gicp_device_ok = true;
+    }
+    if (!c->gicp_device_ok) (void)hipGetLastError();
   }
   if (gicp_server_enabled()) {  // no such memory (no large BAR): the evaluations stay single launches
     if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_cmd), 4096, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -322,6 +334,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_gicp) (void)hipHostFree(c->h_gicp);
   if (c->gicp_cmd) (void)hipFree(c->gicp_cmd);
+  if (c->gicp_slots) (void)hipFree(c->gicp_slots);
+  if (c->h_solve) (void)hipHostFree(const_cast<unsigned long long*>(c->h_solve));
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)
     if (ev) (void)hipEventDestroy(ev);

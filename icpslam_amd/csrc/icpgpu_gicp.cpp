@@ -31,7 +31,7 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   if (cov_version == version && cov.ptr) return ICPGPU_OK;
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
-  static const double knn_pop = [] { const char* e = std::getenv("ICPGPU_KNN_POP"); return e ? std::atof(e) : 8.0; }();
+  static const double knn_pop = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_KNN_POP"); return e ? std::atof(e) : 8.0; }();
   int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G, nullptr, knn_pop);
   if (rc) return rc;
   if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
@@ -148,6 +148,50 @@ static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, b
   return 0;
 }
 
+// The device solver's result: kSolveOut granules carrying number `seq`.  0 = all there (values in out[]), 1 = the stream went
+// idle without them (the kernel gave up: the caller falls back to the host's solver), < 0 = error.
+static int wait_solve_result(icpgpu_ctx* c, unsigned long long seq, double* out) {
+  const int n = gicp_solve_out_granules();
+  auto all_there = [&]() {
+    bool all = true;
+    for (int k = 0; k < n; ++k) all = gicp_granule_read(c->h_solve + 2 * k, seq, &out[k]) && all;
+    return all;
+  };
+  std::chrono::steady_clock::time_point t0;
+  for (unsigned spins = 1;; ++spins) {
+    if (all_there()) break;
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (all_there()) break;
+        return 1;
+      }
+      if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for the GICP device solver: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for the GICP device solver (hung kernel?)", wait_timeout_ms());
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
+// workgroups of a device-solver run: one per 1024 correspondences while every lane's share stays one quad in registers; larger
+// clouds stream their shares with at most kSolveStreamBlocks workgroups (every workgroup gathers every other's 28 granules per
+// evaluation: the gather grows with the count)
+static int gicp_solve_blocks(int n_s, int most) {
+  constexpr int kSolveStreamBlocks = 64;
+  static const int cap = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_SOLVE_BLOCKS"); const int v = e ? std::atoi(e) : kSolveStreamBlocks; return v < 1 ? 1 : (v > kGicpDirectBlocks ? kGicpDirectBlocks : v); }();
+  int blocks = (n_s + 1023) / 1024;
+  if (blocks > cap) blocks = cap;
+  if (blocks > most) blocks = most;
+  return blocks < 1 ? 1 : blocks;
+}
+
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res) {
   struct ServerGuard {  // whatever way this function is left, no server stays behind
     icpgpu_ctx* c;
@@ -227,7 +271,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
 
     // rigid_transformation_estimation_: BFGS over x = (t, roll, pitch, yaw), every evaluation one reduction on the device
     double m_count = 0.0;
-    auto eval = [&](const Vec6& x, bool want_gradient, GicpEval& out) -> bool {
+    auto eval = [&](const Vec6& x, GicpEval& out) -> bool {
       float T[16];
       std::memcpy(T, guess, sizeof(T));
       gicp_apply_state(T, x);
@@ -238,7 +282,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       if ((unsigned int)seq == kGicpServerExit) seq = (c->sums_seq += 2);  // (never a command number; the server skips it too)
       const int nblk = gicp_direct_blocks(n_s, c->gicp_blocks_most);
       bool have = false;
-      static const bool timing = [] { const char* e = std::getenv("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
+      static const bool timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
       std::chrono::steady_clock::time_point tq0, tq1, tq2;
       if (timing) {
         tq0 = std::chrono::steady_clock::now();
@@ -288,39 +332,71 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       c->prof.gicp_eval_corr += (uint64_t)s[0];
       m_count = s[0];
       mse = s[0] > 0 ? s[14] / s[0] : 0.0;
-      if (!(s[0] >= 1.0)) {
-        out.f = 0.0;
-        out.g.fill(0.0);
-        return true;
-      }
-      out.f = s[1] / s[0];
-      if (want_gradient) {
-        const double sc = 2.0 / s[0];
-        double Rm[9];
-        for (int k = 0; k < 3; ++k) out.g[k] = s[2 + k] * sc;
-        for (int k = 0; k < 9; ++k) Rm[k] = s[5 + k] * sc;
-        gicp_rotation_gradient(x, Rm, out.g);
-      }
+      gicp::eval_from_sums(x, s, out);
       return true;
     };
-    // the ~35 dependent evaluations of this outer iteration go to a resident kernel (queued behind the two kernels above)
-    if ((rc = gicp_server_start(c, n_s, keys, thr_excl, base, maha))) return rc;
-    // number of correspondences (one evaluation at the current state; it is also the BFGS start, cached by the solver)
+    // rigid_transformation_estimation_: the whole BFGS run on the device (gicp_solve_kernel), one result for the host to poll
     Vec6 x = gicp_state_from_matrix(transformation);
-    GicpEval probe;
-    if (!eval(x, true, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
-    n_corr = (unsigned)m_count;
-    std::memcpy(previous, transformation, sizeof(previous));
-    if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
-      state = ICPGPU_CONV_NO_CORRESPONDENCES;
-      break;
+    bool solved = false;
+    if (c->gicp_device_ok && c->gicp_server_allowed) {
+      const auto t_solve0 = std::chrono::steady_clock::now();
+      const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
+      const unsigned long long seq0 = (c->gicp_solve_seq += 8192);  // evaluation e of the run carries seq0 + e (e < 8192: <= 20 steps of <= 200 trials)
+      HIP_TRY(c, launch_gicp_solve(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, base, guess, maha, x.v, c->gicp_slots,
+                                   c->h_solve_dev, seq0, 20, 1e-2, c->stream));
+      double out[24];
+      const int w = wait_solve_result(c, seq0, out);
+      if (w < 0) return w;
+      const int status = w == 0 ? (int)out[0] : (int)gicp::kDeviceError;
+      if (status == gicp::kDeviceError) {  // a gather timed out (or the kernel never answered): the host's solver from here on
+        c->gicp_device_ok = false;
+        if (std::getenv("ICPGPU_DEBUG"))
+          fprintf(stderr, "[icpgpu] gicp device solver gave up (%s, %d workgroups, record %.0f); falling back to the host solver\n",
+                  w == 0 ? "a gather timed out" : "no answer", nblk, w == 0 ? out[11] : -1.0);
+        if (std::getenv("ICPGPU_DEBUG") && w == 0)
+          fprintf(stderr, "[icpgpu]   seq0 %llu: hi granule number %.0f checksum %.0f, lo granule number %.0f, checksum of the hi bits %.0f\n", seq0, out[12], out[13], out[14], out[15]);
+      } else {
+        solved = true;
+        c->prof.gicp_device_solves += 1;
+        const double m = out[7], evals = out[10];
+        m_count = m;
+        mse = m > 0 ? out[8] / m : 0.0;
+        n_corr = (unsigned)m;
+        c->prof.gicp_cost_launches += (uint64_t)evals;
+        c->prof.gicp_eval_corr += (uint64_t)(m * evals);
+        c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_solve0).count();
+        std::memcpy(previous, transformation, sizeof(previous));
+        if (status == gicp::kNotEnoughPoints) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+          state = ICPGPU_CONV_NO_CORRESPONDENCES;
+          break;
+        }
+        if (status != gicp::kOk) {  // SolverDidntConvergeException
+          state = ICPGPU_NOT_CONVERGED;
+          break;
+        }
+        for (int k = 0; k < 6; ++k) x[k] = out[1 + k];
+      }
     }
-    const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
-    gicp_server_stop(c);
-    if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
-    if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
-      state = ICPGPU_NOT_CONVERGED;
-      break;
+    if (!solved) {
+      // the ~35 dependent evaluations of this outer iteration go to a resident kernel (queued behind the two kernels above)
+      if ((rc = gicp_server_start(c, n_s, keys, thr_excl, base, maha))) return rc;
+      // number of correspondences (one evaluation at the current state; it is also the BFGS start, cached by the solver)
+      x = gicp_state_from_matrix(transformation);
+      GicpEval probe;
+      if (!eval(x, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+      n_corr = (unsigned)m_count;
+      std::memcpy(previous, transformation, sizeof(previous));
+      if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+        state = ICPGPU_CONV_NO_CORRESPONDENCES;
+        break;
+      }
+      const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
+      gicp_server_stop(c);
+      if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+      if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
+        state = ICPGPU_NOT_CONVERGED;
+        break;
+      }
     }
     mat4f_identity(transformation);
     gicp_apply_state(transformation, x);

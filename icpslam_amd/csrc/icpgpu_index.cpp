@@ -6,7 +6,7 @@
 namespace icpgpu_impl {
 
 static double sparse_population() {  // ICPGPU_SPARSE_POP overrides (tuning experiments only)
-  static const double v = [] { const char* e = std::getenv("ICPGPU_SPARSE_POP"); return e ? std::atof(e) : kSparseCellPopulation; }();
+  static const double v = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_SPARSE_POP"); return e ? std::atof(e) : kSparseCellPopulation; }();
   return v;
 }
 
@@ -17,7 +17,7 @@ static double sparse_population() {  // ICPGPU_SPARSE_POP overrides (tuning expe
 // depend on what the context did before.)
 static double grid_divisor() {
   static const double d = [] {
-    const char* v = std::getenv("ICPGPU_GRID_DIV");
+    const char* v = ICPGPU_DEV_ENV("ICPGPU_GRID_DIV");
     const double x = v ? std::atof(v) : 0.0;
     return (x >= 1.0 && x <= 64.0) ? x : 4.5;
   }();
@@ -102,7 +102,7 @@ int gb_issue_count(icpgpu_ctx* c, GridBuild& b) {
   g.nx = (int)nx;
   g.ny = (int)ny;
   g.nz = (int)nz;
-  if (nz <= ny && !std::getenv("ICPGPU_Z_OUTER")) {
+  if (nz <= ny && !ICPGPU_DEV_ENV("ICPGPU_Z_OUTER")) {
     g.sy = g.nx * g.nz;  // y outermost, z in the middle (the usual case: a scene much wider than it is tall)
     g.sz = g.nx;
   } else {
@@ -143,7 +143,7 @@ int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
   const int attempt = b.attempt;
   bool again = false;
   if (attempt == 0 && b.adapt && pop > kDenseCellPopulation) {
-    static const double target_pop = [] { const char* e = std::getenv("ICPGPU_TARGET_POP"); return e ? std::atof(e) : kTargetCellPopulation; }();
+    static const double target_pop = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_TARGET_POP"); return e ? std::atof(e) : kTargetCellPopulation; }();
     const double h_new = std::max(h * std::sqrt(target_pop / pop), cut / 16.0);
     if (h_new < 0.9 * h) {
       h = h_new;
@@ -237,7 +237,7 @@ int grid_flags(const GridIndex& G, bool src_in_cell_order) {
 // keeps none (ICPGPU_PREV=0 switches the mechanism off: A/B measurements).  use = the entries come from a sweep of the
 // same queries over the same target points.
 int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, float4*& buf, bool& use) {
-  static const bool enabled = [] { const char* e = std::getenv("ICPGPU_PREV"); return !e || std::atoi(e) != 0; }();
+  static const bool enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_PREV"); return !e || std::atoi(e) != 0; }();
   buf = nullptr;
   use = false;
   if (!enabled || !grid_search_keeps_prev(n_q, flags)) return ICPGPU_OK;
@@ -315,7 +315,7 @@ bool grid_ready(const icpgpu_ctx* c) { return c->grid.usable && c->grid.version 
 // promote_source_to_target and brings this grid along, so every cloud is binned exactly once.  The order of the source
 // is irrelevant to the fused reduction; paths that return per-point results keep the caller's order.
 int source_order_mode() {  // ICPGPU_ORDER_SOURCE=0/1 overrides the size rule (experiments)
-  static const int m = [] { const char* v = std::getenv("ICPGPU_ORDER_SOURCE"); return v ? std::atoi(v) : -1; }();
+  static const int m = [] { const char* v = ICPGPU_DEV_ENV("ICPGPU_ORDER_SOURCE"); return v ? std::atoi(v) : -1; }();
   return m;
 }
 

@@ -165,7 +165,10 @@ void approx_adopt(VoxelMap& M, const float p[3]) {
     if (!any) return;
     const double side = (double)(1ll << b.depth) * b.res;
     for (int a = 0; a < 3; ++a)
-      if (!upper[a]) b.min[a] -= side;
+      if (!upper[a]) {
+        b.min[a] -= side;
+        M.box_shift[a] += 1ll << b.depth;  // stored keys move by whole voxels with the minimum
+      }
     b.depth += 1;
     for (int a = 0; a < 3; ++a) b.max[a] = b.min[a] + ((double)(1ll << b.depth) * b.res - eps);
   }
@@ -195,6 +198,16 @@ int approx_nn_keys(icpgpu_ctx* c, const Xform& T, int n_s, unsigned long long* k
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     approx_adopt(M, p);
     M.box_version++;
+    if (M.box_hist.n >= kApproxMaxVersions) return fail(c, ICPGPU_ERR_UNSUPPORTED, "map: the octree's bounding box changed more than %d times", kApproxMaxVersions);
+    {  // the version in force from this point on (the point that made the box grow is keyed under the grown box)
+      ApproxHistory& H = M.box_hist;
+      H.first[H.n] = M.box_upto;
+      for (int a = 0; a < 3; ++a) {
+        H.min[H.n][a] = M.box.min[a];
+        H.shift[H.n][a] = M.box_shift[a];
+      }
+      H.n += 1;
+    }
     M.box_upto += 1;
     if (M.box.depth > approx_max_depth()) break;  // (reported below -- on this call and on every later one)
   }
@@ -224,7 +237,7 @@ int approx_nn_keys(icpgpu_ctx* c, const Xform& T, int n_s, unsigned long long* k
     M.nodes_upto = 0;
     M.nodes_box_version = M.box_version;
   }
-  HIP_TRY(c, launch_approx_insert(M.pts.data(), M.nodes_upto, M.n, M.box, nk, nv, M.node_cap, c->stream));
+  HIP_TRY(c, launch_approx_insert(M.pts.data(), M.nodes_upto, M.n, M.box, M.box_hist, nk, nv, M.node_cap, c->stream));
   M.nodes_upto = M.n;
   // (3) the descent
   HIP_TRY(c, launch_approx_descend(c->src.data(), n_s, T, M.box, nk, nv, M.node_cap, keys, c->stream));
@@ -255,6 +268,8 @@ int icpgpu_map_reset(icpgpu_ctx* c, double resolution) {
   M.version++;
   M.cap = 0;  // the hash set is rebuilt by the next insertion
   M.box_defined = false;
+  M.box_hist.n = 0;
+  M.box_shift[0] = M.box_shift[1] = M.box_shift[2] = 0;
   M.box_upto = 0;
   M.box_version++;
   M.nodes_upto = 0;

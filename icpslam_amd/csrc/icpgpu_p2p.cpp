@@ -35,7 +35,7 @@ int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T,
         if ((rc = source_in_morton_order(c))) return rc;
         // test mode (ICPGPU_MFMA_CHECK_BOUND=1, read per call): every pair evaluated exactly against its bound; the counters
         // land in the profile (brute_bound_violations must stay 0)
-        const char* chk = getenv("ICPGPU_MFMA_CHECK_BOUND");
+        const char* chk = ICPGPU_DEV_ENV("ICPGPU_MFMA_CHECK_BOUND");
         unsigned long long* d_check = nullptr;
         if (chk && atoi(chk)) {
           if ((rc = ensure(c, O.check, 2 * sizeof(unsigned long long)))) return rc;
@@ -167,7 +167,7 @@ int wait_sums(icpgpu_ctx* c, unsigned long long seq) {
 
 
 int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, SweepTicket& tk) {
-  static const bool timing = [] { const char* e = std::getenv("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
+  static const bool timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
   if (timing) {
     c->pt_issue_in = std::chrono::steady_clock::now();
     if (c->pt_n) c->pt_solve += std::chrono::duration<double, std::micro>(c->pt_issue_in - c->pt_ready).count();
@@ -190,11 +190,16 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
   const float4* red_src = nullptr;
   int red_n = 0;
   volatile int* few_host = nullptr;
-  // EXPERIMENTAL (off by default, read per sweep so that a test can switch it): the grid search on the matrix cores,
-  // icp_tile.hip -- bit-identical results, faster at 50k x 50k, slower at 200k x 200k (experiments)
-  const char* tile_env = std::getenv("ICPGPU_TILE_SEARCH");
+#if defined(ICPGPU_DEV_SWITCHES)
+  // EXPERIMENT, development flavour only (libicpgpu_dev.so; icp_tile.hip is not part of the release library): the grid search
+  // on the matrix cores -- bit-identical results, faster at 50k x 50k, slower at 200k x 200k (experiments).
+  // Read per sweep so that a test can switch it.
+  const char* tile_env = ICPGPU_DEV_ENV("ICPGPU_TILE_SEARCH");
   const int tile_search = tile_env ? std::atoi(tile_env) : 0;
-  if (use_grid && !open_range && tile_search && source_ordered(c) && n_s >= kMfmaMinPoints) {
+#endif
+  if (false) {
+#if defined(ICPGPU_DEV_SWITCHES)
+  } else if (use_grid && !open_range && tile_search && source_ordered(c) && n_s >= kMfmaMinPoints) {
     // the grid search on the matrix cores (icp_tile.hip): keys, then the keys-path reduction
     if ((rc = source_in_morton_order(c))) return rc;
     TileSeed& S = c->tile_seed;
@@ -233,6 +238,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
     HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
+#endif
   } else if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
     const bool ordered = source_ordered(c);
@@ -480,7 +486,7 @@ int p2p_advance(icpgpu_ctx* c, P2PRun& r, int* deferred) {
 int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
   P2PRun r;
   int rc = p2p_begin(c, r, guess, out_xyzw, want_fitness, res);
-  static const bool timing = [] { const char* e = std::getenv("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
+  static const bool timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
   while (!rc && r.phase != P2PRun::Done) {
     const auto t0 = std::chrono::steady_clock::now();
     if ((rc = wait_sums(c, r.ticket.seq))) break;

@@ -41,7 +41,7 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   float ms = 0.f;
   // the direct path (one distribution pass + a sort in LDS): every cloud up to 2M points; it reports the rare cloud it cannot
   // take (thousands of points in one voxel) through `status`, and the library-sort path runs instead
-  static const bool force_sort = [] { const char* e = std::getenv("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
+  static const bool force_sort = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
   bool done = false;
   // (PCL's overflow test uses the float extents, its cell index the integer ones: when these are one cell wider the index of
   // the topmost cells can wrap in int32 and PCL -- and the sort path, on signed keys -- puts them first.  The direct path's

@@ -144,6 +144,7 @@ typedef struct {
   uint64_t targets_recognised; /* icpgpu_set_target calls that found the cloud already in HBM (no upload, no rebuild) */
   uint64_t brute_bound_violations; /* test mode ICPGPU_MFMA_CHECK_BOUND=1 of the bf16 matrix-core search: pairs whose lower bound */
   double brute_bound_worst;        /*   exceeded what their own exact distance allows (must stay 0); worst excess / (P^2 + |v|^2) seen */
+  uint64_t gicp_device_solves;     /* GICP outer iterations whose whole inner BFGS ran on the device (gicp_solve_kernel) */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

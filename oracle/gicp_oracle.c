@@ -23,6 +23,7 @@
  */
 #include <float.h>
 #include <math.h>
+#include <quadmath.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -262,13 +263,26 @@ int orc_gicp_covariances(const float* cloud, size_t n, int arith, double* cov_ou
 /* ------------------------------------------------------------------------------------------ */
 /* applyState / cost / gradient                                                                */
 /* ------------------------------------------------------------------------------------------ */
+/* The sines and cosines of the state maps.  PCL takes them from the platform's libm (Eigen::AngleAxisf: cosf / sinf;
+ * computeRDerivative: cos / sin), whose results are not portable -- glibc 2.35's differ from the correctly rounded value on
+ * 0.2 % (sin), 0.1 % (cos), 1.8 % (sinf), 0.7 % (cosf) of random arguments -- and BFGS amplifies an ulp.  So, like the sums:
+ *   ORC_GICP_SUMS_EXACT       (the contract a parallel implementation is compared with bit for bit): the CORRECTLY ROUNDED
+ *                             functions -- evaluated in binary128 (libquadmath: 113 bits), rounded once;
+ *   ORC_GICP_SUMS_SEQUENTIAL* (PCL's own evaluation): this platform's libm, as a PCL built here would call it.
+ * (The product computes the correctly rounded values its own way -- double-double arithmetic, icpslam_amd/csrc/icp_trig.h --
+ * so agreement is a test of both.)  Thread-local: the mode of the orc_icp_align call running on this thread. */
+static __thread int tl_trig_cr = 1;
+static double o_sin(double x) { return tl_trig_cr ? (double)sinq((__float128)x) : sin(x); }
+static double o_cos(double x) { return tl_trig_cr ? (double)cosq((__float128)x) : cos(x); }
+static float o_sinf(float x) { return tl_trig_cr ? (float)sinq((__float128)x) : sinf(x); }
+static float o_cosf(float x) { return tl_trig_cr ? (float)cosq((__float128)x) : cosf(x); }
 /* t <- Rz(x5) Ry(x4) Rx(x3) * t.R ; t.col(3) += (x0, x1, x2).  float, like Eigen's Matrix4f/AngleAxisf path:
  * each AngleAxis becomes a quaternion (cos a/2, sin a/2 * axis), the product is converted to a rotation matrix. */
 static void apply_state(float t[16], const double x[6]) {
   const float hx = 0.5f * (float)x[3], hy = 0.5f * (float)x[4], hz = 0.5f * (float)x[5];
-  const float qx[4] = {cosf(hx), sinf(hx), 0.f, 0.f}; /* w, x, y, z */
-  const float qy[4] = {cosf(hy), 0.f, sinf(hy), 0.f};
-  const float qz[4] = {cosf(hz), 0.f, 0.f, sinf(hz)};
+  const float qx[4] = {o_cosf(hx), o_sinf(hx), 0.f, 0.f}; /* w, x, y, z */
+  const float qy[4] = {o_cosf(hy), 0.f, o_sinf(hy), 0.f};
+  const float qz[4] = {o_cosf(hz), 0.f, 0.f, o_sinf(hz)};
   float a[4], q[4];
   /* a = qz * qy */
   a[0] = qz[0] * qy[0] - qz[1] * qy[1] - qz[2] * qy[2] - qz[3] * qy[3];
@@ -400,7 +414,7 @@ static void eval_sums(const gicp_problem* P, const double x[6], double* f, doubl
 
 static void r_derivative(const double x[6], const double R[9], double g[6]) {
   const double phi = x[3], theta = x[4], psi = x[5];
-  const double cphi = cos(phi), sphi = sin(phi), cth = cos(theta), sth = sin(theta), cpsi = cos(psi), spsi = sin(psi);
+  const double cphi = o_cos(phi), sphi = o_sin(phi), cth = o_cos(theta), sth = o_sin(theta), cpsi = o_cos(psi), spsi = o_sin(psi);
   double dphi[9], dth[9], dpsi[9]; /* row-major */
   dphi[0] = 0; dphi[3] = 0; dphi[6] = 0;
   dphi[1] = sphi * spsi + cphi * cpsi * sth;
@@ -811,6 +825,7 @@ int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, c
   prob.src = src; prob.tgt = tgt; prob.si = si; prob.ti = ti; prob.maha = maha;
   memcpy(prob.base, guess, sizeof(guess));
   prob.sequential = seq;
+  tl_trig_cr = seq == 0; /* EXACT: correctly rounded sines / cosines; PCL's evaluation: this platform's libm */
   while (!converged) {
     float TG[16];
     mat4f_mul(transformation, guess, TG); /* query = transformation * (guess * p): applied as one float matrix */

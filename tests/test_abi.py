@@ -145,3 +145,26 @@ def test_multi_gpu_entry_reports_codes_without_a_gpu(built):
     if not torch.cuda.is_available():
         rc = lib.icpgpu_align_batch_multi(dev, 1, None, 0, None, None, None, None, 0, res, None, 0)
         assert rc == _lib.ERR_NO_DEVICE and b"no CPU fallback" in lib.icpgpu_multi_last_error()
+
+
+def test_release_library_has_no_development_switches(built):
+    """icpslam_amd/csrc/icp_env.h: the release library reads only the PRODUCTION environment switches; every tuning / variant /
+    test-mode switch -- among them the ones that change results on purpose (ICPGPU_SKIP_UNCERT, *_NO_EXACT,
+    ICPGPU_VOXEL_TEST_STALL) -- and the experimental tile search exist only in libicpgpu_dev.so."""
+    here = os.path.dirname(_lib.LIB_PATH)
+
+    def names(path):
+        blob = open(path, "rb").read()
+        return set(m.decode() for m in re.findall(rb"ICPGPU_[A-Z][A-Z_0-9]+", blob))
+
+    production = {"ICPGPU_WAIT_TIMEOUT_MS", "ICPGPU_BATCH_THREADS", "ICPGPU_BATCH_DEPTH", "ICPGPU_RECOGNISE", "ICPGPU_GICP_SERVER",
+                  "ICPGPU_GICP_DEVICE", "ICPGPU_MAILBOX", "ICPGPU_DEBUG"}
+    rel = names(os.path.join(here, "libicpgpu.so"))
+    dev = names(os.path.join(here, "libicpgpu_dev.so"))
+    stray = {n for n in rel if n not in production and not n.startswith(("ICPGPU_COMM_", "ICPGPU_ERR_", "ICPGPU_MAP_"))}
+    assert not stray, stray
+    for n in ("ICPGPU_SKIP_UNCERT", "ICPGPU_MFMA_NO_EXACT", "ICPGPU_TILE_NO_EXACT", "ICPGPU_VOXEL_TEST_STALL", "ICPGPU_TILE_SEARCH",
+              "ICPGPU_MFMA_CHECK_BOUND"):
+        assert n in dev and n not in rel, n
+    sym = subprocess.run(["nm", "-D", "--defined-only", os.path.join(here, "libicpgpu.so")], capture_output=True, text=True).stdout
+    assert "tile_search" not in sym          # icp_tile.hip is not linked into the release library

@@ -47,7 +47,9 @@ def _cases():
 
 
 @pytest.mark.parametrize("name,src,tgt,T", list(_cases()), ids=[c[0] for c in _cases()])
-def test_three_brute_kernels_agree_and_no_bound_is_too_high(built, name, src, tgt, T):
+def test_three_brute_kernels_agree_and_no_bound_is_too_high(built, dev_flavour, name, src, tgt, T):
+    if dev_flavour.delegated:     # ICPGPU_MFMA_CHECK_BOUND exists only in the development flavour (icp_env.h)
+        return
     T = np.asarray(T, np.float32)
     os.environ["ICPGPU_MFMA_CHECK_BOUND"] = "1"
     try:

@@ -211,7 +211,7 @@ def test_gicp_server_variants_agree_bit_for_bit(tmp_path):
         "    r = ctx.align(want_fitness=True)\n"
         "np.savez(sys.argv[1], T=r['T'], meta=np.array([r['iterations'], r['n_corr'], r['converged']]), f=np.array([r['mse'], r['fitness']]))\n")
     outs = []
-    for name, env in (("resident", {}), ("streamed", {"ICPGPU_GICP_RESIDENT_MAX": "0"}), ("launches", {"ICPGPU_GICP_SERVER": "0"})):
+    for name, env in (("resident", {}), ("streamed", {"ICPGPU_GICP_RESIDENT_MAX": "0", "ICPGPU_FLAVOUR": "dev"}), ("launches", {"ICPGPU_GICP_SERVER": "0"})):
         e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
         path = str(tmp_path / (name + ".npz"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=300)
@@ -219,3 +219,43 @@ def test_gicp_server_variants_agree_bit_for_bit(tmp_path):
     for o in outs[1:]:
         for k in outs[0]:
             assert np.array_equal(outs[0][k], o[k]), k
+
+
+def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path):
+    """Round 4: the whole inner BFGS of an outer iteration runs inside gicp_solve_kernel (icp_gicp.hip) -- the profile says so,
+    one device solve per outer iteration -- and ICPGPU_GICP_DEVICE=0 (the host's solver over the evaluation server, same source:
+    icp_gicp_solver_impl.h) returns the same bits: transform, iterations, correspondences, fitness.  Sizes: one workgroup,
+    several workgroups with the correspondences resident in registers, and the streaming variant (more than 64 x 1024)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "from icpslam_amd import Context, GICP, synth\n"
+        "out = {}\n"
+        "with Context(0) as ctx:\n"
+        "    for n in (900, 9000, 30000, 90000):\n"
+        "        src, tgt, _ = synth.make_pair(n, n + 500, seed=300 + n)\n"
+        "        ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10)\n"
+        "        ctx.set_source(src); ctx.set_target(tgt)\n"
+        "        ctx.profile_reset()\n"
+        "        r = ctx.align(want_fitness=True)\n"
+        "        p = ctx.profile()\n"
+        "        out['T%d' % n] = r['T']\n"
+        "        out['m%d' % n] = np.array([r['iterations'], r['n_corr'], r['converged'], p.gicp_device_solves, p.gicp_cost_launches], np.float64)\n"
+        "        out['f%d' % n] = np.array([r['mse'], r['fitness']])\n"
+        "np.savez(sys.argv[1], **out)\n")
+    res = {}
+    for name, env in (("device", {}), ("host", {"ICPGPU_GICP_DEVICE": "0"})):
+        e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
+        path = str(tmp_path / (name + ".npz"))
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=300)
+        res[name] = dict(np.load(path))
+    for n in (900, 9000, 30000, 90000):
+        d, h = res["device"], res["host"]
+        assert d["m%d" % n][3] == d["m%d" % n][0] >= 1, n          # one device solve per outer iteration
+        assert h["m%d" % n][3] == 0, n
+        assert np.array_equal(d["T%d" % n].view(np.uint32), h["T%d" % n].view(np.uint32)), n
+        assert np.array_equal(d["m%d" % n][:3], h["m%d" % n][:3]) and d["m%d" % n][4] == h["m%d" % n][4], n   # same evaluation count too
+        assert np.array_equal(d["f%d" % n], h["f%d" % n]), n

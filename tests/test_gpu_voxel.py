@@ -180,6 +180,6 @@ def test_voxel_published_count_timeout_hands_over_to_the_sort_path(tmp_path):
         "        got, ref = ctx.voxel_grid(c, leaf), oracle.voxel_grid(c, leaf)\n"
         "        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))\n"
         "print('ok')\n")
-    env = dict(os.environ, ICPGPU_VOXEL_TEST_STALL="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, ICPGPU_VOXEL_TEST_STALL="1", ICPGPU_FLAVOUR="dev", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
