@@ -220,6 +220,11 @@ struct icpgpu_ctx {
   unsigned long long* h_solve_dev = nullptr;
   unsigned long long gicp_solve_seq = 0;
   bool gicp_device_ok = false;
+  // ... its one-XCD variant: granule slots in ordinary device memory (the XCD's L2 is the medium), the worker claims, the XCD
+  unsigned long long* gicp_slots_local = nullptr;
+  unsigned long long* gicp_owner = nullptr;
+  int gicp_xcc = 0;
+  bool gicp_local_ok = false;
   bool gicp_server_on = false;
   bool gicp_server_allowed = true;  // align_batch with more than kMaxServerWorkers threads: single launches (below)
   int gicp_blocks_most = kGicpDirectBlocks;

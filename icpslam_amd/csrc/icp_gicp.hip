@@ -393,6 +393,21 @@ __host__ __device__ __forceinline__ DD dd_add(const DD& a, const DD& b) {
   return r;
 }
 
+// Sixteen double-double numbers added as a BALANCED TREE (depth 4) rather than one after the other: the same fifteen additions,
+// but four dependent ones instead of fifteen -- a dependent float64 operation costs a wave 8-10 cycles, an independent one 4
+// (round 4: a workgroup's two reduction stages 1.55 -> 0.9 us).  The order of these additions does not matter to the result (the
+// sums are exact to ~1e-30: see above), which is what makes them comparable bit for bit with the oracle in the first place.
+__host__ __device__ __forceinline__ DD dd_sum16(const DD* x) {
+  DD a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = dd_add(x[2 * i], x[2 * i + 1]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a[i] = dd_add(a[2 * i], a[2 * i + 1]);
+  a[0] = dd_add(a[0], a[1]);
+  a[1] = dd_add(a[2], a[3]);
+  return dd_add(a[0], a[1]);
+}
+
 constexpr int kGicpSums = 13;  // f, g_t(3), R(9): terms 1..13 of the layout above
 
 struct GicpAcc {
@@ -465,10 +480,11 @@ __device__ __forceinline__ void gicp_clear(GicpAcc& acc) {
 __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __restrict__ src, int n_s,
                                                 const float4* __restrict__ tgt,
                                                 const unsigned long long* __restrict__ keys, float thr, const Xform& T,
-                                                const Xform& base, const double* __restrict__ maha6) {
+                                                const Xform& base, const double* __restrict__ maha6, int wid = (int)blockIdx.x,
+                                                int nw = (int)gridDim.x) {
   gicp_clear(acc);
-  const int stride = gridDim.x * 256;
-  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n_s; i0 += 4 * stride) {
+  const int stride = nw * 256;
+  for (int i0 = wid * 256 + threadIdx.x; i0 < n_s; i0 += 4 * stride) {
     GicpQuad L;
     gicp_load_quad(L, i0, stride, src, n_s, tgt, keys, thr, maha6);
     gicp_add_quad(acc, L, T, base);
@@ -483,27 +499,32 @@ __device__ __forceinline__ void gicp_store_tagged(double* __restrict__ out, int 
   // a cached line out, and a release fence is exactly what this protocol is there to avoid
   store_pair_system(out + 2 * entry, (unsigned long long)__double_as_longlong(value), tag);
 }
-__device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, double* __restrict__ partials, unsigned long long tag) {
+// md (nullable): the workgroup's m and sum d2 from an EARLIER evaluation of the same correspondences (they do not depend on the
+// state): md[2] != 0 means md[0], md[1] are valid and the two wave reductions (twelve dependent cross-lane steps) are skipped;
+// otherwise they are computed and left there (thread kGicpSums keeps them).
+__device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, double* __restrict__ partials, unsigned long long tag,
+                                                        double* md = nullptr) {
   __shared__ DD s_lane[kGicpSums][16][17];  // [sum][lane % 16][lane / 16], rows padded: neither the writes (a lane per
                                             // thread) nor the reads (a chunk per thread) pile up on one LDS bank
   __shared__ DD s_chunk[kGicpSums][16];
   __shared__ double s_md[2][4];
 #pragma unroll
   for (int k = 0; k < kGicpSums; ++k) s_lane[k][threadIdx.x & 15][threadIdx.x >> 4] = acc.s[k];
-  const double m = wave_sum(acc.m), d2 = wave_sum(acc.d2);
-  if ((threadIdx.x & 63) == 0) {
-    s_md[0][threadIdx.x >> 6] = m;
-    s_md[1][threadIdx.x >> 6] = d2;
+  const bool have_md = md && md[2] != 0.0;  // (workgroup-uniform: every thread holds the same flag)
+  if (!have_md) {
+    const double m = wave_sum(acc.m), d2 = wave_sum(acc.d2);
+    if ((threadIdx.x & 63) == 0) {
+      s_md[0][threadIdx.x >> 6] = m;
+      s_md[1][threadIdx.x >> 6] = d2;
+    }
   }
   __syncthreads();
   if (threadIdx.x < kGicpSums * 16) {
     const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
     DD x[16];
 #pragma unroll
-    for (int l = 0; l < 16; ++l) x[l] = s_lane[k][l][c];  // lanes 16c .. 16c+15, in lane order; 16 independent reads, then the chain
-    DD v = x[0];
-#pragma unroll
-    for (int l = 1; l < 16; ++l) v = dd_add(v, x[l]);
+    for (int l = 0; l < 16; ++l) x[l] = s_lane[k][l][c];  // lanes 16c .. 16c+15, in lane order; 16 independent reads, then the tree
+    const DD v = dd_sum16(x);
     s_chunk[k][c] = v;
   }
   __syncthreads();
@@ -512,15 +533,20 @@ __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, doub
     DD x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
-    DD v = x[0];
-#pragma unroll
-    for (int c = 1; c < 16; ++c) v = dd_add(v, x[c]);
+    const DD v = dd_sum16(x);
     gicp_store_tagged(out, 1 + threadIdx.x, v.hi, tag);
     gicp_store_tagged(out, 16 + threadIdx.x, v.lo, tag);
   } else if (threadIdx.x == kGicpSums) {
-    gicp_store_tagged(out, 0, (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]), tag);
-    gicp_store_tagged(out, 14, (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]), tag);
+    double m = have_md ? md[0] : (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]);
+    double d2 = have_md ? md[1] : (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]);
+    gicp_store_tagged(out, 0, m, tag);
+    gicp_store_tagged(out, 14, d2, tag);
+    if (md) {
+      md[0] = m;
+      md[1] = d2;
+    }
   }
+  if (md) md[2] = 1.0;
 }
 
 // One evaluation as ONE kernel of <= kGicpDirectBlocks workgroups: every workgroup stores its partials straight into
@@ -567,6 +593,7 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
   // release, 9-11 % faster at every size from 5k to 200k once the results travelled as self-tagged pairs.)
   GicpQuad mine;
   if constexpr (RESIDENT) gicp_load_quad(mine, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, src, n_s, tgt, keys, thr, maha6);
+  double md[3] = {0.0, 0.0, 0.0};  // this workgroup's m and sum d2: the same at every evaluation of the run
   for (;;) {
     const long long t_loop = (long long)wall_clock64();
     if (threadIdx.x < 64) {
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
       host_partials[2 * 30] = (double)(s_seen - t_loop) * 0.01;   // polling
       host_partials[2 * 31] = (double)(t_now - s_seen) * 0.01;    // work up to the reduction
     }
-    gicp_block_reduce_store(acc, host_partials, ((unsigned long long)seq_hi << 32) | seq);
+    gicp_block_reduce_store(acc, host_partials, ((unsigned long long)seq_hi << 32) | seq, md);
     expect = seq + 1u;
     if (expect == kGicpServerExit) expect = 0u;
     __syncthreads();  // s_T / s_seq are rewritten in the next round
@@ -638,6 +665,7 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
 //     slowest one (it needs everybody's partials of evaluation k to start k + 1).
 //   * Nobody waits for ever: 50 ms without a granule ends the run with kDeviceError everywhere (the host falls back to its own
 //     solver); the workgroups are co-resident by construction (one per CU, at most the context's share of the chip).
+constexpr int kSolveLocalBlocks = 32;  // CUs of one XCD: the most workgroups of the one-XCD variant
 constexpr int kSolveGranules = 28;  // per workgroup and parity: 13 sums' high parts, their low parts, m, sum d2
 constexpr int kSolveOut = 20;       // host granules: status, x[6], m, sum d2, f, evaluations, inner iterations done
 
@@ -663,6 +691,10 @@ struct GicpSolveArgs {
   unsigned long long seq0;       // evaluation e of this run carries the number seq0 + e; the result carries seq0
   int max_inner;
   double gradient_tol;
+  // one-XCD variant (LOCAL): `workers` participants, all on XCD `xcc_want`, exchange their granules through that XCD's L2
+  int workers;
+  int xcc_want;
+  unsigned long long* owner;     // [kGicpDirectBlocks]: worker index -> number of the run that claimed it
 };
 
 // The six sine / cosine pairs of a state, six lanes at a time: lane l (mod 8) evaluates argument l, the results come back through
@@ -698,10 +730,37 @@ __device__ __forceinline__ gicp::Trig6 trig6_lanes(const gicp::V6& x, const doub
   return t;
 }
 
-template <bool RESIDENT>
+// LOCAL: the workgroups of the run sit on ONE XCD (each has checked its own XCC id), so a granule travels through the L2 they
+// share -- a plain 16-byte store (stays in L2) and L1-bypassing loads (sc1, served by L2): ~0.3 us per hop instead of the
+// ~1 us of a trip through the fabric to fine-grained memory and back.  Not LOCAL: any placement, write-through stores and
+// system-scope loads on fine-grained memory.  The protocol (self-validating granules, double buffer, timeouts) is the same.
+template <bool LOCAL>
+__device__ __forceinline__ void granule_publish(unsigned long long* g, double value, unsigned long long seq) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(value);
+  if constexpr (LOCAL) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u64x2*>(g) = u64x2{bits, granule_tag(seq, bits)};
+  } else {
+    store_pair_system(g, bits, granule_tag(seq, bits));
+  }
+}
+template <bool LOCAL>
+__device__ __forceinline__ unsigned long long granule_word(const unsigned long long* p) {
+  if constexpr (LOCAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+#if defined(ICPGPU_DEV_SWITCHES)
+#define SOLVE_CLOCK() ((long long)wall_clock64())   // development flavour: phase times of an evaluation (six clock reads of ~0.15 us each)
+#else
+#define SOLVE_CLOCK() (0ll)
+#endif
+
+template <bool RESIDENT, bool LOCAL>
 struct DeviceEval {
   const GicpSolveArgs& A;
   const GicpQuad& mine;
+  int wid, nw;         // this workgroup's index among the run's workgroups, and their number
   double* s_sums;      // LDS: the 15 numbers of an evaluation
   int* s_ok;           // LDS: the gather's verdict
   const double (*s_table)[4];  // LDS: icp_trig.h's table
@@ -709,10 +768,12 @@ struct DeviceEval {
   double m = 0.0, d2 = 0.0;
   double dbg_raw[4] = {0, 0, 0, 0};
   long long t_apply = 0, t_acc = 0, t_pub = 0, t_gather = 0, t_grad = 0;  // phase times (100 MHz ticks), development
+  unsigned long long n_pass = 0;  // gather passes (development)
+  double md[3] = {0.0, 0.0, 0.0};  // this workgroup's m and sum d2 (the same at every evaluation of the run)
   double dbg = 0.0;    // on a gather timeout: evaluation * 1e6 + the first missing workgroup * 1e3 + quantity (host_out granule 11)
 
   __device__ __forceinline__ bool operator()(const gicp::V6& x, gicp::Eval& out) {
-    const long long c0 = (long long)wall_clock64();
+    const long long c0 = SOLVE_CLOCK();
     const gicp::Trig6 tr = trig6_lanes(x, s_table);
     float T[16];
 #pragma unroll
@@ -723,24 +784,24 @@ struct DeviceEval {
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 4; ++c) Tx.m[4 * r + c] = T[c * 4 + r];
-    const long long c1 = (long long)wall_clock64();
+    const long long c1 = SOLVE_CLOCK();
     GicpAcc acc;
     if constexpr (RESIDENT) {
       gicp_clear(acc);
       gicp_add_quad(acc, mine, Tx, A.base);
     } else {
-      gicp_accumulate(acc, A.src, A.n_s, A.tgt, A.keys, A.thr, Tx, A.base, A.maha6);
+      gicp_accumulate(acc, A.src, A.n_s, A.tgt, A.keys, A.thr, Tx, A.base, A.maha6, wid, nw);
     }
-    const long long c2 = (long long)wall_clock64();
+    const long long c2 = SOLVE_CLOCK();
     ++n_eval;
     const unsigned long long seq = A.seq0 + n_eval;
-    const int B = (int)gridDim.x;
+    const int B = nw;
     unsigned long long* parity = A.slots + (size_t)(n_eval & 1ull) * (size_t)B * kSolveGranules * 2;
-    publish(acc, parity + (size_t)blockIdx.x * kSolveGranules * 2, seq);
-    const long long c3 = (long long)wall_clock64();
+    publish(acc, parity + (size_t)wid * kSolveGranules * 2, seq);
+    const long long c3 = SOLVE_CLOCK();
     gather(parity, B, seq);
     __syncthreads();
-    const long long c4 = (long long)wall_clock64();
+    const long long c4 = SOLVE_CLOCK();
     const bool ok = *s_ok != 0;
     double s[15];
 #pragma unroll
@@ -750,7 +811,7 @@ struct DeviceEval {
     m = s[0];
     d2 = s[14];
     gicp::eval_from_sums(tr, s, out);
-    const long long c5 = (long long)wall_clock64();
+    const long long c5 = SOLVE_CLOCK();
     t_apply += c1 - c0;
     t_acc += c2 - c1;
     t_pub += c3 - c2;
@@ -766,10 +827,13 @@ struct DeviceEval {
     __shared__ double s_md[2][4];
 #pragma unroll
     for (int k = 0; k < kGicpSums; ++k) s_lane[k][threadIdx.x & 15][threadIdx.x >> 4] = acc.s[k];
-    const double wm = wave_sum(acc.m), wd = wave_sum(acc.d2);
-    if ((threadIdx.x & 63) == 0) {
-      s_md[0][threadIdx.x >> 6] = wm;
-      s_md[1][threadIdx.x >> 6] = wd;
+    const bool have_md = md[2] != 0.0;
+    if (!have_md) {
+      const double wm = wave_sum(acc.m), wd = wave_sum(acc.d2);
+      if ((threadIdx.x & 63) == 0) {
+        s_md[0][threadIdx.x >> 6] = wm;
+        s_md[1][threadIdx.x >> 6] = wd;
+      }
     }
     __syncthreads();
     if (threadIdx.x < kGicpSums * 16) {
@@ -777,9 +841,7 @@ struct DeviceEval {
       DD x[16];
 #pragma unroll
       for (int l = 0; l < 16; ++l) x[l] = s_lane[k][l][c];
-      DD v = x[0];
-#pragma unroll
-      for (int l = 1; l < 16; ++l) v = dd_add(v, x[l]);
+      const DD v = dd_sum16(x);
       s_chunk[k][c] = v;
     }
     __syncthreads();
@@ -787,15 +849,18 @@ struct DeviceEval {
       DD x[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
-      DD v = x[0];
-#pragma unroll
-      for (int c = 1; c < 16; ++c) v = dd_add(v, x[c]);
-      granule_store(slot + 2 * threadIdx.x, v.hi, seq);
-      granule_store(slot + 2 * (kGicpSums + threadIdx.x), v.lo, seq);
+      const DD v = dd_sum16(x);
+      granule_publish<LOCAL>(slot + 2 * threadIdx.x, v.hi, seq);
+      granule_publish<LOCAL>(slot + 2 * (kGicpSums + threadIdx.x), v.lo, seq);
     } else if (threadIdx.x == kGicpSums) {
-      granule_store(slot + 2 * 26, (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]), seq);
-      granule_store(slot + 2 * 27, (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]), seq);
+      if (!have_md) {
+        md[0] = (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]);
+        md[1] = (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]);
+      }
+      granule_publish<LOCAL>(slot + 2 * 26, md[0], seq);
+      granule_publish<LOCAL>(slot + 2 * 27, md[1], seq);
     }
+    md[2] = 1.0;
   }
 
   // wave 0: lane = (quantity q = lane / 4, part p = lane % 4) merges the workgroups p, p + 4, ... of quantity q, then the four
@@ -820,19 +885,22 @@ struct DeviceEval {
         hi[u] = lo[u] = 0.0;
         if (active && b0 + 4 * u < B) want |= 1u << u;
       }
-      const long long t0 = (long long)wall_clock64();
-      while (have != want) {
+      long long t0 = 0;
+      for (unsigned pass = 0; have != want; ++pass) {
+        ++n_pass;
         // every load of the round is issued before any is looked at (addresses clamped to the last workgroup: no branches
         // between the loads), then the granules are validated; what is not there yet is read again
         unsigned long long hb[R], ht[R], lb[R], lt[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
+          hb[u] = ht[u] = lb[u] = lt[u] = 0ull;
+          if (b0 - p + 4 * u >= B) continue;  // (wave-uniform: nobody's u-th workgroup of this round exists)
           const int b = min(b0 + 4 * u, B - 1);
           const unsigned long long* slot = parity + (size_t)b * kSolveGranules * 2;
-          hb[u] = __hip_atomic_load(slot + 2 * g_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          ht[u] = __hip_atomic_load(slot + 2 * g_hi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          lb[u] = __hip_atomic_load(slot + 2 * g_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          lt[u] = __hip_atomic_load(slot + 2 * g_lo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          hb[u] = granule_word<LOCAL>(slot + 2 * g_hi);
+          ht[u] = granule_word<LOCAL>(slot + 2 * g_hi + 1);
+          lb[u] = granule_word<LOCAL>(slot + 2 * g_lo);
+          lt[u] = granule_word<LOCAL>(slot + 2 * g_lo + 1);
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -843,7 +911,10 @@ struct DeviceEval {
             have |= 1u << u;
           }
         }
-        if (have != want && (long long)wall_clock64() - t0 > patience) {
+        if (have != want && (pass & 31u) == 31u) {  // (the clock is a memory instruction: not in every pass)
+          const long long now = (long long)wall_clock64();
+          if (t0 == 0) t0 = now;
+          if (now - t0 <= patience) continue;
           failed = true;
           int miss = 0;
 #pragma unroll
@@ -853,9 +924,16 @@ struct DeviceEval {
           break;
         }
       }
+      {  // the round's (up to) eight workgroups as a tree (absent ones are zeros), then onto the running sum
+        DD t[R];
 #pragma unroll
-      for (int u = 0; u < R; ++u)
-        if ((want >> u) & 1u) v = dd_add(v, DD{hi[u], lo[u]});
+        for (int u = 0; u < R; ++u) t[u] = ((want >> u) & 1u) ? DD{hi[u], lo[u]} : DD{0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < R / 2; ++u) t[u] = dd_add(t[2 * u], t[2 * u + 1]);
+#pragma unroll
+        for (int u = 0; u < R / 4; ++u) t[u] = dd_add(t[2 * u], t[2 * u + 1]);
+        v = dd_add(v, dd_add(t[0], t[1]));
+      }
     }
     // combine the four parts (TwoSum is symmetric in its arguments: all four lanes end with the same bits)
 #pragma unroll
@@ -877,12 +955,30 @@ struct DeviceEval {
   }
 };
 
-template <bool RESIDENT>
+template <bool RESIDENT, bool LOCAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gicp_solve_kernel(GicpSolveArgs A) {
   __shared__ double s_sums[16];
   __shared__ int s_ok;
   __shared__ double s_table[128][4];
   const long long t_kernel0 = (long long)wall_clock64();
+  int wid = (int)blockIdx.x, nw = (int)gridDim.x;
+  if constexpr (LOCAL) {
+    // Eight times the workgroups the run needs are launched; a workgroup takes part iff the hardware says it sits on XCD
+    // xcc_want -- round-robin dispatch puts workgroup b on XCD b % 8, so those are the ones with one residue and b / 8 numbers
+    // them 0 .. workers - 1, but NOTHING relies on that: a worker index is claimed (atomic exchange of the run's number), a
+    // second claimant leaves, and an index nobody claims makes the gathers time out -- the host then uses the variant that
+    // works under any placement.
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if ((int)(xcc & 0xFu) != A.xcc_want) return;
+    wid = (int)blockIdx.x >> 3;
+    nw = A.workers;
+    if (wid >= nw) return;
+    __shared__ int s_mine;
+    if (threadIdx.x == 0) s_mine = atomicExch(&A.owner[wid], A.seq0) != A.seq0 ? 1 : 0;
+    __syncthreads();
+    if (!s_mine) return;
+  }
   {
     const double (*src_table)[4] = trig::trig_table();
     for (int i = threadIdx.x; i < 512; i += 256) s_table[i >> 2][i & 3] = src_table[i >> 2][i & 3];
@@ -890,8 +986,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   GicpQuad mine;
   if constexpr (RESIDENT)
-    gicp_load_quad(mine, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, A.src, A.n_s, A.tgt, A.keys, A.thr, A.maha6);
-  DeviceEval<RESIDENT> ev{A, mine, s_sums, &s_ok, s_table};
+    gicp_load_quad(mine, wid * 256 + threadIdx.x, nw * 256, A.src, A.n_s, A.tgt, A.keys, A.thr, A.maha6);
+  DeviceEval<RESIDENT, LOCAL> ev{A, mine, wid, nw, s_sums, &s_ok, s_table};
   gicp::V6 x;
 #pragma unroll
   for (int i = 0; i < 6; ++i) x[i] = A.x0[i];
@@ -909,7 +1005,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ev.d2 = d20;
   }
   f_last = probe.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (wid == 0 && threadIdx.x == 0) {
     unsigned long long* o = A.host_out;
     granule_store(o + 2 * 1, x[0], A.seq0);
     granule_store(o + 2 * 2, x[1], A.seq0);
@@ -934,7 +1030,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       granule_store(o + 2 * 16, (double)ev.t_grad * 0.01, A.seq0);
       granule_store(o + 2 * 17, (double)t_all * 0.01, A.seq0);
     }
-    granule_store(o + 2 * 18, 0.0, A.seq0);
+    granule_store(o + 2 * 18, (double)ev.n_pass, A.seq0);
     granule_store(o + 2 * 19, 0.0, A.seq0);
     granule_store(o + 2 * 0, (double)status, A.seq0);
   }
@@ -1010,7 +1106,8 @@ int gicp_solve_out_granules() { return kSolveOut; }
 hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                              const Xform& base, const float guess[16], const double* maha6, const double x0[6],
                              unsigned long long* slots, unsigned long long* host_out, unsigned long long seq0, int max_inner,
-                             double gradient_tol, hipStream_t stream) {
+                             double gradient_tol, hipStream_t stream, unsigned long long* local_slots, unsigned long long* owner,
+                             int xcc_want) {
   GicpSolveArgs A;
   A.src = src;
   A.n_s = n_s;
@@ -1026,12 +1123,21 @@ hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float
   A.seq0 = seq0;
   A.max_inner = max_inner;
   A.gradient_tol = gradient_tol;
-  if ((long long)blocks * 1024 >= n_s)
-    hipLaunchKernelGGL(gicp_solve_kernel<true>, dim3(blocks), dim3(256), 0, stream, A);
-  else
-    hipLaunchKernelGGL(gicp_solve_kernel<false>, dim3(blocks), dim3(256), 0, stream, A);
+  A.workers = blocks;
+  A.xcc_want = xcc_want;
+  A.owner = owner;
+  const bool resident = (long long)blocks * 1024 >= n_s;
+  if (local_slots && owner && resident && blocks <= kSolveLocalBlocks) {  // one XCD: up to 32 workgroups (one per CU of the XCD)
+    A.slots = local_slots;
+    hipLaunchKernelGGL((gicp_solve_kernel<true, true>), dim3(8 * blocks), dim3(256), 0, stream, A);
+  } else if (resident) {
+    hipLaunchKernelGGL((gicp_solve_kernel<true, false>), dim3(blocks), dim3(256), 0, stream, A);
+  } else {
+    hipLaunchKernelGGL((gicp_solve_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, A);
+  }
   return hipGetLastError();
 }
+int gicp_solve_local_blocks() { return kSolveLocalBlocks; }
 // host side of a granule: true and the value if it carries number `seq` and its own checksum
 bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value) {
   const unsigned long long bits = g[0], tag = g[1];

@@ -239,7 +239,11 @@ int gicp_solve_out_granules();
 hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                              const Xform& base, const float guess[16], const double* maha6, const double x0[6],
                              unsigned long long* slots, unsigned long long* host_out, unsigned long long seq0, int max_inner,
-                             double gradient_tol, hipStream_t stream);
+                             double gradient_tol, hipStream_t stream, unsigned long long* local_slots = nullptr,
+                             unsigned long long* owner = nullptr, int xcc_want = 0);
+// one-XCD variant (local_slots / owner given, <= gicp_solve_local_blocks() workgroups, correspondences resident): ordinary device
+// memory (gicp_solve_slot_bytes) for the granules, kGicpDirectBlocks words for the worker claims
+int gicp_solve_local_blocks();
 bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value);
 static constexpr unsigned int kGicpServerExit = 0xFFFFFFFFu;
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,

@@ -233,6 +233,18 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
       if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_solve_dev), h, 0) == hipSuccess) c->gicp_device_ok = true;
     }
     if (!c->gicp_device_ok) (void)hipGetLastError();
+    if (c->gicp_device_ok) {
+      static std::atomic<int> serial{0};
+      c->gicp_xcc = serial.fetch_add(1) & 7;  // concurrent contexts spread their one-XCD runs over the eight XCDs
+      const size_t owner_bytes = (size_t)kGicpDirectBlocks * sizeof(unsigned long long);
+      if (hipMalloc(reinterpret_cast<void**>(&c->gicp_slots_local), slot_bytes) == hipSuccess &&
+          hipMemset(c->gicp_slots_local, 0, slot_bytes) == hipSuccess &&
+          hipMalloc(reinterpret_cast<void**>(&c->gicp_owner), owner_bytes) == hipSuccess &&
+          hipMemset(c->gicp_owner, 0, owner_bytes) == hipSuccess)
+        c->gicp_local_ok = true;
+      else
+        (void)hipGetLastError();
+    }
   }
   if (gicp_server_enabled()) {  // no such memory (no large BAR): the evaluations stay single launches
     if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_cmd), 4096, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -335,6 +347,8 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   if (c->h_gicp) (void)hipHostFree(c->h_gicp);
   if (c->gicp_cmd) (void)hipFree(c->gicp_cmd);
   if (c->gicp_slots) (void)hipFree(c->gicp_slots);
+  if (c->gicp_slots_local) (void)hipFree(c->gicp_slots_local);
+  if (c->gicp_owner) (void)hipFree(c->gicp_owner);
   if (c->h_solve) (void)hipHostFree(const_cast<unsigned long long*>(c->h_solve));
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   for (auto& ev : c->ev)

@@ -338,20 +338,26 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     // rigid_transformation_estimation_: the whole BFGS run on the device (gicp_solve_kernel), one result for the host to poll
     Vec6 x = gicp_state_from_matrix(transformation);
     bool solved = false;
-    if (c->gicp_device_ok && c->gicp_server_allowed) {
+    for (int attempt = 0; attempt < 2 && !solved && c->gicp_device_ok && c->gicp_server_allowed; ++attempt) {
       const auto t_solve0 = std::chrono::steady_clock::now();
       const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
+      // the one-XCD variant when the run fits one XCD's 32 CUs with its correspondences in registers (the reference's
+      // voxel-filtered scans do: ~22k points); it needs 8 x nblk workgroups launched, so the context must own the chip's share
+      const bool local = c->gicp_local_ok && nblk <= gicp_solve_local_blocks() && (long long)nblk * 1024 >= n_s &&
+                         8 * nblk <= c->gicp_blocks_most;
       const unsigned long long seq0 = (c->gicp_solve_seq += 8192);  // evaluation e of the run carries seq0 + e (e < 8192: <= 20 steps of <= 200 trials)
       HIP_TRY(c, launch_gicp_solve(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, base, guess, maha, x.v, c->gicp_slots,
-                                   c->h_solve_dev, seq0, 20, 1e-2, c->stream));
+                                   c->h_solve_dev, seq0, 20, 1e-2, c->stream, local ? c->gicp_slots_local : nullptr,
+                                   local ? c->gicp_owner : nullptr, c->gicp_xcc));
       double out[24];
       const int w = wait_solve_result(c, seq0, out);
       if (w < 0) return w;
       const int status = w == 0 ? (int)out[0] : (int)gicp::kDeviceError;
-      if (status == gicp::kDeviceError) {  // a gather timed out (or the kernel never answered): the host's solver from here on
-        c->gicp_device_ok = false;
+      if (status == gicp::kDeviceError) {  // a gather timed out (or the kernel never answered)
+        if (local) c->gicp_local_ok = false;  // placement was not what the one-XCD variant needs: the any-placement variant from here on
+        else c->gicp_device_ok = false;       // ... and if that one fails too: the host's solver
         if (std::getenv("ICPGPU_DEBUG"))
-          fprintf(stderr, "[icpgpu] gicp device solver gave up (%s, %d workgroups, record %.0f); falling back to the host solver\n",
+          fprintf(stderr, "[icpgpu] gicp device solver%s gave up (%s, %d workgroups, record %.0f); falling back\n", local ? " (one XCD)" : "",
                   w == 0 ? "a gather timed out" : "no answer", nblk, w == 0 ? out[11] : -1.0);
         if (std::getenv("ICPGPU_DEBUG") && w == 0)
           fprintf(stderr, "[icpgpu]   seq0 %llu: hi granule number %.0f checksum %.0f, lo granule number %.0f, checksum of the hi bits %.0f\n", seq0, out[12], out[13], out[14], out[15]);

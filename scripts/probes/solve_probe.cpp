@@ -37,23 +37,28 @@ int main(int argc, char** argv) {
   Xform base{}; base.m[0] = base.m[5] = base.m[10] = 1.f;
   float guess[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   double x0[6] = {0, 0, 0, 0, 0, 0};
-  for (int rep = 0; rep < 3; ++rep) {
+  unsigned long long *local_slots, *owner;
+  hipMalloc((void**)&local_slots, sb); hipMemset(local_slots, 0, sb);
+  hipMalloc((void**)&owner, 256 * 8); hipMemset(owner, 0, 256 * 8);
+  const int xcc = argc > 2 ? atoi(argv[2]) : 0;
+  for (int rep = 0; rep < 6; ++rep) {
+    const bool local = rep >= 3;
     const unsigned long long seq0 = 8192ull * (rep + 1);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    hipError_t e = launch_gicp_solve(blocks, d_src, n, d_tgt, d_keys, 1.0f, base, guess, d_maha, x0, slots, h_out_dev, seq0, 20, 1e-2, 0);
+    hipError_t e = launch_gicp_solve(blocks, d_src, n, d_tgt, d_keys, 1.0f, base, guess, d_maha, x0, slots, h_out_dev, seq0, 20, 1e-2, 0, local ? local_slots : nullptr, local ? owner : nullptr, xcc);
     hipEventRecord(e1, 0);
     hipError_t e2 = hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     double out[24] = {0};
     int valid = 0;
     for (int k = 0; k < gicp_solve_out_granules(); ++k) valid += gicp_granule_read(h_out + 2 * k, seq0, &out[k]) ? 1 : 0;
-    printf("rep %d: launch %s sync %s, %.3f ms, %d/%d result granules valid; status %.0f x = %.6f %.6f %.6f %.6f %.6f %.6f m %.0f evals %.0f dbg %.0f -> %.2f us per evaluation\n", rep,
+    printf("%s rep %d: launch %s sync %s, %.3f ms, %d/%d result granules valid; status %.0f x = %.6f %.6f %.6f %.6f %.6f %.6f m %.0f evals %.0f dbg %.0f -> %.2f us per evaluation\n", local ? "one-XCD" : "any-XCD", rep,
            hipGetErrorString(e), hipGetErrorString(e2), ms, valid, gicp_solve_out_granules(), out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[10], out[11], out[10] > 0 ? ms * 1e3 / out[10] : 0.0);
     if (out[0] != 3) {
       const double ev = out[10] > 0 ? out[10] : 1;
-      printf("   per evaluation (us): apply_state %.2f | accumulate %.2f | publish %.2f | gather %.2f | gradient %.2f | kernel total %.2f -> solver between evaluations %.2f\n", out[12] / ev,
-             out[13] / ev, out[14] / ev, out[15] / ev, out[16] / ev, out[17] / ev, (out[17] - out[12] - out[13] - out[14] - out[15] - out[16]) / ev);
+      printf("   per evaluation (us): apply_state %.2f | accumulate %.2f | publish %.2f | gather %.2f | gradient %.2f | kernel total %.2f -> solver between evaluations %.2f; gather passes per evaluation %.2f\n", out[12] / ev,
+             out[13] / ev, out[14] / ev, out[15] / ev, out[16] / ev, out[17] / ev, (out[17] - out[12] - out[13] - out[14] - out[15] - out[16]) / ev, out[18] / ev);
     }
     if (out[0] == 3) {  // inspect the slots
       std::vector<unsigned long long> s(sb / 8);
