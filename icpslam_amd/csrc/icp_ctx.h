@@ -158,9 +158,12 @@ using namespace icpgpu_impl;
 
 constexpr size_t kMaxServerWorkers = 8;
 
-// ICPGPU_GICP_DEVICE=0: GICP's inner BFGS stays on the host (evaluation server or single launches)
+// ICPGPU_GICP_DEVICE=1: GICP's inner BFGS runs inside a resident kernel (icp_gicp.hip: gicp_solve_kernel) instead of on the host
+// over the evaluation server.  Same bits either way (tests/test_gpu_gicp.py); OFF by default because it is not faster: an
+// evaluation takes 7.4-8.1 us in the kernel against 7.0-7.6 us through the host loop -- what
+// it buys is a host thread that waits once per outer iteration instead of once per evaluation.
 inline bool gicp_device_solver_enabled() {
-  static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_DEVICE"); return !e || std::atoi(e) != 0; }();
+  static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_DEVICE"); return e && std::atoi(e) != 0; }();
   return v;
 }
 inline bool gicp_server_enabled() {  // ICPGPU_GICP_SERVER=0: every GICP evaluation is its own launch
@@ -206,6 +209,7 @@ struct icpgpu_ctx {
   volatile unsigned long long* h_flags = nullptr;
   unsigned long long* h_flags_dev = nullptr;  // device alias of h_flags
   unsigned long long sums_seq = 0;
+  bool mailbox_release = false;  // result pairs leave the device as value / system-scope release / tag (icp_kernels.h)
   // GICP cost evaluations: per-workgroup partials (kGicpDirectBlocks x 17) + one flag per workgroup, same kind of memory
   double* h_gicp = nullptr;
   double* h_gicp_dev = nullptr;
@@ -261,6 +265,9 @@ struct icpgpu_ctx {
   int host_share = 1;                // batch drivers of this process that share its CPUs with this context (icp_multi.cpp)
   std::string err;
 };
+
+// the number a kernel is handed for its result pairs: the plain number, marked when the mailbox is in release mode
+inline unsigned long long wire_seq(const icpgpu_ctx* c, unsigned long long seq) { return c->mailbox_release ? (seq | kMailboxReleaseBit) : seq; }
 
 #define HIP_TRY(c, expr)                                                                              \
   do {                                                                                                \

@@ -33,6 +33,19 @@ __device__ __forceinline__ void store_pair_system(void* p, unsigned long long a,
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 3" ::"v"(p), "v"(v) : "memory");
 }
 
+// A result pair {value bits, tag(number, bits)} (icp_kernels.h: mailbox_tag) into host-visible memory.  `number` may carry
+// kMailboxReleaseBit: the classic form then -- value, system-scope release, tag -- instead of the single 16-byte store.
+__device__ __forceinline__ void store_result_pair(void* p, unsigned long long bits, unsigned long long number) {
+  const unsigned long long tag = mailbox_tag(number & ~kMailboxReleaseBit, bits);
+  if (number & kMailboxReleaseBit) {
+    unsigned long long* w = static_cast<unsigned long long*>(p);
+    __hip_atomic_store(w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(w + 1, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    store_pair_system(p, bits, tag);
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

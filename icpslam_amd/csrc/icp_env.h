@@ -5,7 +5,7 @@
 //   ICPGPU_BATCH_THREADS / ICPGPU_BATCH_DEPTH   host threads of icpgpu_align_batch and alignments each drives
 //   ICPGPU_RECOGNISE=0       icpgpu_set_target always uploads (no content recognition)
 //   ICPGPU_GICP_SERVER=0     every GICP cost evaluation is its own kernel launch (no resident server)
-//   ICPGPU_GICP_DEVICE=0     GICP's inner BFGS runs on the host (evaluation server or single launches), not in the device solver
+//   ICPGPU_GICP_DEVICE=1     GICP's inner BFGS runs in the device solver (gicp_solve_kernel) instead of on the host (same bits)
 //   ICPGPU_MAILBOX=pairs|release   how results reach the host (default: self-test at context creation picks it)
 //   ICPGPU_DEBUG=1           diagnostics on stderr
 //   LOCAL_WORLD_SIZE         (torch.distributed.run) processes sharing this host's CPUs

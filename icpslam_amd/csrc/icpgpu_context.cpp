@@ -208,6 +208,47 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
   c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
   {
+    // How result pairs leave the device (icp_kernels.h): ICPGPU_MAILBOX=pairs|release decides; otherwise the self-test does,
+    // once per device and process: 4096 pairs into one slot, read back concurrently; one torn pair selects the release form.
+    static std::atomic<int> verdict[64];  // 0 unknown, 1 pairs, 2 release
+    const int slot = device_id >= 0 && device_id < 64 ? device_id : 0;
+    int v = verdict[slot].load();
+    if (const char* m = std::getenv("ICPGPU_MAILBOX")) v = std::strcmp(m, "release") == 0 ? 2 : (std::strcmp(m, "pairs") == 0 ? 1 : v);
+    if (v == 0) {
+      volatile unsigned long long* pair = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 22);
+      unsigned long long* pair_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 22);
+      const int rounds = 4096;
+      pair[0] = pair[1] = 0;
+      if ((e = launch_mailbox_selftest(pair_dev, rounds, c->stream)) != hipSuccess) return bail("mailbox self-test", e);
+      unsigned long long torn = 0, seen = 0, last = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 1;; ++spins) {
+        const unsigned long long tag = pair[1], bits = pair[0], tag2 = pair[1];
+        const unsigned long long n = tag >> 24;
+        if (tag == tag2 && n >= 1 && n <= (unsigned long long)rounds) {
+          if (tag != mailbox_tag(n, bits)) ++torn;
+          if (n != last) {
+            ++seen;
+            last = n;
+          }
+        }
+        if (n == (unsigned long long)rounds) break;
+        if ((spins & 0xFFFu) == 0 &&
+            (hipStreamQuery(c->stream) != hipErrorNotReady ||
+             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2000.0))
+          break;
+      }
+      if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("mailbox self-test", e);
+      v = torn ? 2 : 1;
+      if (std::getenv("ICPGPU_DEBUG"))
+        fprintf(stderr, "[icpgpu] mailbox self-test on device %d: %llu of %d pairs observed, %llu torn -> %s\n", device_id, seen, rounds, torn,
+                v == 2 ? "release form" : "16-byte pairs");
+      pair[0] = pair[1] = 0;
+      verdict[slot].store(v);
+    }
+    c->mailbox_release = v == 2;
+  }
+  {
     const size_t n_flags_end = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8 + kGicpDirectBlocks;  // partials, gap, flags
     const size_t cmd_off = (n_flags_end + 7) & ~(size_t)7;                                        // 64-byte aligned
     const size_t n_d = cmd_off + 8;                                                              // + the server's command line

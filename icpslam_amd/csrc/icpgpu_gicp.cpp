@@ -93,7 +93,7 @@ static int gicp_server_start(icpgpu_ctx* c, int n_s, const unsigned long long* k
   Xform none{};
   gicp_server_command(c, next - 1u, none);  // a number the server does not wait for: the line may still hold an old exit
   HIP_TRY(c, launch_gicp_server(gicp_direct_blocks(n_s, c->gicp_blocks_most), c->src.data(), n_s, c->tgt.data(), keys, thr, base, maha, c->h_gicp_dev, c->h_gicp_flags_dev,
-                                c->gicp_cmd, next, (unsigned int)((c->sums_seq + 1) >> 32), c->stream));
+                                c->gicp_cmd, next, (unsigned int)(wire_seq(c, c->sums_seq + 1) >> 32), c->stream));
   c->gicp_server_on = true;
   return ICPGPU_OK;
 }
@@ -118,8 +118,9 @@ static const int kGicpEntries[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13,
 static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
   const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(mailbox);
   bool all = true;
+  unsigned long long bits;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
-    for (int e : kGicpEntries) all = all && (w[2 * e + 1] == seq);
+    for (int e : kGicpEntries) all = mailbox_read(w + 2 * e, seq, &bits) && all;
   return all;
 }
 // 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
@@ -300,7 +301,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       }
       if (!have) {
         if (launch_gicp_cost_direct(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, xform_from_f16(T), base, maha,
-                                    c->h_gicp_dev, c->h_gicp_flags_dev, seq, c->stream) != hipSuccess)
+                                    c->h_gicp_dev, c->h_gicp_flags_dev, wire_seq(c, seq), c->stream) != hipSuccess)
           return false;
         if (wait_gicp_tags(c, nblk, seq, /*server=*/false) != 0) return false;
       }
@@ -347,7 +348,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
                          8 * nblk <= c->gicp_blocks_most;
       const unsigned long long seq0 = (c->gicp_solve_seq += 8192);  // evaluation e of the run carries seq0 + e (e < 8192: <= 20 steps of <= 200 trials)
       HIP_TRY(c, launch_gicp_solve(nblk, c->src.data(), n_s, c->tgt.data(), keys, thr_excl, base, guess, maha, x.v, c->gicp_slots,
-                                   c->h_solve_dev, seq0, 20, 1e-2, c->stream, local ? c->gicp_slots_local : nullptr,
+                                   c->h_solve_dev, wire_seq(c, seq0), 20, 1e-2, c->stream, local ? c->gicp_slots_local : nullptr,
                                    local ? c->gicp_owner : nullptr, c->gicp_xcc));
       double out[24];
       const int w = wait_solve_result(c, seq0, out);

@@ -117,10 +117,12 @@ double wait_timeout_ms() {
   return v;
 }
 
-// the sums mailbox: pair k = {sum bits, sequence number} at words 2k, 2k + 1 (reduce_final_kernel)
+// the sums mailbox: pair k = {sum bits, tag(sweep number, bits)} at words 2k, 2k + 1 (reduce_final_kernel; icp_kernels.h:
+// mailbox_tag): a pair counts when its tag carries the number AND the checksum of the bits beside it
 bool flags_ready(const volatile unsigned long long* pairs, int n_pairs, unsigned long long seq) {
   bool all = true;
-  for (int k = 0; k < n_pairs; ++k) all = all && (pairs[2 * k + 1] == seq);
+  unsigned long long bits;
+  for (int k = 0; k < n_pairs; ++k) all = mailbox_read(pairs + 2 * k, seq, &bits) && all;
   return all;
 }
 // ... into c->h_sums, where everybody reads them
@@ -237,7 +239,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     red_n = n_s;
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
+    HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, wire_seq(c, seq), c->stream));
 #endif
   } else if (use_grid && !open_range) {
     // cell-ordered source when there is one (non-finite points are absent from it: they never match anyway)
@@ -262,7 +264,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
       c->pt_issue_in = tl1;
     }
     EVREC(ev[1]);
-    HIP_TRY(c, launch_reduce_final(partials, blocks, /*term_major=*/true, d_sums, c->h_flags_dev, seq, c->stream));
+    HIP_TRY(c, launch_reduce_final(partials, blocks, /*term_major=*/true, d_sums, c->h_flags_dev, wire_seq(c, seq), c->stream));
   } else {
     red_src = c->src.data();
     red_n = n_s;
@@ -283,7 +285,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     EVREC(ev[1]);
     if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, seq, c->stream));
+    HIP_TRY(c, launch_reduce(red_src, red_n, c->tgt.data(), keys, T, thr, partials, d_sums, c->h_flags_dev, wire_seq(c, seq), c->stream));
   }
   EVREC(ev[2]);
   if (timed) c->pending.push_back({slot, use_grid});

@@ -223,8 +223,8 @@ def test_gicp_server_variants_agree_bit_for_bit(tmp_path):
 
 def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path):
     """Round 4: the whole inner BFGS of an outer iteration runs inside gicp_solve_kernel (icp_gicp.hip) -- the profile says so,
-    one device solve per outer iteration -- and ICPGPU_GICP_DEVICE=0 (the host's solver over the evaluation server, same source:
-    icp_gicp_solver_impl.h) returns the same bits: transform, iterations, correspondences, fitness.  Sizes: one workgroup,
+    one device solve per outer iteration (ICPGPU_GICP_DEVICE=1; off by default: it is not faster) -- and the default
+    path (the host's solver over the evaluation server, same source: icp_gicp_solver_impl.h) returns the same bits: transform, iterations, correspondences, fitness.  Sizes: one workgroup,
     several workgroups with the correspondences resident in registers, and the streaming variant (more than 64 x 1024)."""
     import os
     import subprocess
@@ -247,7 +247,7 @@ def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path
         "        out['f%d' % n] = np.array([r['mse'], r['fitness']])\n"
         "np.savez(sys.argv[1], **out)\n")
     res = {}
-    for name, env in (("device", {}), ("host", {"ICPGPU_GICP_DEVICE": "0"})):
+    for name, env in (("device", {"ICPGPU_GICP_DEVICE": "1"}), ("host", {"ICPGPU_GICP_DEVICE": "0"})):
         e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
         path = str(tmp_path / (name + ".npz"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=300)
@@ -258,4 +258,7 @@ def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path
         assert h["m%d" % n][3] == 0, n
         assert np.array_equal(d["T%d" % n].view(np.uint32), h["T%d" % n].view(np.uint32)), n
         assert np.array_equal(d["m%d" % n][:3], h["m%d" % n][:3]) and d["m%d" % n][4] == h["m%d" % n][4], n   # same evaluation count too
-        assert np.array_equal(d["f%d" % n], h["f%d" % n]), n
+        assert d["f%d" % n][1] == h["f%d" % n][1], n                                     # fitness: the same sweep
+        # mse_last = (sum of the correspondences' float d2) / m: a diagnostic; its float64 sum is rounded in workgroup order, and
+        # the two paths use different workgroup counts for clouds of more than 64 x 1024 points
+        assert abs(d["f%d" % n][0] - h["f%d" % n][0]) <= 1e-12 * h["f%d" % n][0], n
