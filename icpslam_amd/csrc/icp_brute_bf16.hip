@@ -24,9 +24,13 @@
 //
 // Error budget of the lower bound, relative to (P^2 + |v|^2):
 //   operand splits: |u.v - (uh + ul).(vh + vl)| <= (2^-16 + 2^-16)|u||v| per sum, times 2: 2^-14 |u||v| <= 2^-15 (P^2 + |v|^2)
-//   S = S_h + S_l + r, |r| <= 2^-16 |S| <= 2^-16 |v|^2 (+ tau);  the MFMA's own accumulation of 14 terms, each bounded by
-//   P^2 + |v|^2: taken as 2^-17 (P^2 + |v|^2) -- 16 roundings of 2^-21, eight times an f32 ulp, since the hardware's internal
-//   alignment is not documented; the f32 kernel's budget for the rounded differences and |v|^2: 2^-19.
+//   S = S_h + S_l + r, |r| <= 2^-16 |S| <= 2^-16 |v|^2 (+ tau);  the MFMA's own accumulation: MEASURED (round 4,
+//   scripts/probes/mfma_accum.cpp, profiles/r04_mfma_accumulation.txt: 8192 MFMAs x 1024 outputs against the exact sums, operands
+//   chosen to cancel in the 14 K slots used here, exponent spreads up to 30 binades): the adder aligns to the largest product and
+//   drops what lies 2^-21 .. 2^-24 below it -- worst |error| = 2^-21.9 of the sum of the |products| (2^-20.8 of the largest
+//   one).  The |products| of a bound add up to <= 2 |u||v| (1 + 2^-7) + |v|^2 + tau <= 2 (P^2 + |v|^2), so the accumulation costs
+//   <= 2^-20.9 (P^2 + |v|^2); the budget keeps the 2^-17 it assumed until then (a factor 15 above the measurement); the f32
+//   kernel's budget for the rounded differences and |v|^2: 2^-19.
 //   Sum < 1.9 x 2^-15; tau = 2^-13 leaves a factor two.  MEASURED, not only argued: ICPGPU_MFMA_CHECK_BOUND=1 evaluates every
 //   pair exactly and counts the pairs whose bound exceeds what their own distance allows (must be 0) and the worst
 //   (s + tau - truth) / (P^2 + |v|^2) seen (tests/test_gpu_brute_bf16.py and a campaign of 4000 random clouds: 1.8e-5 = 2^-15.8 at worst against tau = 2^-13).

@@ -88,3 +88,22 @@ def test_seeded_sweeps_and_the_production_kernel_without_the_check(built):
         assert c.profile().brute_bound_violations == 0
     assert np.array_equal(res[0]["T"], res[1]["T"]) and res[0]["n_corr"] == res[1]["n_corr"]
     assert res[0]["fitness"] == res[1]["fitness"]
+
+
+def test_bound_campaign_slice_of_200_random_clouds(built):
+    """A 200-cloud slice of scripts/bf16_campaign.py (4000 clouds in round 3) with the kernel's test mode on -- EVERY pair's
+    bound against its exact distance: shapes, scales 1e-3 .. 1e3, offsets to 1e4 m, lattices, duplicates, outliers, non-finite
+    points.  Development flavour (ICPGPU_MFMA_CHECK_BOUND exists only there).  The MFMA's accumulation error inside the
+    budget is measured separately (scripts/probes/mfma_accum.cpp, profiles/r04_mfma_accumulation.txt)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ICPGPU_FLAVOUR="dev", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "bf16_campaign.py"), "4000", "4200"], env=env, capture_output=True,
+                         text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert "0 clouds with different keys, 0 bound violations" in last, last
+    worst = float(last.split("worst excess")[1].split()[0])
+    assert 0.0 < worst < TAU / 2, last
+    print(last)
