@@ -68,6 +68,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (e2e rate, GICP, brute force)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline sample")
+    ap.add_argument("--multi-entry", action="store_true",
+                    help="batch50k through the C multi-GPU entry (icpgpu_align_batch_multi): ONE process, one host thread per GPU, "
+                         "ncclAllGather of the records -- what INTEGRATION.md section 3 recommends to a C++ host; --gpus N = N device entries")
+    ap.add_argument("--secondary-scans", type=int, default=50, help="scans in each secondary (e2e / GICP / pipeline) loop")
     a = ap.parse_args()
     batch = WORKLOADS[a.workload][2] == "batch"
     if a.steps is None:
@@ -252,8 +256,69 @@ def _load_json(name: str) -> dict:
         return {}
 
 
+def run_multi_entry(a):
+    """BASELINE config 4 through icpgpu_align_batch_multi (include/icpgpu.h; icp_multi.cpp): one process, `--gpus` device
+    entries, contiguous shards of a.pairs_per_rank pairs each, one all-gather of the 184-byte records (RCCL; host-staged when
+    the box has fewer GPUs than entries, i.e. several entries share a device -- stated in the line).  Same JSON contract."""
+    import ctypes as C
+    import gc
+    from concurrent.futures import ThreadPoolExecutor
+
+    import numpy as np
+    import torch
+
+    from icpslam_amd import _lib, sharding, synth
+    if "WORLD_SIZE" in os.environ:
+        raise SystemExit("bench.py --multi-entry is ONE process (no launcher): it drives all GPUs itself")
+    n_s, n_t, _ = WORKLOADS["batch50k"]
+    n_dev = a.gpus
+    have = torch.cuda.device_count()
+    real = have >= n_dev
+    devices = list(range(n_dev)) if real else [0] * n_dev
+    comm = sharding.COMM_RCCL if real else sharding.COMM_HOST
+    n_total = a.pairs_per_rank * n_dev
+    with ThreadPoolExecutor(max(2, min(16, _effective_cpus()))) as ex:
+        pairs = list(ex.map(lambda k: synth.make_pair(n_s, n_t, seed=1000 + k)[:2], range(n_total)))
+    srcs, tgts = [p[0] for p in pairs], [p[1] for p in pairs]
+    P = _lib.Params()
+    _lib.load().icpgpu_default_params(C.byref(P))
+    P.max_iterations = a.iters
+
+    def step():
+        return sharding.align_batch_multi(devices, srcs, tgts, params=P, want_fitness=True, communicator=comm)
+    for _ in range(1 + a.warmup):
+        res, recs = step()
+    gc.collect()
+    gc.disable()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res, recs = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    iters_all = a.steps * sum(r["iterations"] for r in res)
+    assert np.array_equal(recs[:, 0], np.arange(n_total))
+    out = {"metric": "icp_iterations_per_sec", "value": iters_all / elapsed, "unit": "iterations/s", "n_gpus": n_dev, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"batch50k: {a.pairs_per_rank} independent 50k x 50k synthetic scan pairs per GPU entry and step (seeds 1000+k; "
+                                  f"BASELINE config 4 = 512 pairs over 8 GPUs), <= {a.iters} point-to-point ICP iterations + getFitnessScore each",
+                      "n_src": n_s, "n_tgt": n_t,
+                      "parallelism": f"ONE process, icpgpu_align_batch_multi over {n_dev} device entr{'y' if n_dev == 1 else 'ies'} "
+                                     f"{devices} (one host thread per entry), records gathered by "
+                                     + ("ncclAllGather (RCCL)" if real else "the host-staged communicator: this box shows only "
+                                        f"{have} GPU(s), the entries SHARE device 0 -- a logic run, not a scaling measurement")},
+           "entry": "icpgpu_align_batch_multi", "devices": devices, "scan_pairs_per_sec": a.steps * n_total / elapsed,
+           "usable_cpus": _effective_cpus(),
+           "roofline": {"kernel": "(batch workload: see the pair workloads for the kernel's roofline)", "bound": "hbm", "achieved": 0.0,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.multi_entry:
+        return run_multi_entry(a)
     maybe_self_launch(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -383,28 +448,29 @@ def main():
                 ctx.promote_source_to_target()
             torch.cuda.synchronize()
             return n_pairs / (time.perf_counter() - t)
-        n_e2e = max(4, min(20, a.steps))
+        n_e2e = max(4, a.secondary_scans)
         e2e = odometry_loop(n_e2e, max_iterations=a.iters, force_iterations=1)
         # ... and the resident-pair figure of round 1 (align + getFitnessScore, target index reused)
         ctx.set_source(src); ctx.set_target(tgt)
         ctx.align(want_fitness=True)
         t1 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(n_e2e):
             ctx.align(want_fitness=True)
         torch.cuda.synchronize()
-        resident = 5 / (time.perf_counter() - t1)
+        resident = n_e2e / (time.perf_counter() - t1)
         extras["scan_pairs_per_sec_e2e"] = e2e
         extras["scan_pairs_per_sec_resident"] = resident
+        extras["secondary_loop_scans"] = n_e2e
         extras["scan_pair_def"] = (
             f"e2e: per scan set_source from a host buffer (H2D) + index build + align({a.iters} forced iterations) + "
             "getFitnessScore + promote_source_to_target, as icp_odometer.cpp:188-210 runs per scan; resident: align + "
             "getFitnessScore on a resident pair, target index reused")
         # (2) the solver the reference literally instantiates (GICP, icp_odometer.cpp:188) on the same raw pair, same loop
-        gicp = odometry_loop(max(3, n_e2e // 3), method=GICP, max_iterations=a.iters, force_iterations=0)
+        gicp = odometry_loop(n_e2e, method=GICP, max_iterations=a.iters, force_iterations=0)
         # (3) ... and the reference's whole per-scan pipeline: VoxelGrid at icpslam.yaml's 0.2 m in front of it
         leaf = 0.2
         pg0 = ctx.profile()
-        pipeline = odometry_loop(max(4, n_e2e // 2), voxel_leaf=leaf, method=GICP, max_iterations=a.iters, force_iterations=0)
+        pipeline = odometry_loop(n_e2e, voxel_leaf=leaf, method=GICP, max_iterations=a.iters, force_iterations=0)
         # GICP's own measured line: the evaluation server and the covariance kernel against their algorithmic bytes
         class _Diff:  # the pipeline loop's share of the profile
             def __init__(self, a_, b_):
@@ -433,7 +499,7 @@ def main():
                     "clouds": int(pg.gicp_cov_launches), "algorithmic_bytes_per_cloud": cov_bytes,
                     "note": "gicp_cov_kernel + gicp_cov_finish_kernel per cloud (HIP events): 16 B read + 48 B written per point; the "
                             "time is the 20-NN selection over the cloud's own grid and the per-point 3x3 Jacobi SVD, not the bytes"}}
-        shim = shim_pipeline(src, tgt, leaf, a.iters)
+        shim = shim_pipeline(src, tgt, leaf, a.iters, n_scans=n_e2e + 4)
         gicp_cpu = None if a.no_cpu_baseline else gicp_cpu_baseline(src, tgt, leaf, a.iters, a.cpu_seconds)
         extras["gicp"] = {"scan_pairs_per_sec_e2e": gicp,
                           "shim_pipeline_scans_per_sec": shim.get("scans_per_sec"),
@@ -482,7 +548,7 @@ def main():
             def brute_entry(kernel, ms, note):
                 tf = flops / (ms * 1e-3) / 1e12
                 return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tf / FP32_PEAK_TFLOPS, "avg_launch_ms": ms,
+                        "frac": tf / FP32_PEAK_TFLOPS, "avg_launch_ms": ms, "launches_timed": "every sweep of one whole alignment",
                         "hbm": {"achieved": alg_bytes_keys / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": alg_bytes_keys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                 "algorithmic_bytes_per_launch": alg_bytes_keys}, "note": note}
@@ -492,14 +558,19 @@ def main():
                 "nn_brute_bf16_kernel (LDS-tiled brute force: certified lower bound of every distance from ONE bf16 MFMA "
                 "(K = 16, split operands) per 32 x 32 pairs + exact re-check of the few pairs it cannot settle)",
                 brute["mfma"]["avg_launch_ms"],
-                "`achieved` / `frac` = USEFUL flops by SURVEY.md 8(d)'s convention (8*Ns*Nt per launch: 3 sub + 1 mul + 2 fma per "
-                "pair) against the f32 peak the convention is priced at (157.3 TFLOP/s = f32 MFMA = packed-f32 vector peak): above "
-                "1 because the bound is computed on the bf16 matrix path, not in f32 -- `matrix_path` prices what the kernel "
-                "actually issues against THAT peak; the launches timed are the sweeps of one whole alignment: the first unseeded, the "
+                "`achieved` / `frac` = the bf16 flops the kernel ISSUES on the matrix path (32 per pair: one 32x32x16 MFMA per 1024 pairs) "
+                "against the 2.5 PFLOP/s dense bf16 peak; `useful_flops_equiv` keeps SURVEY.md 8(d)'s 8-flop-per-pair convention for "
+                "comparison with the f32 kernels; the launches timed are the sweeps of one whole alignment: the first unseeded, the "
                 f"other {a.iters - 1} seeded with the previous sweep's neighbours")
             if not small:
                 ms_b = brute["mfma"]["avg_launch_ms"]
                 issued = 32.0 * n_s * n_t / (ms_b * 1e-3) / 1e12       # one 32x32x16 MFMA (32768 flop) per 1024 pairs
+                # the roofline fraction of THIS kernel is the issued-flop fraction of the bf16 peak (pricing the
+                # 8-flop convention against the f32 peak gave 1.5 -- not a fraction); the convention's figure moves aside
+                brute_roofline["useful_flops_equiv"] = {"tflops": brute_roofline["achieved"], "of_fp32_peak": brute_roofline["frac"],
+                                                        "note": "8 * Ns * Nt per launch (SURVEY.md 8(d)) / time: what a 6-instruction-per-pair "
+                                                                "f32 kernel would have to sustain; NOT a roofline fraction of this kernel"}
+                brute_roofline.update(achieved=issued, peak=BF16_PEAK_TFLOPS, unit="TFLOP/s (bf16, issued)", frac=issued / BF16_PEAK_TFLOPS)
                 brute_roofline["matrix_path"] = {
                     "bound": "mfma", "achieved": issued, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16, issued)",
                     "frac": issued / BF16_PEAK_TFLOPS,
@@ -528,8 +599,12 @@ def main():
             roofline = {
                 "kernel": "nn_quad_kernel<fused> (uniform-grid exact NN, four points per wave pass, + rejection + 17-term reduction)",
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": traffic.get("nn_grid_hbm_bytes_per_launch"), "avg_launch_ms": g_ms,
-                "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
+                "traffic": traffic.get("nn_grid_hbm_bytes_per_launch"),
+                "traffic_source": "STATIC: profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, committed), not measured in this run",
+                "avg_launch_ms": g_ms, "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
+                "timed_launches_how": "HIP-event triples on the context's stream around one sweep in 13 (13 is coprime with the 10 sweeps of an "
+                                      "alignment, so over the timed steps every sweep position -- the cold first one to the converged tenth -- "
+                                      "is sampled equally often); avg_launch_ms = their mean",
                 "algorithmic_bytes_per_launch": alg_bytes_fused,
                 "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
                         "(SURVEY.md 8(d) fused lower bound).  An exact NN search does not stream; `issue` gives its VALU "
@@ -560,6 +635,9 @@ def main():
                     "valu_insts_per_source_point": valu / n_s,
                     "salu_insts_per_launch": issue_pmc.get("salu_insts_per_launch"),
                     "candidates_per_launch": cand or None,
+                    "lane_slots_per_candidate": (valu * 64.0 / cand) if cand else None,
+                    "lane_slots_def": "VALU wave-instructions x 64 lanes / target points evaluated: ~10 would be the distance + compare alone",
+                    "pmc_source": "STATIC: profiles/pmc_issue.json (builder-run rocprofv3 --pmc, committed); only the launch time is live",
                     "useful_tflops": (8.0 * cand / (g_ms * 1e-3) / 1e12) if cand else None,
                     "useful_flop_frac_of_fp32_peak": (8.0 * cand / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if cand else None,
                     "source": issue_pmc.get("_how", "profiles/pmc_issue.json")}

@@ -117,11 +117,18 @@ static void gicp_server_stop(icpgpu_ctx* c) {
 static const int kGicpEntries[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
 static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
   const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(mailbox);
-  bool all = true;
-  unsigned long long bits;
+  // the numbers first (one compare per entry, as cheap as the plain tags were: this loop runs thousands of times per scan), the
+  // checksums only once every entry carries the number
+  const volatile unsigned long long* w0 = w;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
-    for (int e : kGicpEntries) all = mailbox_read(w + 2 * e, seq, &bits) && all;
-  return all;
+    for (int e : kGicpEntries)
+      if ((w[2 * e + 1] >> 24) != seq) return false;
+  unsigned long long bits;
+  w = w0;
+  for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
+    for (int e : kGicpEntries)
+      if (!mailbox_read(w + 2 * e, seq, &bits)) return false;  // a torn pair: looked at again on the next poll
+  return true;
 }
 // 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
 static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, bool server) {

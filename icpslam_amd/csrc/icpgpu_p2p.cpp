@@ -120,10 +120,12 @@ double wait_timeout_ms() {
 // the sums mailbox: pair k = {sum bits, tag(sweep number, bits)} at words 2k, 2k + 1 (reduce_final_kernel; icp_kernels.h:
 // mailbox_tag): a pair counts when its tag carries the number AND the checksum of the bits beside it
 bool flags_ready(const volatile unsigned long long* pairs, int n_pairs, unsigned long long seq) {
-  bool all = true;
+  for (int k = 0; k < n_pairs; ++k)
+    if ((pairs[2 * k + 1] >> 24) != seq) return false;  // the numbers first (cheap), the checksums once they are all there
   unsigned long long bits;
-  for (int k = 0; k < n_pairs; ++k) all = mailbox_read(pairs + 2 * k, seq, &bits) && all;
-  return all;
+  for (int k = 0; k < n_pairs; ++k)
+    if (!mailbox_read(pairs + 2 * k, seq, &bits)) return false;
+  return true;
 }
 // ... into c->h_sums, where everybody reads them
 void take_sums(icpgpu_ctx* c) {

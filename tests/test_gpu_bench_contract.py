@@ -87,3 +87,33 @@ def test_bench_batch50k_workload_small():
     assert d["metric"] == "icp_iterations_per_sec" and "batch50k" in d["config"]["workload"]
     assert d["scan_pairs_per_sec"] > 0 and abs(d["scan_pairs_per_sec"] - 6 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["scan_pairs_per_sec"]
     assert d["cpu_baseline"]["pairs_per_sec"] > 0
+
+
+def test_bench_multi_entry_times_the_c_multi_gpu_entry():
+    """`bench.py --multi-entry --gpus N`: ONE process drives N device entries through icpgpu_align_batch_multi (icp_multi.cpp) --
+    the entry INTEGRATION.md recommends to a C++ host -- so that a scaling run can exercise it.  This box has one GPU: the four
+    entries share it and the line says so (host-staged communicator)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--multi-entry", "--gpus", "4", "--workload", "batch50k",
+                        "--pairs-per-rank", "3", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["entry"] == "icpgpu_align_batch_multi" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["scan_pairs_per_sec"] > 0 and len(d["devices"]) == 4
+    assert "SHARE device 0" in d["config"]["parallelism"] or d["devices"] == [0, 1, 2, 3]
+    for k in ("metric", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert k in d, k
+
+
+def test_brute_force_roofline_is_a_fraction():
+    """the bf16-bound brute-force kernel's `frac` is its ISSUED bf16 flops against the bf16 peak (< 1), the 8-flop
+    convention sits beside it as `useful_flops_equiv`."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "50kx50k",
+                        "--no-cpu-baseline", "--secondary-scans", "4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    b = d["roofline"]["brute_force_kernel"]
+    assert 0.0 < b["frac"] < 1.0 and b["peak"] == 2500.0 and abs(b["frac"] - b["achieved"] / b["peak"]) < 1e-12
+    assert b["useful_flops_equiv"]["tflops"] > 0 and "lane_slots_per_candidate" in d["roofline"].get("issue", {"lane_slots_per_candidate": 0})
+    assert d["secondary_loop_scans"] == 4 and "STATIC" in d["roofline"]["traffic_source"]
