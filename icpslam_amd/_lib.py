@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests of the development modes run in sub-processes (tests/test_gpu_dev_flavour.py).  Default: the release library.
 FLAVOUR = "dev" if os.environ.get("ICPGPU_FLAVOUR", "") == "dev" else "release"
 LIB_PATH = os.path.join(_HERE, "libicpgpu_dev.so" if FLAVOUR == "dev" else "libicpgpu.so")
+if os.environ.get("ICPGPU_LIB_PATH"):   # A/B builds of an experiment (scripts/): an explicit library file
+    LIB_PATH = os.environ["ICPGPU_LIB_PATH"]
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_NO_INPUT, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 P2P_SVD, GICP = 0, 1
