@@ -209,10 +209,30 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
           const int rl = __ffsll((long long)rows) - 1;
           rows &= rows - 1;
           const int rlo = __shfl(lo, rl, 64), rlen = __shfl(len, rl, 64);
+          // Two short rows share a chunk (round 4): the cells are sized for ~8 points, a row of three of them holds ~24, so one
+          // row per 64-lane chunk left most lanes idle through the ~150 instructions of a merge round.  Row A takes lanes 0..31
+          // and row B lanes 32..63 when both have at most 32 entries; the merge by rank does not care which lane a key sits in.
+          int blo = 0, blen = 0;
+          if (rlen <= 32 && rows) {
+            const int rb2 = __ffsll((long long)rows) - 1;
+            const int cand_len = __shfl(len, rb2, 64);
+            if (cand_len <= 32) {
+              rows &= rows - 1;
+              blo = __shfl(lo, rb2, 64);
+              blen = cand_len;
+            }
+          }
+          const bool paired = blen > 0;
           for (int k0 = 0; k0 < rlen; k0 += 64) {
             unsigned long long ckey = kEmptyKey;
-            const int cpos = rlo + k0 + lane;
-            if (k0 + lane < rlen) {
+            int cpos = rlo + k0 + lane;
+            bool live = k0 + lane < rlen;
+            if (paired) {  // (rlen <= 32: a single trip of this loop)
+              const int half = lane >> 5, sub = lane & 31;
+              cpos = half ? blo + sub : rlo + sub;
+              live = sub < (half ? blen : rlen);
+            }
+            if (live) {
               const float4 q = sorted[cpos];
               const float d = dist2(q.x, q.y, q.z, s.x, s.y, s.z);
               ckey = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
