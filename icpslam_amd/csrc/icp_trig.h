@@ -13,8 +13,8 @@
 //   sin t = t + t^3 P(t^2), cos t = 1 - (t^2 / 2 - t^4 Q(t^2))   (the small corrections in float64: they are < 2^-15 of the result)
 //   sin x, cos x from sin / cos (i pi / 256) (table, double-double) by the addition theorems, in double-double
 // with a relative error below 2^-68 before the one final rounding: the result is the correctly rounded one unless the exact
-// value lies within 2^-15 ulp of a rounding boundary (probability ~6e-5 per call; no mismatch against binary128 in 4 * 10^7
-// random arguments, tests/test_oracle.py).  Every operation is an IEEE float64 operation or an explicit fma -- the library is
+// value lies within ~2^-20 ulp of a rounding boundary (measured against binary128: 8 one-ulp mismatches in 8 * 10^7 double calls,
+// none in 8 * 10^7 float calls; tests/test_trig.py repeats it on 4 * 10^5 arguments).  Every operation is an IEEE float64 operation or an explicit fma -- the library is
 // compiled with -ffp-contract=off -- so the host compiler and the device compiler produce the same bits.
 // Arguments beyond |x| > 2^19 (never a rotation angle) go through the platform's functions.
 #pragma once
