@@ -204,35 +204,31 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
           lo = cell_start[row + x0];
           len = cell_start[row + x1 + 1] - lo;
         }
-        unsigned long long rows = __ballot(len > 0);
-        while (rows) {  // wave-uniform
-          const int rl = __ffsll((long long)rows) - 1;
-          rows &= rows - 1;
-          const int rlo = __shfl(lo, rl, 64), rlen = __shfl(len, rl, 64);
-          // Two short rows share a chunk (round 4): the cells are sized for ~8 points, a row of three of them holds ~24, so one
-          // row per 64-lane chunk left most lanes idle through the ~150 instructions of a merge round.  Row A takes lanes 0..31
-          // and row B lanes 32..63 when both have at most 32 entries; the merge by rank does not care which lane a key sits in.
-          int blo = 0, blen = 0;
-          if (rlen <= 32 && rows) {
-            const int rb2 = __ffsll((long long)rows) - 1;
-            const int cand_len = __shfl(len, rb2, 64);
-            if (cand_len <= 32) {
-              rows &= rows - 1;
-              blo = __shfl(lo, rb2, 64);
-              blen = cand_len;
+        // The batch's rows as ONE list of candidates, 64 per chunk (round 4; until then one row -- ~24 candidates at cells sized for
+        // ~8 points -- per chunk, later two): an exclusive scan of the row lengths over the lanes, and every lane of a chunk finds
+        // the row of its entry by a binary search over those offsets (six lane reads).  A merge round's ~100 fixed instructions
+        // are then spent on 64 candidates, not on 24.
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d, 64);
+          if ((int)lane >= d) incl += t;
+        }
+        const int start = incl - len, total = __shfl(incl, 63, 64);
+        for (int c0 = 0; c0 < total; c0 += 64) {  // wave-uniform
+          {
+            const int e = c0 + lane;
+            int rr = 0;  // the LAST lane whose offset is <= e (empty rows share their successor's offset: the successor wins)
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+              const int probe = rr + step;
+              const int sp = __shfl(start, probe & 63, 64);
+              if (probe < 64 && sp <= e) rr = probe;
             }
-          }
-          const bool paired = blen > 0;
-          for (int k0 = 0; k0 < rlen; k0 += 64) {
+            const int rlo = __shfl(lo, rr, 64), rst = __shfl(start, rr, 64);
             unsigned long long ckey = kEmptyKey;
-            int cpos = rlo + k0 + lane;
-            bool live = k0 + lane < rlen;
-            if (paired) {  // (rlen <= 32: a single trip of this loop)
-              const int half = lane >> 5, sub = lane & 31;
-              cpos = half ? blo + sub : rlo + sub;
-              live = sub < (half ? blen : rlen);
-            }
-            if (live) {
+            const int cpos = rlo + (e - rst);
+            if (e < total) {
               const float4 q = sorted[cpos];
               const float d = dist2(q.x, q.y, q.z, s.x, s.y, s.z);
               ckey = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);

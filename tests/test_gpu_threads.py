@@ -59,3 +59,43 @@ def test_distinct_contexts_run_concurrently_and_reproducibly():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_device_solver_contexts_that_share_an_xcd_run_concurrently(tmp_path):
+    """The one-XCD variant of the GICP device solver (ICPGPU_GICP_DEVICE=1) confines a run's workgroups to the context's XCD
+    (context serial mod 8): contexts 0 and 8 share XCD 0.  Two threads drive them at once, several registrations each: every
+    result must be the single-threaded one bit for bit -- if the two runs ever starve each other of CUs, the 50 ms gather timeout
+    and the fallback (any-placement variant, then the host solver) must turn that into a slower run, never into a wrong one or
+    a hang.  Sub-process: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import threading, numpy as np\n"
+        "from icpslam_amd import Context, GICP, synth\n"
+        "ctxs = [Context(0) for _ in range(9)]\n"
+        "jobs = [synth.make_pair(20000, 20000, seed=81)[:2], synth.make_pair(14000, 18000, seed=82)[:2]]\n"
+        "def run(c, j, reps):\n"
+        "    out = []\n"
+        "    for _ in range(reps):\n"
+        "        c.set_params(c.default_params(), method=GICP, max_iterations=10)\n"
+        "        c.set_source(j[0]); c.set_target(j[1])\n"
+        "        r = c.align(want_fitness=True)\n"
+        "        out.append((r['T'].tobytes(), r['iterations'], r['n_corr'], r['fitness']))\n"
+        "    return out\n"
+        "pair = [ctxs[0], ctxs[8]]\n"
+        "alone = [run(c, j, 1)[0] for c, j in zip(pair, jobs)]\n"
+        "res = [None, None]\n"
+        "def work(i): res[i] = run(pair[i], jobs[i], 8)\n"
+        "ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]\n"
+        "[t.start() for t in ts]; [t.join(timeout=200) for t in ts]\n"
+        "assert all(r is not None for r in res)\n"
+        "for i in range(2):\n"
+        "    assert all(x == alone[i] for x in res[i]), i\n"
+        "print('device solves', [int(c.profile().gicp_device_solves) for c in pair])\n"
+        "print('ok')\n")
+    env = dict(os.environ, ICPGPU_GICP_DEVICE="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    print(out.stdout.strip().splitlines()[-2])
