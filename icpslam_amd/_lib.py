@@ -48,7 +48,8 @@ class Profile(C.Structure):
                 ("nn_timed", C.c_uint64), ("grid_timed", C.c_uint64), ("reduce_timed", C.c_uint64),
                 ("grid_bounded", C.c_uint64), ("gicp_eval_ms", C.c_double), ("gicp_eval_corr", C.c_uint64), ("gicp_cov_points", C.c_uint64),
                 ("targets_recognised", C.c_uint64), ("brute_bound_violations", C.c_uint64),
-                ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64)]
+                ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64),
+                ("grid_adopted", C.c_uint64)]
 
 
 class Pose(C.Structure):

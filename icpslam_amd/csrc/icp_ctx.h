@@ -68,6 +68,8 @@ struct GridIndex {
   bool built = false, usable = false;
   uint64_t version = 0;      // target version it was built for
   float cutoff = 0.f;        // correspondence distance it was built for
+  double cut_d = 0.0;        // the same before rounding (r_max is derived from this one)
+  bool adopted = false;      // c->grid only: this is the grid the target's GICP covariances were computed over (ensure_grid)
   GridDesc g{};
   int n_binned = 0, max_pop = 0;
   double point_population = 0.0;  // cell population seen by a random point (sum c^2 / sum c)
@@ -235,6 +237,8 @@ struct icpgpu_ctx {
   // ICPGPU_GICP_TIMING=1 (development): where an evaluation's microseconds go, printed when the context is destroyed
   double gt_cmd = 0, gt_wait = 0, gt_merge = 0, gt_between = 0, gt_dev_wait = 0, gt_dev_work = 0;
   unsigned long long gt_n = 0;
+  double gt_stage[10] = {};  // ICPGPU_GICP_TIMING: host wall per stage of align_gicp (icpgpu_gicp.cpp), microseconds
+  unsigned long long gt_aligns = 0;
   // ICPGPU_P2P_TIMING=1 (development): host time between a sweep's sums and the next search kernel's launch
   double pt_wait = 0, pt_solve = 0, pt_prelaunch = 0, pt_launch = 0, pt_rest = 0;
   unsigned long long pt_n = 0;

@@ -544,6 +544,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.targets_recognised += p.targets_recognised;
     c->prof.brute_bound_violations += p.brute_bound_violations;
     c->prof.gicp_device_solves += p.gicp_device_solves;
+    c->prof.grid_adopted += p.grid_adopted;
     if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;
     std::memset(&p, 0, sizeof(p));
   }

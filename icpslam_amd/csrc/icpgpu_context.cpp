@@ -321,6 +321,13 @@ int icpgpu_destroy(icpgpu_ctx* c) {
                     "(device: polling %.2f us, work %.2f us), merge %.2f us, solver between evaluations %.2f us\n",
             c->gt_n, c->gt_cmd / c->gt_n, c->gt_wait / c->gt_n, c->gt_dev_wait / c->gt_n, c->gt_dev_work / c->gt_n, c->gt_merge / c->gt_n,
             c->gt_between / c->gt_n);
+  if (c && c->gt_aligns)
+    fprintf(stderr, "[icpgpu] GICP alignments: %llu; host wall per alignment (us): covariances %.1f | grid + buffers %.1f | search + Mahalanobis "
+                    "launches %.1f | server start + first evaluation %.1f | BFGS %.1f | server stop %.1f | event read-back %.1f | fitness %.1f | "
+                    "output cloud %.1f\n",
+            c->gt_aligns, c->gt_stage[0] / c->gt_aligns, c->gt_stage[1] / c->gt_aligns, c->gt_stage[2] / c->gt_aligns, c->gt_stage[3] / c->gt_aligns,
+            c->gt_stage[4] / c->gt_aligns, c->gt_stage[5] / c->gt_aligns, c->gt_stage[6] / c->gt_aligns, c->gt_stage[7] / c->gt_aligns,
+            c->gt_stage[8] / c->gt_aligns);
   if (!c) return ICPGPU_OK;
   for (icpgpu_ctx* w : c->workers) icpgpu_destroy(w);
   c->workers.clear();
@@ -535,6 +542,7 @@ int promote_internal(icpgpu_ctx* c) {
   // the source's GICP covariances stay valid for the cloud that is now the target
   std::swap(c->cov_src, c->cov_tgt);
   std::swap(c->cov_grid_src, c->cov_grid_tgt);
+  const bool cov_grid_follows = c->cov_grid_tgt.built && c->cov_grid_tgt.version == c->src_version;
   // ... and so does its cell order: it is the new target's grid
   std::swap(c->grid, c->src_grid);
   const bool grid_follows = c->grid.built && c->grid.version == c->src_version;
@@ -545,6 +553,9 @@ int promote_internal(icpgpu_ctx* c) {
   else c->grid.built = c->grid.usable = false;
   c->src_grid.built = c->src_grid.usable = false;
   c->cov_tgt_version = (c->cov_src_version == c->src_version) ? c->tgt_version : 0;
+  if (cov_grid_follows) c->cov_grid_tgt.version = c->tgt_version;  // (ensure_grid may adopt it for the GICP search)
+  else c->cov_grid_tgt.built = c->cov_grid_tgt.usable = false;
+  c->cov_grid_src.built = c->cov_grid_src.usable = false;          // the old target's: never to be mistaken for a new source's
   c->cov_src_version = 0;
   c->src_version++;
   c->src.n = 0;

@@ -206,6 +206,15 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     ~ServerGuard() { gicp_server_stop(c); }
   } server_guard{c};
   const auto t_start = std::chrono::steady_clock::now();
+  // development flavour, ICPGPU_GICP_TIMING=1: host wall per stage (printed by icpgpu_destroy)
+  static const bool stage_timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
+  auto t_mark = t_start;
+  auto mark = [&](int stage) {
+    if (!stage_timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    c->gt_stage[stage] += std::chrono::duration<double, std::micro>(now - t_mark).count();
+    t_mark = now;
+  };
   init_result(res);
   c->prof.aligns += 1;
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
@@ -227,6 +236,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   int rc;
   if ((rc = ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version))) return rc;
   if ((rc = ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version))) return rc;
+  mark(0);
   // GICP keeps d2 < r^2 (strict): the largest float below r^2
   const double r2 = P.max_correspondence_distance * P.max_correspondence_distance;
   float thr = threshold_from(r2);
@@ -239,6 +249,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
   auto* maha = static_cast<double*>(c->maha.ptr);
   const Xform base = xform_from_f16(guess);
+  mark(1);
 
   float transformation[16], previous[16];
   mat4f_identity(transformation);
@@ -276,6 +287,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
                                        static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    mark(2);
 
     // rigid_transformation_estimation_: BFGS over x = (t, roll, pitch, yaw), every evaluation one reduction on the device
     double m_count = 0.0;
@@ -398,6 +410,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       x = gicp_state_from_matrix(transformation);
       GicpEval probe;
       if (!eval(x, probe)) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
+      mark(3);
       n_corr = (unsigned)m_count;
       std::memcpy(previous, transformation, sizeof(previous));
       if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
@@ -405,7 +418,9 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         break;
       }
       const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
+      mark(4);
       gicp_server_stop(c);
+      mark(5);
       if (sr == GicpSolve::DeviceError) return fail(c, ICPGPU_ERR_HIP, "GICP cost evaluation failed: %s", hipGetErrorString(hipGetLastError()));
       if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
         state = ICPGPU_NOT_CONVERGED;
@@ -419,6 +434,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     dev_ms += ms;
     c->prof.grid_launches += grid_ready(c) ? 1 : 0;
     c->prof.grid_ms += grid_ready(c) ? ms : 0.0;
+    mark(6);
     double delta = 0.0;
     for (int k = 0; k < 4; ++k)
       for (int l = 0; l < 4; ++l) {
@@ -461,7 +477,10 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     dev_ms += c->dev_ms_accum;  // 0 when this sweep was not a timed one
     res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   }
+  mark(7);
   if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
+  mark(8);
+  c->gt_aligns += 1;
   res->t_device_ms = dev_ms;
   res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   return ICPGPU_OK;

@@ -43,8 +43,10 @@ int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, 
   if (G.built && G.version == version && G.cutoff == cutoff) return ICPGPU_OK;  // (state Done)
   G.built = true;
   G.usable = false;
+  G.adopted = false;
   G.version = version;
   G.cutoff = cutoff;
+  G.cut_d = cut;
   int rc = ensure(c, G.ints, (6 + kGridStatInts) * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(G.ints.ptr);
@@ -222,6 +224,28 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
     G.usable = false;
     G.built = false;
     return ICPGPU_OK;
+  }
+  // GICP: the grid the target's covariances were computed over (cells for ~8 points: ensure_covariances) serves the
+  // correspondence search as well.  The keys are exact whatever the cells are and nothing downstream of them depends on the
+  // cell size, so the results are the same bits -- and the per-scan pipeline builds ONE index per cloud instead of two (the
+  // second one cost 0.15 ms per scan: a bounding box and up to three count passes, each a host round trip).  The grids change
+  // hands (a swap: no buffer is freed); other methods never see an adopted grid.
+  static const bool adopt_enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_ADOPT_GRID"); return !e || std::atoi(e) != 0; }();
+  const bool gicp = c->params.method == ICPGPU_GICP && adopt_enabled;
+  if (G.adopted) {
+    if (gicp && G.built && G.usable && G.version == c->tgt_version && (double)accept_thr <= G.cut_d * G.cut_d) return ICPGPU_OK;
+    G.built = G.usable = G.adopted = false;  // another method, another target or a wider gate: its own grid
+  }
+  if (gicp && !(G.built && G.version == c->tgt_version && G.cutoff == (float)cut)) {
+    GridIndex& V = c->cov_grid_tgt;
+    if (V.built && V.usable && V.version == c->tgt_version && c->cov_tgt_version == c->tgt_version && c->cov_tgt.ptr &&
+        (double)accept_thr <= V.cut_d * V.cut_d) {
+      std::swap(G, V);
+      G.adopted = true;
+      V.built = V.usable = V.adopted = false;
+      c->prof.grid_adopted += 1;
+      return ICPGPU_OK;
+    }
   }
   return build_grid(c, c->tgt, c->tgt_version, cut, /*adapt=*/true, G);
 }

@@ -145,6 +145,8 @@ typedef struct {
   uint64_t brute_bound_violations; /* test mode ICPGPU_MFMA_CHECK_BOUND=1 of the bf16 matrix-core search: pairs whose lower bound */
   double brute_bound_worst;        /*   exceeded what their own exact distance allows (must stay 0); worst excess / (P^2 + |v|^2) seen */
   uint64_t gicp_device_solves;     /* GICP outer iterations whose whole inner BFGS ran on the device (gicp_solve_kernel) */
+  uint64_t grid_adopted;           /* GICP: targets whose correspondence search took over the grid their covariances were computed
+                                    * over instead of building a second one (same keys: the search is exact whatever the cells) */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
