@@ -117,12 +117,17 @@ static void gicp_server_stop(icpgpu_ctx* c) {
 static const int kGicpEntries[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
 static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
   const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(mailbox);
-  // the numbers first (one compare per entry, as cheap as the plain tags were: this loop runs thousands of times per scan), the
-  // checksums only once every entry carries the number
+  // the numbers first (one compare per entry: this loop runs thousands of times per scan), the checksums only once every
+  // entry carries the number.  The pass over the numbers has NO early exit: the device's writes invalidate the host's cached
+  // copies of these lines (7 per workgroup), and a loop that leaves at the first stale entry fetches them one miss after the
+  // other -- without the branch the loads are independent and the misses overlap.
   const volatile unsigned long long* w0 = w;
+  unsigned long long stale = 0;
+  for (int b = 0; b < n_blocks; ++b) stale |= (w0[(size_t)b * kGicpPartialStride + 2 * 28 + 1] >> 24) ^ seq;  // one entry per workgroup: a cheap gate
+  if (stale) return false;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
-    for (int e : kGicpEntries)
-      if ((w[2 * e + 1] >> 24) != seq) return false;
+    for (int e : kGicpEntries) stale |= (w[2 * e + 1] >> 24) ^ seq;
+  if (stale) return false;
   unsigned long long bits;
   w = w0;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
