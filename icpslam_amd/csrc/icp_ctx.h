@@ -237,6 +237,9 @@ struct icpgpu_ctx {
   // ICPGPU_GICP_TIMING=1 (development): where an evaluation's microseconds go, printed when the context is destroyed
   double gt_cmd = 0, gt_wait = 0, gt_merge = 0, gt_between = 0, gt_dev_wait = 0, gt_dev_work = 0;
   unsigned long long gt_n = 0;
+  double gt_dev_reduce = 0, gt_trickle = 0;
+  unsigned long long gt_dev_n = 0;
+  int gt_pending = 0;
   double gt_stage[10] = {};  // ICPGPU_GICP_TIMING: host wall per stage of align_gicp (icpgpu_gicp.cpp), microseconds
   unsigned long long gt_aligns = 0;
   // ICPGPU_P2P_TIMING=1 (development): host time between a sweep's sums and the next search kernel's launch

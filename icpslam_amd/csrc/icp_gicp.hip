@@ -545,22 +545,31 @@ __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, doub
   }
   __syncthreads();
   double* out = partials + (size_t)blockIdx.x * kGicpPartialStride;
-  if (threadIdx.x < kGicpSums) {
-    DD x[16];
+  if (threadIdx.x < 64) {
+    // wave 0: lane s < 13 adds the chunks of sum s, lane 13 has m and sum d2; then the 28 results are dealt to the lanes whose
+    // number is the entry's (two ds_bpermute per double), so that ONE store instruction writes the workgroup's whole answer --
+    // seven 64-byte requests towards the host instead of ten from four instructions (the answers of a run's workgroups reach
+    // the host over 1.2-2 us, the largest single item of an evaluation's wall time: icpgpu_gicp.cpp's stage timers)
+    DD v{0.0, 0.0};
+    double m = 0.0, d2 = 0.0;
+    if (threadIdx.x < kGicpSums) {
+      DD x[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
-    const DD v = dd_sum16(x);
-    gicp_store_tagged(out, 1 + threadIdx.x, v.hi, tag);
-    gicp_store_tagged(out, 16 + threadIdx.x, v.lo, tag);
-  } else if (threadIdx.x == kGicpSums) {
-    double m = have_md ? md[0] : (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]);
-    double d2 = have_md ? md[1] : (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]);
-    gicp_store_tagged(out, 0, m, tag);
-    gicp_store_tagged(out, 14, d2, tag);
-    if (md) {
-      md[0] = m;
-      md[1] = d2;
+      for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
+      v = dd_sum16(x);
+    } else if (threadIdx.x == kGicpSums) {
+      m = have_md ? md[0] : (s_md[0][0] + s_md[0][1]) + (s_md[0][2] + s_md[0][3]);
+      d2 = have_md ? md[1] : (s_md[1][0] + s_md[1][1]) + (s_md[1][2] + s_md[1][3]);
+      if (md) {
+        md[0] = m;
+        md[1] = d2;
+      }
     }
+    const int e = (int)threadIdx.x;  // entry number
+    const double from_hi = __shfl(v.hi, e >= 1 ? e - 1 : 0, 64), from_lo = __shfl(v.lo, e >= 16 ? e - 16 : 0, 64);
+    const double from_m = __shfl(m, kGicpSums, 64), from_d2 = __shfl(d2, kGicpSums, 64);
+    const double value = e == 0 ? from_m : e <= 13 ? from_hi : e == 14 ? from_d2 : from_lo;
+    if (e <= 28 && e != 15) gicp_store_tagged(out, e, value, tag);
   }
   if (md) md[2] = 1.0;
 }
@@ -597,10 +606,11 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
                                                           const unsigned long long* __restrict__ keys, float thr, Xform base,
                                                           const double* __restrict__ maha6, double* __restrict__ host_partials,
                                                           unsigned long long* host_flags, unsigned int* cmd,
-                                                          unsigned int first_seq, unsigned int seq_hi) {
+                                                          unsigned int first_seq, unsigned int seq_hi, int stamps) {
   __shared__ Xform s_T;
   __shared__ unsigned int s_seq;
   __shared__ long long s_seen;
+  __shared__ unsigned int s_polls;
   const long long patience = 5000000;  // 50 ms of the 100 MHz wall clock
   unsigned int expect = first_seq;
   // RESIDENT (small problems: every lane's share is one quad): the correspondences do not change during a run, so they are
@@ -617,19 +627,25 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
       // memory).  The words of T were posted before the number, so a read that returns the number returns them too.
       unsigned int got = kGicpServerExit, word = 0u;
       const long long t0 = (long long)wall_clock64();
-      for (;;) {
-        word = __hip_atomic_load(&cmd[threadIdx.x & 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (One read in flight, 0.18 us each.  Four -- a hand-written loop behind s_waitcnt vmcnt(3) -- were measured in round 4 and
+      // made an evaluation SLOWER, 8.3 instead of 7.1 us.)
+      const unsigned int* line = &cmd[threadIdx.x & 15];
+      unsigned int polls_done = 0;
+      for (unsigned int polls = 1;; ++polls) {
+        polls_done = polls;
+        word = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned int v = (unsigned int)__builtin_amdgcn_readlane((int)word, 12);
         if (v == expect || v == kGicpServerExit) {
           got = v;
           break;
         }
-        if ((long long)wall_clock64() - t0 > patience) break;  // got stays kGicpServerExit
+        if ((polls & 15u) == 0 && (long long)wall_clock64() - t0 > patience) break;  // got stays kGicpServerExit
       }
       if (threadIdx.x < 12) s_T.m[threadIdx.x] = __uint_as_float(word);
       if (threadIdx.x == 12) {
         s_seq = got;
         s_seen = (long long)wall_clock64();
+        s_polls = polls_done;
       }
     }
     __syncthreads();
@@ -648,12 +664,21 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
     } else {
       gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (development, ICPGPU_GICP_TIMING: two spare entries of the mailbox)
-      const long long t_now = (long long)wall_clock64();
-      host_partials[2 * 30] = (double)(s_seen - t_loop) * 0.01;   // polling
-      host_partials[2 * 31] = (double)(t_now - s_seen) * 0.01;    // work up to the reduction
-    }
+    const long long t_acc = stamps ? (long long)wall_clock64() : 0;
     gicp_block_reduce_store(acc, host_partials, ((unsigned long long)seq_hi << 32) | seq, md);
+    if (stamps && threadIdx.x == 0) {  // (development flavour, ICPGPU_GICP_TIMING: three spare entries of this workgroup's line; 100 MHz ticks)
+      double* o = host_partials + (size_t)blockIdx.x * kGicpPartialStride;
+      o[2 * 29] = (double)s_seen;                    // command seen
+      o[2 * 30] = (double)t_acc;                     // its share accumulated
+      o[2 * 31] = (double)(long long)wall_clock64(); // reduced, results on their way
+      o[2 * 29 + 1] = (double)t_loop;                // started polling
+      o[2 * 30 + 1] = (double)s_polls;               // reads of the command line it took
+      {
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[2 * 31 + 1] = (double)(xcc & 15u);         // the XCD it runs on
+      }
+    }
     expect = seq + 1u;
     if (expect == kGicpServerExit) expect = 0u;
     __syncthreads();  // s_T / s_seq are rewritten in the next round
@@ -1101,14 +1126,15 @@ hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,
                               unsigned int* cmd, unsigned int first_seq, unsigned int seq_hi, hipStream_t stream) {
+  static const int stamps = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0 ? 1 : 0; }();
   // every lane's share fits one quad: up to 256 workgroups x 1024 points (ICPGPU_GICP_RESIDENT_MAX: tuning switch; 0 = never)
   static const int resident_max = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_RESIDENT_MAX"); return e ? std::atoi(e) : 262144; }();
   if ((long long)blocks * 1024 >= n_s && n_s <= resident_max)
     hipLaunchKernelGGL(gicp_server_kernel<true>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
-                       host_partials, host_flags, cmd, first_seq, seq_hi);
+                       host_partials, host_flags, cmd, first_seq, seq_hi, stamps);
   else
     hipLaunchKernelGGL(gicp_server_kernel<false>, dim3(blocks), dim3(256), 0, stream, src, n_s, tgt, keys, thr, base, maha6,
-                       host_partials, host_flags, cmd, first_seq, seq_hi);
+                       host_partials, host_flags, cmd, first_seq, seq_hi, stamps);
   return hipGetLastError();
 }
 

@@ -318,9 +318,12 @@ int icpgpu_destroy(icpgpu_ctx* c) {
             c->pt_n, c->pt_wait / c->pt_n, c->pt_solve / c->pt_n, c->pt_prelaunch / c->pt_n, c->pt_launch / c->pt_n, c->pt_rest / c->pt_n);
   if (c && c->gt_n)
     fprintf(stderr, "[icpgpu] GICP evaluations through the server: %llu; per evaluation: command write %.2f us, wait for the flags %.2f us "
-                    "(device: polling %.2f us, work %.2f us), merge %.2f us, solver between evaluations %.2f us\n",
-            c->gt_n, c->gt_cmd / c->gt_n, c->gt_wait / c->gt_n, c->gt_dev_wait / c->gt_n, c->gt_dev_work / c->gt_n, c->gt_merge / c->gt_n,
-            c->gt_between / c->gt_n);
+                    "(first workgroup's result visible -> all visible and checked: %.2f us), merge %.2f us, solver between evaluations %.2f us | "
+                    "device, mean over the workgroups: polling %.2f us, accumulate %.2f us, reduce + store %.2f us (three evaluations are "
+                    "printed workgroup by workgroup above)\n",
+            c->gt_n, c->gt_cmd / c->gt_n, c->gt_wait / c->gt_n, c->gt_trickle / c->gt_n, c->gt_merge / c->gt_n, c->gt_between / c->gt_n,
+            c->gt_dev_n ? c->gt_dev_wait / c->gt_dev_n : 0.0, c->gt_dev_n ? c->gt_dev_work / c->gt_dev_n : 0.0,
+            c->gt_dev_n ? c->gt_dev_reduce / c->gt_dev_n : 0.0);
   if (c && c->gt_aligns)
     fprintf(stderr, "[icpgpu] GICP alignments: %llu; host wall per alignment (us): covariances %.1f | grid + buffers %.1f | search + Mahalanobis "
                     "launches %.1f | server start + first evaluation %.1f | BFGS %.1f | server stop %.1f | event read-back %.1f | fitness %.1f | "

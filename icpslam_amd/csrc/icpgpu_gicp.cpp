@@ -61,8 +61,10 @@ static inline void gicp_dd_add(double& hi, double& lo, double bh, double bl) {
 }
 
 // ---- the resident evaluation server of a BFGS run (gicp_server_kernel) ---------------------------------------------
-// A command is four 16-byte chunks {3 floats of T, sequence number}; each chunk is ONE aligned 16-byte store, so the
-// device never sees half a chunk, and it acts once all four carry the number it waits for.
+// A command is the 12 floats of T, then the sequence number, in one 64-byte line of fine-grained device memory; the device acts
+// once the line carries the number it waits for.  (Round 4 measured two variations, neither faster: a line per workgroup --
+// written 23 times by the host -- and four reads in flight per workgroup instead of one; per-workgroup stamps show all workgroups
+// seeing a command within 0.2 us of each other as it is, a read of the line taking 0.18 us.)
 static void gicp_server_command(icpgpu_ctx* c, unsigned int seq, const Xform& T) {
 #if defined(__x86_64__)
   // T first, the number last, a store fence in between and behind: posted writes reach the device in that order
@@ -124,7 +126,7 @@ static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsign
   const volatile unsigned long long* w0 = w;
   unsigned long long stale = 0;
   for (int b = 0; b < n_blocks; ++b) stale |= (w0[(size_t)b * kGicpPartialStride + 2 * 28 + 1] >> 24) ^ seq;  // one entry per workgroup: a cheap gate
-  if (stale) return false;
+  if (stale) return false;  // (polling all entries instead -- fetching the lines as they arrive -- measured the same)
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
     for (int e : kGicpEntries) stale |= (w[2 * e + 1] >> 24) ^ seq;
   if (stale) return false;
@@ -138,8 +140,19 @@ static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsign
 // 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
 static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, bool server) {
   std::chrono::steady_clock::time_point t0;
+  static const bool timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
+  bool any_seen = false;
+  std::chrono::steady_clock::time_point t_any;
   for (unsigned spins = 1;; ++spins) {
-    if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) break;
+    if (timing && !any_seen) {  // (development flavour: when does the FIRST workgroup's result show up, when the last?)
+      const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(c->h_gicp);
+      for (int b = 0; b < n_blocks && !any_seen; ++b) any_seen = (w[(size_t)b * kGicpPartialStride + 2 * 28 + 1] >> 24) == seq;
+      if (any_seen) t_any = std::chrono::steady_clock::now();
+    }
+    if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) {
+      if (timing && any_seen) c->gt_trickle += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_any).count();
+      break;
+    }
     if ((spins & 0x3FFu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {
@@ -312,6 +325,32 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       if (timing) {
         tq0 = std::chrono::steady_clock::now();
         if (c->gt_n && c->gicp_server_on) c->gt_between += std::chrono::duration<double, std::micro>(tq0 - c->gt_last).count();
+        if (c->gt_pending > 0) {  // the last evaluation's device stamps (icp_gicp.hip: gicp_server_kernel), 100 MHz ticks
+          double first_seen = 1e300, last_seen = 0, last_done = 0, acc = 0, red = 0, poll = 0;
+          for (int b = 0; b < c->gt_pending; ++b) {
+            const double* o = c->h_gicp + (size_t)b * kGicpPartialStride;
+            const double seen = o[2 * 29], t_acc = o[2 * 30], done = o[2 * 31], loop = o[2 * 29 + 1];
+            first_seen = std::min(first_seen, seen);
+            last_seen = std::max(last_seen, seen);
+            last_done = std::max(last_done, done);
+            acc += t_acc - seen;
+            red += done - t_acc;
+            poll += seen - loop;
+          }
+          if (c->gt_dev_n >= 1000 && c->gt_dev_n < 1003) {  // a few evaluations in full
+            fprintf(stderr, "[icpgpu] evaluation %llu, per workgroup (us after the first one saw the command): xcd | started polling | saw it | accumulated | stored | reads\n", c->gt_dev_n);
+            for (int b = 0; b < c->gt_pending; ++b) {
+              const double* o = c->h_gicp + (size_t)b * kGicpPartialStride;
+              fprintf(stderr, "[icpgpu]   %2d: %d | %7.2f | %5.2f | %5.2f | %5.2f | %3.0f\n", b, (int)o[2 * 31 + 1], (o[2 * 29 + 1] - first_seen) * 0.01,
+                      (o[2 * 29] - first_seen) * 0.01, (o[2 * 30] - first_seen) * 0.01, (o[2 * 31] - first_seen) * 0.01, o[2 * 30 + 1]);
+            }
+          }
+          c->gt_dev_wait += poll / c->gt_pending * 0.01;
+          c->gt_dev_work += acc / c->gt_pending * 0.01;
+          c->gt_dev_reduce += red / c->gt_pending * 0.01;
+          c->gt_dev_n += 1;
+          c->gt_pending = 0;
+        }
       }
       if (c->gicp_server_on) {  // the resident server evaluates; no launch
         gicp_server_command(c, (unsigned int)seq, xform_from_f16(T));
@@ -346,8 +385,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         c->gt_cmd += std::chrono::duration<double, std::micro>(tq1 - tq0).count();
         c->gt_wait += std::chrono::duration<double, std::micro>(tq2 - tq1).count();
         c->gt_merge += std::chrono::duration<double, std::micro>(tq3 - tq2).count();
-        c->gt_dev_wait += c->h_gicp[2 * 30];   // block 0's stamps (icp_gicp.hip): polling, then work, in microseconds
-        c->gt_dev_work += c->h_gicp[2 * 31];
+        c->gt_pending = nblk;  // the workgroups' stamps of this evaluation are read when the next one starts (they trail the tags)
         c->gt_n += 1;
         c->gt_last = tq3;
       }
