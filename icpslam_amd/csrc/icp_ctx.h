@@ -60,6 +60,12 @@ struct Cloud {
   // different cloud (fixed-size scans!) in a microsecond instead of hashing megabytes to find out
   unsigned long long sample_fp = 0;
   bool sample_valid = false;
+  // a box that CONTAINS every finite point (encoded like bbox_kernel's result), valid while the owner's version counter equals
+  // bbox_version (0 = none): what a grid build needs of the cloud before its count pass.  Filled by the voxel filter (the raw
+  // scan's box contains its centroids) and by a grid build's own bounding-box pass; mutable: a cache, not content.
+  mutable uint64_t bbox_version = 0;
+  mutable int bbox_enc[6] = {0, 0, 0, 0, 0, 0};
+  mutable bool bbox_exact = false;  // from a bounding-box pass over these very points (no containment check needed)
   const float4* data() const { return static_cast<const float4*>(buf.ptr); }
 };
 
@@ -201,6 +207,7 @@ struct icpgpu_ctx {
   uint64_t src_version = 1;  // bumped whenever the source cloud changes
   // GICP mode: grids used for the 20-NN covariances, per-point covariances (6 doubles), Mahalanobis matrices
   GridIndex cov_grid_src, cov_grid_tgt;
+  double cov_h_hint = 0.0, cov_h_hint_cut = 0.0;  // the cell size the last covariance grid settled on (ensure_covariances)
   DeviceBuf cov_src, cov_tgt, maha;
   uint64_t cov_src_version = 0, cov_tgt_version = 0;
   // Per-iteration result mailbox in pinned, mapped host memory: 17 sums + 17 sequence flags.  The final reduction
@@ -307,6 +314,8 @@ struct GridBuild {
   GridIndex* G = nullptr;
   const int* orig_index = nullptr;
   double knn_population = 0.0;
+  bool box_cached = false;  // the bounding box came from the cloud's cache (a CONTAINING box: gb_on_count checks that every point was binned)
+  double h_start = 0.0;  // > 0: the first count pass uses this cell size instead of cut / 4.5 (k-NN grids only: see ensure_covariances)
   double h = 0.0;
   int attempt = 0;
   bool shrunk = false;
@@ -360,10 +369,10 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
 int promote_internal(icpgpu_ctx* c);
 // icpgpu_index.cpp
 int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
-             const int* orig_index = nullptr, double knn_population = 0.0);
+             const int* orig_index = nullptr, double knn_population = 0.0, double h_start = 0.0);
 int gb_advance(icpgpu_ctx* c, GridBuild& b);
 int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
-               const int* orig_index = nullptr, double knn_population = 0.0);
+               const int* orig_index = nullptr, double knn_population = 0.0, double h_start = 0.0);
 int ensure_grid(icpgpu_ctx* c, float accept_thr);
 int grid_flags(const GridIndex& G, bool src_in_cell_order);
 int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, float4*& buf, bool& use);
@@ -397,7 +406,8 @@ int p2p_begin(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int
 int p2p_advance(icpgpu_ctx* c, P2PRun& r, int* deferred = nullptr);
 int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res);
 // icpgpu_voxel.cpp
-int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough);
+int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough,
+                        int* bbox_enc_out = nullptr);
 // icpgpu_gicp.cpp
 int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version);
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res);

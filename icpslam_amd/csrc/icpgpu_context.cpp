@@ -100,6 +100,7 @@ int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool s
   }
   cl.n = n;
   cl.set = true;
+  cl.bbox_version = 0;
   cl.sample_valid = n > 0;
   cl.sample_fp = n > 0 ? sample_fingerprint(xyzw, n) : 0;
   return ICPGPU_OK;
@@ -114,6 +115,7 @@ int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n) {
   cl.buf.external = true;
   cl.n = n;
   cl.set = true;
+  cl.bbox_version = 0;
   cl.sample_valid = false;
   return ICPGPU_OK;
 }
@@ -482,6 +484,7 @@ int icpgpu_set_target(icpgpu_ctx* c, const float* xyzw, size_t n) {
           c->src.set = true;
           c->src.sample_fp = c->tgt.sample_fp;  // the copy IS the target's content
           c->src.sample_valid = c->tgt.sample_valid;
+          c->src.bbox_version = 0;
           c->src_fp = fp;
           c->src_fp_version = c->src_version;
           return ICPGPU_OK;
@@ -546,6 +549,7 @@ int promote_internal(icpgpu_ctx* c) {
   std::swap(c->cov_src, c->cov_tgt);
   std::swap(c->cov_grid_src, c->cov_grid_tgt);
   const bool cov_grid_follows = c->cov_grid_tgt.built && c->cov_grid_tgt.version == c->src_version;
+  const bool box_follows = c->tgt.bbox_version != 0 && c->tgt.bbox_version == c->src_version;  // (c->tgt is the old source by now)
   // ... and so does its cell order: it is the new target's grid
   std::swap(c->grid, c->src_grid);
   const bool grid_follows = c->grid.built && c->grid.version == c->src_version;
@@ -559,6 +563,8 @@ int promote_internal(icpgpu_ctx* c) {
   if (cov_grid_follows) c->cov_grid_tgt.version = c->tgt_version;  // (ensure_grid may adopt it for the GICP search)
   else c->cov_grid_tgt.built = c->cov_grid_tgt.usable = false;
   c->cov_grid_src.built = c->cov_grid_src.usable = false;          // the old target's: never to be mistaken for a new source's
+  c->tgt.bbox_version = box_follows ? c->tgt_version : 0;          // the box travels with the cloud, re-stamped for its new counter
+  c->src.bbox_version = 0;
   c->cov_src_version = 0;
   c->src_version++;
   c->src.n = 0;

@@ -32,8 +32,18 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
   static const double knn_pop = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_KNN_POP"); return e ? std::atof(e) : 8.0; }();
-  int rc = build_grid(c, cloud, version, std::isfinite(cut) ? std::min(cut, 1e6) : 1.0, /*adapt=*/false, G, nullptr, knn_pop);
+  // The first count pass starts from the cell size the LAST covariance grid of this context settled on (consecutive scans of a
+  // drive are alike: one pass instead of two); the rule that accepts or corrects it is the same.  History may decide the cells,
+  // never a result: the 20 neighbours are exact whatever the cells are, and they are summed in order of distance.
+  static const bool hint_enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_KNN_HINT"); return !e || std::atoi(e) != 0; }();
+  const double cut_used = std::isfinite(cut) ? std::min(cut, 1e6) : 1.0;
+  const double h_start = (hint_enabled && c->cov_h_hint > 0.0 && c->cov_h_hint_cut == cut_used) ? c->cov_h_hint : 0.0;
+  int rc = build_grid(c, cloud, version, cut_used, /*adapt=*/false, G, nullptr, knn_pop, h_start);
   if (rc) return rc;
+  if (G.usable) {
+    c->cov_h_hint = (double)G.g.h;
+    c->cov_h_hint_cut = cut_used;
+  }
   if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
   if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));

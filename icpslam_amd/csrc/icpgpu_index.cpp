@@ -27,11 +27,13 @@ static double grid_divisor() {
 
 
 int gb_issue_count(icpgpu_ctx* c, GridBuild& b);
+static int gb_with_bbox(icpgpu_ctx* c, GridBuild& b, const int enc[6], bool cached);
 
 // queue the bounding box (or find the grid already built)
 int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
-             const int* orig_index, double knn_population) {
+             const int* orig_index, double knn_population, double h_start) {
   b = GridBuild{};
+  b.h_start = h_start;
   b.cloud = &cloud;
   b.version = version;
   b.cut = cut;
@@ -51,6 +53,7 @@ int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, 
   if (rc) return rc;
   int* d_ints = static_cast<int*>(G.ints.ptr);
   b.t0 = std::chrono::steady_clock::now();
+  if (version != 0 && cloud.bbox_version == version) return gb_with_bbox(c, b, cloud.bbox_enc, !cloud.bbox_exact);  // a containing box is known: no pass, no round trip
   HIP_TRY(c, launch_bbox(cloud.data(), (int)cloud.n, d_ints, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   b.state = GridBuild::WaitBbox;
@@ -59,7 +62,25 @@ int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, 
 
 // the bounding box has arrived (the caller synchronised the stream): size the table, queue the count pass
 int gb_on_bbox(icpgpu_ctx* c, GridBuild& b) {
-  decode_bbox(c->h_ints, b.lo, b.hi);
+  if (b.version != 0) {  // remembered with the cloud: its next grid (another cell size, the other role after a promote) starts here
+    std::memcpy(b.cloud->bbox_enc, c->h_ints, sizeof(b.cloud->bbox_enc));
+    b.cloud->bbox_version = b.version;
+    b.cloud->bbox_exact = true;
+  }
+  return gb_with_bbox(c, b, c->h_ints, false);
+}
+
+static int gb_with_bbox(icpgpu_ctx* c, GridBuild& b, const int enc[6], bool cached) {
+  decode_bbox(enc, b.lo, b.hi);
+  b.box_cached = cached;
+  if (cached)  // a box handed over by the voxel filter holds float means of its points: room for their rounding (gb_on_count checks)
+    for (int a = 0; a < 3; ++a) {
+      const float pad = std::ldexp(std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])), -10);
+      if (std::isfinite(pad)) {
+        b.lo[a] -= pad;
+        b.hi[a] += pad;
+      }
+    }
   if (!(b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2])) {  // no finite point
     b.state = GridBuild::Done;
     return ICPGPU_OK;
@@ -69,7 +90,7 @@ int gb_on_bbox(icpgpu_ctx* c, GridBuild& b) {
   // of many scans), the cells shrink so that this population comes down to ~kTargetCellPopulation (populations of
   // surface samples scale with h^2): the octant stage then still certifies most points (their neighbour is closer than
   // h/2) and reads 4x fewer candidates.  Measured at 200k x 1M: 126 -> ~84 us per iteration.
-  b.h = b.cut / grid_divisor();
+  b.h = b.h_start > 0.0 ? std::min(std::max(b.h_start, b.cut / 64.0), 8.0 * b.cut / grid_divisor()) : b.cut / grid_divisor();
   b.attempt = 0;
   b.shrunk = false;
   return gb_issue_count(c, b);
@@ -141,6 +162,16 @@ int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
   unsigned long long sumsq = 0;
   std::memcpy(&sumsq, c->h_ints + 8, sizeof sumsq);
   const int binned = c->h_ints[10];
+  if (b.box_cached && binned != n_t) {
+    // the cached box does not contain every point (a mean that left its points' box through float rounding: thousands of
+    // points in one voxel far from the origin) or the cloud holds non-finite points: the cloud's own bounding-box pass decides
+    b.cloud->bbox_version = 0;
+    b.box_cached = false;
+    HIP_TRY(c, launch_bbox(b.cloud->data(), n_t, d_ints, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    b.state = GridBuild::WaitBbox;
+    return ICPGPU_OK;
+  }
   const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
   const int attempt = b.attempt;
   bool again = false;
@@ -204,9 +235,9 @@ int gb_advance(icpgpu_ctx* c, GridBuild& b) {
 }
 
 int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
-               const int* orig_index, double knn_population) {
+               const int* orig_index, double knn_population, double h_start) {
   GridBuild b;
-  int rc = gb_begin(c, b, cloud, version, cut, adapt, G, orig_index, knn_population);
+  int rc = gb_begin(c, b, cloud, version, cut, adapt, G, orig_index, knn_population, h_start);
   while (!rc && b.state != GridBuild::Done) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     rc = gb_advance(c, b);

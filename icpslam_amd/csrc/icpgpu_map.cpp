@@ -328,6 +328,7 @@ int icpgpu_map_nn_target(icpgpu_ctx* c, const float* pose, const float* pose_inv
   c->tgt_version++;
   c->tgt.set = true;
   c->tgt.n = 0;
+  c->tgt.bbox_version = 0;
   c->tgt.sample_valid = false;
   c->have_final = false;
   if (M.n == 0 || n_s == 0) return ICPGPU_OK;  // approxNearestNeighbors() on an empty map: empty nn cloud

@@ -6,9 +6,12 @@ namespace icpgpu_impl {
 
 // pcl::VoxelGrid<PointXYZ>::filter on a device-resident cloud (icp_odometer.cpp:96-101). out receives *n_out points
 // (ascending cell index). *passthrough = PCL's "leaf size too small for the input dataset" case: input returned as is.
-int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough) {
+int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough,
+                        int* bbox_enc_out) {
   *n_out = 0;
   *passthrough = false;
+  if (bbox_enc_out)
+    for (int a = 0; a < 3; ++a) bbox_enc_out[a] = 1, bbox_enc_out[3 + a] = 0;  // (an empty box until the input's has been read back)
   if (!(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel filter: leaf size must be positive");
   if (n <= 0) return ICPGPU_OK;
   int rc = ensure(c, c->vox_ints, 16 * sizeof(int));
@@ -19,6 +22,7 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   float lo[3], hi[3];
   decode_bbox(c->h_ints, lo, hi);
+  if (bbox_enc_out) std::memcpy(bbox_enc_out, c->h_ints, 6 * sizeof(int));  // the input's box: it contains every centroid
   if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
   const float inv = 1.0f / leaf;  // PCL: inverse_leaf_size_ = 1 / leaf_size_ in float
   int minb[3], divb[3];
@@ -123,7 +127,7 @@ int icpgpu_voxel_grid(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, fl
   if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   int m = 0;
   bool pass = false;
-  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass))) return rc;
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass, nullptr))) return rc;
   if (m && out_xyzw) {
     HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -157,9 +161,19 @@ int icpgpu_set_source_voxel_filtered(icpgpu_ctx* c, const float* xyzw, size_t n,
   bool pass = false;
   if (c->src.buf.external) c->src.buf = DeviceBuf{};
   c->src_version++;
-  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->src.buf, &m, &pass))) return rc;
+  c->src.bbox_version = 0;
+  int box[6];
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->src.buf, &m, &pass, box))) return rc;
   c->src.n = (size_t)m;
   c->src.set = true;
+  // The raw scan's bounding box contains every centroid (a mean of points inside a box lies inside it, up to a rounding the
+  // grid's one-cell margin absorbs): the grids built over the filtered cloud start from it, without a pass and a round trip
+  // of their own.  (An empty / non-finite input leaves lo > hi: a grid build then finds "no finite point", as its own pass would.)
+  if (m > 0) {
+    std::memcpy(c->src.bbox_enc, box, sizeof(box));
+    c->src.bbox_version = c->src_version;
+    c->src.bbox_exact = false;
+  }
   c->src.sample_valid = false;  // written on the device: no host sample to compare with
   if (n_out) *n_out = (size_t)m;
   return ICPGPU_OK;

@@ -262,3 +262,51 @@ def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path
         # mse_last = (sum of the correspondences' float d2) / m: a diagnostic; its float64 sum is rounded in workgroup order, and
         # the two paths use different workgroup counts for clouds of more than 64 x 1024 points
         assert abs(d["f%d" % n][0] - h["f%d" % n][0]) <= 1e-12 * h["f%d" % n][0], n
+
+
+def test_filtered_scans_covariances_do_not_depend_on_the_box_or_the_cells_they_start_from(ctx):
+    """set_source_voxel_filtered hands the RAW scan's bounding box to the covariance grid (it contains the centroids; no second
+    bounding-box pass), and the grid's first count pass starts from the cell size the previous cloud settled on.  Neither may
+    change a bit: (1) a filtered scan's covariances equal the ones of the same cloud set directly (own box, default cells), over
+    a short sequence (so that the hint is live), the last scan with non-finite points; (2) a voxel of 600 000 identical points
+    far from the origin, whose float mean (PCL's sequential sum) lands 0.7 m outside the raw box, is caught by the build's
+    containment check and still indexed."""
+    ctx.set_params(ctx.default_params(), method=GICP)
+    rng = np.random.default_rng(11)
+    scene = synth.make_scene(3, extent=60.0)
+    direct = []
+    for k in range(3):
+        scan = synth.scan(scene, synth.pose_matrix(0.3 * k, 0.0, 0.0, 0.0, 0.0, 0.02 * k), 60000, seed=900 + k)
+        if k == 2:
+            scan = scan.copy()
+            scan[rng.integers(0, scan.shape[0], 50), 0] = np.nan
+            scan[rng.integers(0, scan.shape[0], 50), 2] = np.inf
+        m = ctx.set_source_voxel_filtered(scan, 0.2)
+        got = ctx.gicp_covariances()
+        filt = oracle.voxel_grid(scan[np.isfinite(scan[:, :3]).all(axis=1)], 0.2)  # (PCL skips non-finite points; the oracle expects none)
+        assert m == filt.shape[0]
+        direct.append((filt, got))
+        ctx.promote_source_to_target()
+    with type(ctx)(0) as fresh:
+        fresh.set_params(fresh.default_params(), method=GICP)
+        for filt, got in direct:
+            fresh.set_source(filt)
+            assert np.array_equal(fresh.gicp_covariances(), got)
+    # (2): the mean of 600 000 copies of one far point, summed in float, is not that point
+    far = np.tile(np.array([[99.0, -60.07, 1.01, 1.0]], np.float32), (600000, 1))
+    plane = np.zeros((400, 4), np.float32)
+    plane[:, 0] = 94.0 + 0.21 * (np.arange(400) % 20)
+    plane[:, 1] = -60.0 + 0.21 * (np.arange(400) // 20)
+    plane[:, 2] = 1.0 + 0.01 * rng.standard_normal(400).astype(np.float32)
+    plane[:, 3] = 1.0
+    cloud = np.concatenate([far, plane])
+    m = ctx.set_source_voxel_filtered(cloud, 0.2)
+    filt = oracle.voxel_grid(cloud, 0.2)
+    assert m == filt.shape[0]
+    lo, hi = cloud[:, :3].min(0), cloud[:, :3].max(0)
+    assert ((filt[:, :3] < lo) | (filt[:, :3] > hi)).any(), "the case is meant to leave the raw box"
+    got = ctx.gicp_covariances()
+    with type(ctx)(0) as fresh:
+        fresh.set_params(fresh.default_params(), method=GICP)
+        fresh.set_source(filt)
+        assert np.array_equal(fresh.gicp_covariances(), got)
