@@ -533,7 +533,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   mark(7);
   if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
   mark(8);
-  c->gt_aligns += 1;
+  if (stage_timing) c->gt_aligns += 1;
   res->t_device_ms = dev_ms;
   res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   return ICPGPU_OK;
