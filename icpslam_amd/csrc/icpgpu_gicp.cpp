@@ -336,13 +336,11 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         tq0 = std::chrono::steady_clock::now();
         if (c->gt_n && c->gicp_server_on) c->gt_between += std::chrono::duration<double, std::micro>(tq0 - c->gt_last).count();
         if (c->gt_pending > 0) {  // the last evaluation's device stamps (icp_gicp.hip: gicp_server_kernel), 100 MHz ticks
-          double first_seen = 1e300, last_seen = 0, last_done = 0, acc = 0, red = 0, poll = 0;
+          double first_seen = 1e300, acc = 0, red = 0, poll = 0;
           for (int b = 0; b < c->gt_pending; ++b) {
             const double* o = c->h_gicp + (size_t)b * kGicpPartialStride;
             const double seen = o[2 * 29], t_acc = o[2 * 30], done = o[2 * 31], loop = o[2 * 29 + 1];
             first_seen = std::min(first_seen, seen);
-            last_seen = std::max(last_seen, seen);
-            last_done = std::max(last_done, done);
             acc += t_acc - seen;
             red += done - t_acc;
             poll += seen - loop;
