@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
           len = cell_start[row + x1 + 1] - lo;
         }
         // The batch's rows as ONE list of candidates, 64 per chunk (round 4; until then one row -- ~24 candidates at cells sized for
-        // ~8 points -- per chunk, later two): an exclusive scan of the row lengths over the lanes, and every lane of a chunk finds
+        // ~8 points then -- per chunk, later two): an exclusive scan of the row lengths over the lanes, and every lane of a chunk finds
         // the row of its entry by a binary search over those offsets (six lane reads).  A merge round's ~100 fixed instructions
         // are then spent on 64 candidates, not on 24.
         int incl = len;

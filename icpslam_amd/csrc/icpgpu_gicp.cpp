@@ -31,7 +31,12 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   if (cov_version == version && cov.ptr) return ICPGPU_OK;
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
-  static const double knn_pop = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_KNN_POP"); return e ? std::atof(e) : 8.0; }();
+  // point-weighted cell population the covariance grid aims at.  8 until the kernel walked a cube level as one dense list of
+  // candidates (round 4); re-measured then: a voxel-filtered 22k-point scan 110 (8) / 94 (16) / 96 (24) / 98 us (32), raw scans --
+  // whose density falls with the square of the range, so that cells sized for the near field are empty in the far field --
+  // 5k 0.95 / 0.58 / 0.52, 50k 0.53 / 0.48 / 0.31, 200k 1.21 / 1.14 / 0.92 ms per cloud at 8 / 16 / 32.  (The neighbours are exact
+  // whatever the cells: a tuning constant, not a result.)
+  static const double knn_pop = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_KNN_POP"); return e ? std::atof(e) : 32.0; }();
   // The first count pass starts from the cell size the LAST covariance grid of this context settled on (consecutive scans of a
   // drive are alike: one pass instead of two); the rule that accepts or corrects it is the same.  History may decide the cells,
   // never a result: the 20 neighbours are exact whatever the cells are, and they are summed in order of distance.

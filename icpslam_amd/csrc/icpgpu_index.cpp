@@ -184,7 +184,7 @@ int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
       again = true;
     }
   }
-  // k-nearest-neighbour searches (GICP covariances) read whole 3x3x3 cubes: they want only a few points per cell
+  // k-nearest-neighbour searches (GICP covariances) read whole 3x3x3 cubes: they want cells for their own population (ensure_covariances)
   if (!again && attempt == 0 && b.knn_population > 0.0 && binned > 0 && (pop > 2.0 * b.knn_population || pop < 0.5 * b.knn_population)) {
     // ... in both directions: over a sparse (voxel-filtered) cloud the 20 neighbours lie ~2.5 point spacings away, and
     // cells that small make the search restart with cubes of 25 and 81 rows (22k-point cloud: 0.60 -> 0.35 ms)
@@ -256,7 +256,7 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
     G.built = false;
     return ICPGPU_OK;
   }
-  // GICP: the grid the target's covariances were computed over (cells for ~8 points: ensure_covariances) serves the
+  // GICP: the grid the target's covariances were computed over (cells for a population of ~32: ensure_covariances) serves the
   // correspondence search as well.  The keys are exact whatever the cells are and nothing downstream of them depends on the
   // cell size, so the results are the same bits -- and the per-scan pipeline builds ONE index per cloud instead of two (the
   // second one cost 0.15 ms per scan: a bounding box and up to three count passes, each a host round trip).  The grids change
