@@ -16,7 +16,7 @@ echo "## ICPGPU_MAILBOX=release scripts/align_campaign.py 4000 4040 (the release
 ICPGPU_MAILBOX=release timeout 1200 python scripts/align_campaign.py 4000 4040 2>&1 | grep -v amdgpu.ids | tail -2
 echo "## scripts/voxel_campaign.py 1000  (direct path)"
 timeout 2400 python scripts/voxel_campaign.py 1000 2>&1 | grep -v amdgpu.ids | tail -1
-echo "## scripts/pipeline_campaign.py 100 160 (the reference's per-scan pipeline on random raw scans, bit for bit)"
-timeout 1200 python scripts/pipeline_campaign.py 100 160 2>&1 | grep -v amdgpu.ids | tail -2
+echo "## scripts/pipeline_campaign.py 100 300 (the reference's per-scan pipeline on random raw scans, bit for bit)"
+timeout 1200 python scripts/pipeline_campaign.py 100 300 2>&1 | grep -v amdgpu.ids | tail -2
 } > $O/campaigns.txt 2>&1
 cat $O/campaigns.txt

@@ -22,3 +22,4 @@ python scripts/configs_timing.py > $O/configs.txt 2>&1; grep "^C" $O/configs.txt
 { timeout 120 scripts/probes/solve_probe_dev 22000 5; timeout 100 scripts/probes/solve_probe_dev 5000 3; timeout 100 scripts/probes/solve_probe_dev 200000 1; } > $O/solve_probe.txt 2>&1; grep -A1 "rep 2\|rep 5" $O/solve_probe.txt | head -12
 timeout 100 scripts/probes/granule_probe 200 > $O/granule_probe.txt 2>&1; tail -4 $O/granule_probe.txt
 python scripts/host_scaling_probe.py 2>&1 | grep -v amdgpu.ids > $O/host_scaling.txt; tail -3 $O/host_scaling.txt
+{ ICPGPU_FLAVOUR=dev ICPGPU_GICP_TIMING=1 python scripts/pipeline_breakdown.py 43 2>&1 | grep -v "amdgpu.ids"; } > $O/stages.txt 2>&1; grep "scans of\|host wall per align" $O/stages.txt | cut -c1-300
