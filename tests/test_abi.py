@@ -130,6 +130,40 @@ def test_fingerprint_is_a_content_hash(built):
     assert fp(np.zeros((0, 4), np.float32)) == fp(np.zeros((0, 4), np.float32))
 
 
+def test_fingerprint_equals_its_definition_at_every_length(built):
+    """The host fingerprint has a vector path (AVX-512 DQ where the CPU has it: four points per step, two steps per trip) in front
+    of the scalar loop: the number must be the DEFINITION's -- sum over the points of mix(w0 + K1 (2i + 1)) + mix(w1 ^ K2 (2i + 2)),
+    plus mix(n ^ 0xa5..) -- at every length around the vector loop's trip sizes (the device kernel computes the same sum:
+    tests/test_gpu_recognition.py)."""
+    import ctypes as C
+    lib = _lib.load()
+    M = (1 << 64) - 1
+
+    def mix(x):
+        x ^= x >> 30
+        x = (x * 0xbf58476d1ce4e5b9) & M
+        x ^= x >> 27
+        x = (x * 0x94d049bb133111eb) & M
+        return x ^ (x >> 31)
+
+    def definition(a):
+        s = 0
+        for i, (w0, w1) in enumerate(a.view(np.uint64).reshape(-1, 2).tolist()):
+            s = (s + mix((w0 + 0x9e3779b97f4a7c15 * (2 * i + 1)) & M) + mix(w1 ^ ((0xd6e8feb86659fd93 * (2 * i + 2)) & M))) & M
+        return (s + mix(a.shape[0] ^ 0xa5a5a5a5a5a5a5a5)) & M
+
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 3, 8, 63, 64, 65, 71, 72, 73, 127, 128, 1001, 4099):
+        a = rng.normal(size=(n, 4)).astype(np.float32)
+        a.view(np.uint32)[:: 7] ^= 0x80000000  # sign bits, and ...
+        if n > 3:
+            a[3] = [np.nan, np.inf, -0.0, 1.0]  # ... bit patterns that are not numbers
+        assert lib.icpgpu_fingerprint(a.ctypes.data_as(C.POINTER(C.c_float)), n) == definition(a), n
+        b = np.empty((n + 1, 4), np.float32)[1:]  # (only 16-byte aligned)
+        b[...] = a
+        assert lib.icpgpu_fingerprint(b.ctypes.data_as(C.POINTER(C.c_float)), n) == definition(a), n
+
+
 def test_multi_gpu_entry_reports_codes_without_a_gpu(built):
     """icpgpu_align_batch_multi (one process, one host thread per device): argument errors are status codes with a message, and
     without a usable device the call fails like icpgpu_create does -- no fallback, no abort."""
