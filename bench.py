@@ -166,7 +166,8 @@ def shim_pipeline(scan_a, scan_b, leaf: float, iters: int, n_scans: int = 24, th
                     out[key] = None
                     out["error"] = r.stderr.strip()[-300:]
                     continue
-                out[key] = float(r.stdout.strip().splitlines()[-1].split()[6])
+                timing = [l for l in r.stdout.splitlines() if l.startswith("TIMING ")][-1]
+                out[key] = float(timing.split()[6])
             out["scans"] = n_scans - 4
             out["threads"] = threads
     except Exception as e:  # the headline must not die with a secondary figure

@@ -54,6 +54,10 @@ struct IcpOdometer {
   float voxel_leaf_size_ = 0.2f;                                                           // config/icpslam.yaml:14
   Cloud::Ptr prev_cloud_{new Cloud()}, curr_cloud_{new Cloud()};
   std::vector<std::string> lines;
+  // ICPGPU_DEMO_TIMING=1: wall time per stage of the callback, summed (printed as a STAGES line behind TIMING)
+  double stage_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int stage_n = 0;
+  bool stage_timing = std::getenv("ICPGPU_DEMO_TIMING") != nullptr;
 
   void voxelFilterCloud(Cloud::Ptr* input, Cloud::Ptr* output) {  // icp_odometer.cpp:96-101
     icpgpu::VoxelGrid<Cloud> voxel_filter;                        // was: pcl::VoxelGrid<pcl::PointXYZ>
@@ -64,7 +68,15 @@ struct IcpOdometer {
 
   void laserCloudCallback(int k, Cloud::Ptr cloud_msg) {  // icp_odometer.cpp:147-220 (ROS / tf parts left out)
     Cloud::Ptr input_cloud = cloud_msg;  // pcl::fromROSMsg(*cloud_msg, *input_cloud): the message conversion is the caller's, not timed here
+    auto t_mark = std::chrono::steady_clock::now();
+    auto mark = [&](int stage) {
+      if (!stage_timing || k < 4) return;  // (the first callbacks create the contexts and size every buffer)
+      const auto now = std::chrono::steady_clock::now();
+      stage_us[stage] += std::chrono::duration<double, std::micro>(now - t_mark).count();
+      t_mark = now;
+    };
     voxelFilterCloud(&input_cloud, &curr_cloud_);
+    mark(0);
     if (prev_cloud_->points.size() == 0) {
       *prev_cloud_ = *curr_cloud_;
       return;
@@ -74,18 +86,24 @@ struct IcpOdometer {
     icp.setTransformationEpsilon(ICP_EPSILON);
     icp.setMaxCorrespondenceDistance(ICP_MAX_CORR_DIST);
     icp.setRANSACIterations(0);
+    mark(1);
     icp.setInputSource(curr_cloud_);
     icp.setInputTarget(prev_cloud_);
+    mark(2);
     Cloud::Ptr curr_cloud_in_prev_frame(new Cloud());
     icp.align(*curr_cloud_in_prev_frame);
+    mark(3);
     const auto T = icp.getFinalTransformation();
     const bool conv = icp.hasConverged();
     const double fit = conv ? icp.getFitnessScore() : -1.0;
+    mark(4);
     char buf[640];
     int o = std::snprintf(buf, sizeof buf, "%d %d %d %.17g %zu", k, conv ? 1 : 0, icp.getResult().iterations, fit, curr_cloud_->points.size());
     for (int i = 0; i < 16; ++i) o += std::snprintf(buf + o, sizeof buf - o, " %.9g", T.data()[i]);
     lines.emplace_back(buf);
     if (conv && fit < 20) *prev_cloud_ = *curr_cloud_;            // :201-210 (updateICPOdometry always succeeds here)
+    mark(5);
+    stage_n += k >= 4 ? 1 : 0;
   }
 };
 
@@ -139,5 +157,11 @@ int main(int argc, char** argv) {
   const int timed = n_scans - warmup;
   std::printf("TIMING scans %d seconds %.6f scans_per_sec %.3f warmup %d threads %d\n", timed, secs, timed > 0 && secs > 0 ? timed / secs : 0.0,
               warmup, n_threads);
+  if (odo.stage_timing) icpgpu::release_cached_contexts();  // (the development library prints its own stage timers when a context ends)
+  if (odo.stage_timing && odo.stage_n)
+    std::printf("STAGES us per callback (%d callbacks, the first four left out): VoxelGrid::filter %.1f | object + setters %.1f | setInputSource + setInputTarget (calls deferred to align) %.1f | "
+                "align %.1f | getFinalTransformation + hasConverged + getFitnessScore %.1f | result line + *prev = *curr %.1f\n",
+                odo.stage_n, odo.stage_us[0] / odo.stage_n, odo.stage_us[1] / odo.stage_n, odo.stage_us[2] / odo.stage_n, odo.stage_us[3] / odo.stage_n,
+                odo.stage_us[4] / odo.stage_n, odo.stage_us[5] / odo.stage_n);
   return 0;
 }
