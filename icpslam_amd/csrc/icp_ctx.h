@@ -207,6 +207,7 @@ struct icpgpu_ctx {
   uint64_t src_version = 1;  // bumped whenever the source cloud changes
   // GICP mode: grids used for the 20-NN covariances, per-point covariances (6 doubles), Mahalanobis matrices
   GridIndex cov_grid_src, cov_grid_tgt;
+  bool cov_timing_pending = false;  // ev[2] .. ev[3] bracket a covariance pass whose duration has not been read yet (resolve_cov_timing)
   double cov_h_hint = 0.0, cov_h_hint_cut = 0.0;  // the cell size the last covariance grid settled on (ensure_covariances)
   DeviceBuf cov_src, cov_tgt, maha;
   uint64_t cov_src_version = 0, cov_tgt_version = 0;
@@ -389,6 +390,7 @@ int source_in_morton_order(icpgpu_ctx* c);
 // icpgpu_p2p.cpp
 int nn_keys_brute(icpgpu_ctx* c, const float4* tgt_pts, int n_t, const Xform& T, unsigned long long* keys, bool* used_mfma = nullptr);
 int resolve_sweep_timings(icpgpu_ctx* c, bool block = true);
+int resolve_cov_timing(icpgpu_ctx* c);  // icpgpu_gicp.cpp
 double wait_timeout_ms();
 bool flags_ready(const volatile unsigned long long* pairs, int n_pairs, unsigned long long seq);
 void take_sums(icpgpu_ctx* c);

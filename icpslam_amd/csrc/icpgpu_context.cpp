@@ -631,6 +631,7 @@ extern "C" {
 int icpgpu_profile_reset(icpgpu_ctx* c) {
   if (!c) return ICPGPU_ERR_INVALID_ARG;
   (void)resolve_sweep_timings(c);
+  (void)resolve_cov_timing(c);
   std::memset(&c->prof, 0, sizeof(c->prof));
   return ICPGPU_OK;
 }
@@ -650,6 +651,7 @@ int icpgpu_profile_get(icpgpu_ctx* c, icpgpu_profile* out) {
   if (!c || !out) return ICPGPU_ERR_INVALID_ARG;
   int rc = resolve_sweep_timings(c);
   if (rc) return rc;
+  if ((rc = resolve_cov_timing(c))) return rc;
   *out = c->prof;
   return ICPGPU_OK;
 }
