@@ -310,3 +310,41 @@ def test_filtered_scans_covariances_do_not_depend_on_the_box_or_the_cells_they_s
         fresh.set_params(fresh.default_params(), method=GICP)
         fresh.set_source(filt)
         assert np.array_equal(fresh.gicp_covariances(), got)
+
+
+def test_adopted_grid_never_outlives_its_conditions(ctx):
+    """GICP's correspondence search adopts the grid the target's covariances were computed over (icpgpu_index.cpp: ensure_grid).
+    One context, one pair of clouds, a sequence of parameter changes that must each drop or keep that grid correctly: a wider
+    gate than the grid was sized for, the point-to-point method (its cell-ordered source must never meet an adopted grid), GICP
+    again, a narrower gate, a new target.  Every result equals the one a fresh context gives for the same call -- bit for bit."""
+    from icpslam_amd import P2P_SVD
+    src, tgt, _ = synth.make_pair(30000, 30000, seed=41)
+    other, _, _ = synth.make_pair(30000, 10, seed=42)
+    steps = [dict(method=GICP, max_correspondence_distance=1.0), dict(method=GICP, max_correspondence_distance=2.5),
+             dict(method=P2P_SVD, max_correspondence_distance=2.5), dict(method=GICP, max_correspondence_distance=2.5),
+             dict(method=GICP, max_correspondence_distance=0.6), dict(method=P2P_SVD, max_correspondence_distance=1.0),
+             dict(method=GICP, max_correspondence_distance=1.0, new_target=True)]
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    adopted = []
+    for st in steps:
+        st = dict(st)
+        if st.pop("new_target", False):
+            ctx.set_target(other)
+            tg = other
+        else:
+            tg = tgt
+        ctx.set_params(ctx.default_params(), max_iterations=6, **st)
+        got = ctx.align(want_fitness=True)
+        adopted.append(int(ctx.profile().grid_adopted))
+        with type(ctx)(0) as fresh:
+            fresh.set_params(fresh.default_params(), max_iterations=6, **st)
+            fresh.set_source(src)
+            fresh.set_target(tg)
+            ref = fresh.align(want_fitness=True)
+        assert np.array_equal(got["T"], ref["T"]) and got["iterations"] == ref["iterations"] and got["n_corr"] == ref["n_corr"], st
+        assert got["fitness"] == ref["fitness"], st
+    # adopted for the first GICP call, not again for the wider gate (the covariance grid was sized for 1.0 m; a grid of its own is
+    # built), nor by point-to-point; the narrower gate and the new target adopt again
+    assert adopted[0] == 1 and adopted[1] == 1 and adopted[2] == 1, adopted
+    assert adopted[-1] > adopted[2], adopted
