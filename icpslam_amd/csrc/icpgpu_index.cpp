@@ -269,6 +269,9 @@ int ensure_grid(icpgpu_ctx* c, float accept_thr) {
   }
   if (gicp && !(G.built && G.version == c->tgt_version && G.cutoff == (float)cut)) {
     GridIndex& V = c->cov_grid_tgt;
+    if (std::getenv("ICPGPU_DEBUG"))
+      fprintf(stderr, "[icpgpu] ensure_grid (GICP): covariance grid built %d usable %d version %llu (target %llu, covariances %llu) cut %.3f thr %.6f\n",
+              (int)V.built, (int)V.usable, (unsigned long long)V.version, (unsigned long long)c->tgt_version, (unsigned long long)c->cov_tgt_version, V.cut_d, (double)accept_thr);
     if (V.built && V.usable && V.version == c->tgt_version && c->cov_tgt_version == c->tgt_version && c->cov_tgt.ptr &&
         (double)accept_thr <= V.cut_d * V.cut_d) {
       std::swap(G, V);
