@@ -166,14 +166,20 @@ using namespace icpgpu_impl;
 
 constexpr size_t kMaxServerWorkers = 8;
 
-// ICPGPU_GICP_DEVICE=1: GICP's inner BFGS runs inside a resident kernel (icp_gicp.hip: gicp_solve_kernel) instead of on the host
-// over the evaluation server.  Same bits either way (tests/test_gpu_gicp.py); OFF by default because it is not faster: an
-// evaluation takes 7.4-8.1 us in the kernel against 7.0-7.6 us through the host loop -- what
-// it buys is a host thread that waits once per outer iteration instead of once per evaluation.
-inline bool gicp_device_solver_enabled() {
-  static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_DEVICE"); return e && std::atoi(e) != 0; }();
+// ICPGPU_GICP_DEVICE: where GICP's inner BFGS runs -- 0: on the host over the evaluation server; 1: inside a resident kernel
+// (icp_gicp.hip: gicp_solve_kernel); unset or "auto": MEASURED per context.  Same bits either way (tests/test_gpu_gicp.py,
+// 1 200 campaign registrations through both).  Which one is faster depends on the box: the host loop's evaluation is 6.8-8.3 us
+// with the box's PCIe and CPU, the kernel's 7.2-7.7 us wherever it runs -- so a context times a few
+// outer iterations each way (align_gicp) and keeps the faster; runs the one-XCD variant cannot take stay on the host.
+inline int gicp_device_solver_mode() {  // 0 host, 1 device, 2 measured
+  static const int v = [] {
+    const char* e = std::getenv("ICPGPU_GICP_DEVICE");
+    if (!e || std::strcmp(e, "auto") == 0) return 2;
+    return std::atoi(e) != 0 ? 1 : 0;
+  }();
   return v;
 }
+inline bool gicp_device_solver_enabled() { return gicp_device_solver_mode() != 0; }  // (its buffers are allocated with the context)
 inline bool gicp_server_enabled() {  // ICPGPU_GICP_SERVER=0: every GICP evaluation is its own launch
 #if defined(__x86_64__)
   static const bool v = [] { const char* e = std::getenv("ICPGPU_GICP_SERVER"); return !e || std::atoi(e) != 0; }();
@@ -234,6 +240,12 @@ struct icpgpu_ctx {
   unsigned long long* h_solve_dev = nullptr;
   unsigned long long gicp_solve_seq = 0;
   bool gicp_device_ok = false;
+  // measured mode: 0 = still timing both solvers, 1 = host, 2 = device; microseconds and evaluations of the timed inner
+  // minimisations, [0] host [1] device (the first run of each is a warm-up and not counted)
+  int gicp_choice = 0;
+  double gicp_cal_us[2] = {0.0, 0.0};
+  unsigned long long gicp_cal_evals[2] = {0, 0};
+  unsigned int gicp_cal_runs[2] = {0, 0};
   // ... its one-XCD variant: granule slots in ordinary device memory (the XCD's L2 is the medium), the worker claims, the XCD
   unsigned long long* gicp_slots_local = nullptr;
   unsigned long long* gicp_owner = nullptr;

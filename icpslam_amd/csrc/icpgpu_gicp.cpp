@@ -424,8 +424,25 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     };
     // rigid_transformation_estimation_: the whole BFGS run on the device (gicp_solve_kernel), one result for the host to poll
     Vec6 x = gicp_state_from_matrix(transformation);
-    bool solved = false;
-    for (int attempt = 0; attempt < 2 && !solved && c->gicp_device_ok && c->gicp_server_allowed; ++attempt) {
+    bool solved = false, leave_outer_loop = false;
+    // which solver: forced by ICPGPU_GICP_DEVICE, or (default) the one this context has measured to be faster on this box --
+    // until it knows, inner minimisations alternate and are timed (same bits either way, so nothing but time depends on it)
+    bool try_device = c->gicp_device_ok && c->gicp_server_allowed;
+    bool timing_this_run = false;
+    if (try_device && gicp_device_solver_mode() == 2) {
+      const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
+      const bool fits_one_xcd = c->gicp_local_ok && nblk <= gicp_solve_local_blocks() && (long long)nblk * 1024 >= n_s && 8 * nblk <= c->gicp_blocks_most;
+      if (!fits_one_xcd) try_device = false;  // (streamed shares, 13 us gathers: the device solver is 30 % slower there)
+      else if (c->gicp_choice == 0) {
+        timing_this_run = true;
+        try_device = c->gicp_cal_runs[1] <= c->gicp_cal_runs[0];  // the one that has run less
+      } else {
+        try_device = c->gicp_choice == 2;
+      }
+    }
+    const auto t_inner0 = std::chrono::steady_clock::now();
+    const uint64_t evals_before = c->prof.gicp_cost_launches;
+    for (int attempt = 0; attempt < 2 && !solved && try_device && c->gicp_device_ok && c->gicp_server_allowed; ++attempt) {
       const auto t_solve0 = std::chrono::steady_clock::now();
       const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
       // the one-XCD variant when the run fits one XCD's 32 CUs with its correspondences in registers (the reference's
@@ -461,15 +478,20 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         std::memcpy(previous, transformation, sizeof(previous));
         if (status == gicp::kNotEnoughPoints) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
           state = ICPGPU_CONV_NO_CORRESPONDENCES;
+          leave_outer_loop = true;
           break;
         }
         if (status != gicp::kOk) {  // SolverDidntConvergeException
           state = ICPGPU_NOT_CONVERGED;
+          leave_outer_loop = true;
           break;
         }
         for (int k = 0; k < 6; ++k) x[k] = out[1 + k];
       }
     }
+    if (leave_outer_loop) break;  // (the two exits above leave the attempt loop only: until round 4's last day the outer loop went on
+                                  //  and reported a converged alignment with the unchanged transform -- found when the device
+                                  //  solver became part of the default path; tests/test_gpu_gicp.py now runs the degenerate cases through it)
     if (!solved) {
       // the ~35 dependent evaluations of this outer iteration go to a resident kernel (queued behind the two kernels above)
       if ((rc = gicp_server_start(c, n_s, keys, thr_excl, base, maha))) return rc;
@@ -492,6 +514,22 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
         state = ICPGPU_NOT_CONVERGED;
         break;
+      }
+    }
+    if (timing_this_run) {
+      const int which = solved ? 1 : 0;
+      if (c->gicp_cal_runs[which]++ > 0) {  // (a solver's first run pays for code upload and first-touch: not counted)
+        c->gicp_cal_us[which] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_inner0).count();
+        c->gicp_cal_evals[which] += c->prof.gicp_cost_launches - evals_before;
+      }
+      if (!c->gicp_device_ok || (!c->gicp_local_ok && !solved)) {
+        c->gicp_choice = 1;  // the device solver gave up on this context
+      } else if (c->gicp_cal_evals[0] >= 150 && c->gicp_cal_evals[1] >= 150) {
+        const double host_us = c->gicp_cal_us[0] / (double)c->gicp_cal_evals[0], dev_us = c->gicp_cal_us[1] / (double)c->gicp_cal_evals[1];
+        c->gicp_choice = dev_us < 0.97 * host_us ? 2 : 1;  // (the host loop on a tie: it is the simpler machine)
+        if (std::getenv("ICPGPU_DEBUG"))
+          fprintf(stderr, "[icpgpu] GICP inner solver measured on this context: host loop %.2f us, device solver %.2f us per evaluation -> %s\n", host_us,
+                  dev_us, c->gicp_choice == 2 ? "device solver" : "host loop");
       }
     }
     mat4f_identity(transformation);

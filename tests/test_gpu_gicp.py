@@ -223,8 +223,9 @@ def test_gicp_server_variants_agree_bit_for_bit(tmp_path):
 
 def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path):
     """Round 4: the whole inner BFGS of an outer iteration runs inside gicp_solve_kernel (icp_gicp.hip) -- the profile says so,
-    one device solve per outer iteration (ICPGPU_GICP_DEVICE=1; off by default: it is not faster) -- and the default
-    path (the host's solver over the evaluation server, same source: icp_gicp_solver_impl.h) returns the same bits: transform, iterations, correspondences, fitness.  Sizes: one workgroup,
+    one device solve per outer iteration (ICPGPU_GICP_DEVICE=1; by default a context measures both solvers and keeps the faster,
+    DESIGN.md 9-f1) -- and the host
+    path (ICPGPU_GICP_DEVICE=0: the host's solver over the evaluation server, same source: icp_gicp_solver_impl.h) returns the same bits: transform, iterations, correspondences, fitness.  Sizes: one workgroup,
     several workgroups with the correspondences resident in registers, and the streaming variant (more than 64 x 1024)."""
     import os
     import subprocess
@@ -245,13 +246,31 @@ def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path
         "        out['T%d' % n] = r['T']\n"
         "        out['m%d' % n] = np.array([r['iterations'], r['n_corr'], r['converged'], p.gicp_device_solves, p.gicp_cost_launches], np.float64)\n"
         "        out['f%d' % n] = np.array([r['mse'], r['fitness']])\n"
+        "    # the two exits of PCL's loop that are not convergence: no correspondence within the gate, a cloud below 20 points\n"
+        "    src, tgt, _ = synth.make_known_answer_pair(6000, seed=33)\n"
+        "    far = src.copy(); far[:, 0] += 500\n"
+        "    ctx.set_source(far); ctx.set_target(tgt)\n"
+        "    r = ctx.align()\n"
+        "    out['far'] = np.array([r['converged'], r['n_corr'], r['iterations'], r['state']], np.float64); out['farT'] = r['T']\n"
+        "    ctx.set_source(src[:10])\n"
+        "    r = ctx.align()\n"
+        "    out['few'] = np.array([r['converged'], r['n_corr'], r['iterations'], r['state']], np.float64); out['fewT'] = r['T']\n"
         "np.savez(sys.argv[1], **out)\n")
     res = {}
-    for name, env in (("device", {"ICPGPU_GICP_DEVICE": "1"}), ("host", {"ICPGPU_GICP_DEVICE": "0"})):
+    for name, env in (("device", {"ICPGPU_GICP_DEVICE": "1"}), ("host", {"ICPGPU_GICP_DEVICE": "0"}), ("measured", {"ICPGPU_GICP_DEVICE": "auto"})):
         e = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), **env)
         path = str(tmp_path / (name + ".npz"))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=e, timeout=300)
         res[name] = dict(np.load(path))
+    for name in ("device", "measured"):  # the exits that are not convergence look the same whoever solves
+        for key in ("far", "farT", "few", "fewT"):
+            assert np.array_equal(res[name][key], res["host"][key]), (name, key, res[name][key], res["host"][key])
+    assert res["host"]["far"][0] == 0 and res["host"]["far"][1] == 0 and res["host"]["few"][0] == 0
+    for n in (900, 9000, 30000, 90000):  # the default mode (a context measures both solvers and keeps the faster): the same bits
+        a, h = res["measured"], res["host"]
+        assert np.array_equal(a["T%d" % n].view(np.uint32), h["T%d" % n].view(np.uint32)), n
+        assert np.array_equal(a["m%d" % n][:3], h["m%d" % n][:3]) and a["m%d" % n][4] == h["m%d" % n][4] and a["f%d" % n][1] == h["f%d" % n][1], n
+    assert sum(res["measured"]["m%d" % n][3] for n in (900, 9000, 30000)) >= 1  # ... and it did try the device solver
     for n in (900, 9000, 30000, 90000):
         d, h = res["device"], res["host"]
         assert d["m%d" % n][3] == d["m%d" % n][0] >= 1, n          # one device solve per outer iteration
