@@ -316,7 +316,10 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         R.m[3 * r + cc] = s;
       }
     // correspondences: exact NN keys (only those with d2 < r^2 are used, so the grid's cutoff search is complete)
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    // (timed like the point-to-point sweeps: one outer iteration in `timing_every` -- two event records are barrier packets in
+    //  front of and behind the search, a few microseconds of every outer iteration when each is timed)
+    const bool timed = c->timing_every <= 1 || (c->sweep_counter++ % (unsigned)c->timing_every) == 0;
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (grid_ready(c)) {
       float4* prev = nullptr;  // each outer iteration's neighbours bound the next one's search
       bool use_prev = false;
@@ -330,7 +333,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     }
     HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
                                        static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     mark(2);
 
     // rigid_transformation_estimation_: BFGS over x = (t, roll, pitch, yaw), every evaluation one reduction on the device
@@ -535,10 +538,11 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     mat4f_identity(transformation);
     gicp_apply_state(transformation, x);
     float ms = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    if (timed) HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     dev_ms += ms;
     c->prof.grid_launches += grid_ready(c) ? 1 : 0;
     c->prof.grid_ms += grid_ready(c) ? ms : 0.0;
+    c->prof.grid_timed += (timed && grid_ready(c)) ? 1 : 0;
     mark(6);
     double delta = 0.0;
     for (int k = 0; k < 4; ++k)

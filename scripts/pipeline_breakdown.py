@@ -31,4 +31,4 @@ with Context(0) as ctx:
     p = ctx.profile(); m = n_scans - 3
     print(f"{m} scans of 200k -> ~{n} points: {wall/m*1e3:.2f} ms per scan = {m/wall:.0f} scans/s; outer iterations {its/m:.1f}, cost evaluations {p.gicp_cost_launches/m:.0f} per scan")
     print(f"  host wall per scan: H2D + bbox + voxel filter {t['filter']/m*1e3:.3f} ms | align (GICP + fitness) {t['align']/m*1e3:.3f} ms | promote {t['promote']/m*1e3:.3f} ms")
-    print(f"  device counters per scan: voxel {p.voxel_ms/m*1e3:.0f} us | covariances {p.gicp_cov_ms/m*1e3:.0f} us ({p.gicp_cov_launches/m:.1f} clouds) | correspondence search + Mahalanobis kernels {p.grid_ms/m*1e3:.0f} us ({p.grid_launches/m:.1f} outer iterations' worth + the fitness sweep)")
+    print(f"  device counters per scan: voxel {p.voxel_ms/m*1e3:.0f} us | covariances {p.gicp_cov_ms/m*1e3:.0f} us ({p.gicp_cov_launches/m:.1f} clouds) | correspondence search + Mahalanobis kernels {p.grid_ms*p.grid_launches/max(p.grid_timed,1)/m*1e3:.0f} us ({p.grid_launches/m:.1f} outer iterations' worth + the fitness sweep; {p.grid_timed} of {p.grid_launches} timed)")
