@@ -276,6 +276,9 @@ struct icpgpu_ctx {
   int timing_every = 13;      // time one sweep in 13 (coprime with the 10 / 30 iterations of the reference's aligns; 7 until round 2: an event triple costs 6-7 us)
   unsigned sweep_counter = 0;
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
+  volatile unsigned long long* h_post = nullptr;  // mapped, coherent: 32 result pairs for fetch_ints (icpgpu_context.cpp)
+  unsigned long long* h_post_dev = nullptr;
+  unsigned long long post_seq = 0;
   bool have_final = false;
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
@@ -327,6 +330,7 @@ struct GridBuild {
   GridIndex* G = nullptr;
   const int* orig_index = nullptr;
   double knn_population = 0.0;
+  bool post = false;        // build_grid: the read-backs go through fetch_ints (the batch scheduler copies and synchronises its groups itself)
   bool box_cached = false;  // the bounding box came from the cloud's cache (a CONTAINING box: gb_on_count checks that every point was binned)
   double h_start = 0.0;  // > 0: the first count pass uses this cell size instead of cut / 4.5 (k-NN grids only: see ensure_covariances)
   double h = 0.0;
@@ -377,6 +381,9 @@ void release(DeviceBuf& b);
 Xform to_xform(const Mat4d& T);
 Xform to_xform(const float* T);
 float threshold_from(double r2);
+// n <= 32 ints from device memory, queued behind everything the stream holds, into host_dst -- returns when they are there
+// (a posted kernel + a polled mailbox instead of hipMemcpyAsync + hipStreamSynchronize: icp_kernels.hip post_ints_kernel)
+int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst);
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
 int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
 int promote_internal(icpgpu_ctx* c);

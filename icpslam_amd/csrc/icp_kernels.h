@@ -103,6 +103,8 @@ hipError_t launch_reduce(const float4* src, int n_s, const float4* tgt, const un
 // sees a sum without its number; sums_out is then left alone.  Without flags the sums go to sums_out (device memory).
 // term_major: partials are laid out [term][block] (what launch_nn_grid_search writes) instead of [block][term].
 hipError_t launch_mailbox_selftest(unsigned long long* pair_dev, int rounds, hipStream_t stream);
+// n <= 32 ints of device memory as result pairs {value, tag(number)} into mapped host memory (the host polls them)
+hipError_t launch_post_ints(const int* d_src, int n, unsigned long long* pairs_dev, unsigned long long number, hipStream_t stream);
 hipError_t launch_reduce_final(const double* partials, int n_blocks, bool term_major, double* sums_out,
                                unsigned long long* flags, unsigned long long seq, hipStream_t stream);
 

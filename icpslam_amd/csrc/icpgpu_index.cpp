@@ -32,7 +32,9 @@ static int gb_with_bbox(icpgpu_ctx* c, GridBuild& b, const int enc[6], bool cach
 // queue the bounding box (or find the grid already built)
 int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
              const int* orig_index, double knn_population, double h_start) {
+  const bool post = b.post;  // (set by build_grid before the call)
   b = GridBuild{};
+  b.post = post;
   b.h_start = h_start;
   b.cloud = &cloud;
   b.version = version;
@@ -55,7 +57,7 @@ int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, 
   b.t0 = std::chrono::steady_clock::now();
   if (version != 0 && cloud.bbox_version == version) return gb_with_bbox(c, b, cloud.bbox_enc, !cloud.bbox_exact);  // a containing box is known: no pass, no round trip
   HIP_TRY(c, launch_bbox(cloud.data(), (int)cloud.n, d_ints, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (!b.post) HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   b.state = GridBuild::WaitBbox;
   return ICPGPU_OK;
 }
@@ -147,7 +149,7 @@ int gb_issue_count(icpgpu_ctx* c, GridBuild& b) {
   if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
   HIP_TRY(c, launch_grid_count(b.cloud->data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
                                static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, kGridStatInts * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  if (!b.post) HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, kGridStatInts * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   b.state = GridBuild::WaitCount;
   return ICPGPU_OK;
 }
@@ -168,7 +170,7 @@ int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
     b.cloud->bbox_version = 0;
     b.box_cached = false;
     HIP_TRY(c, launch_bbox(b.cloud->data(), n_t, d_ints, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (!b.post) HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     b.state = GridBuild::WaitBbox;
     return ICPGPU_OK;
   }
@@ -237,10 +239,15 @@ int gb_advance(icpgpu_ctx* c, GridBuild& b) {
 int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
                const int* orig_index, double knn_population, double h_start) {
   GridBuild b;
+  b.post = true;
   int rc = gb_begin(c, b, cloud, version, cut, adapt, G, orig_index, knn_population, h_start);
   while (!rc && b.state != GridBuild::Done) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    rc = gb_advance(c, b);
+    // the six box words or the occupancy statistics: a posted kernel + a polled mailbox (10 us) instead of a copy + a stream
+    // synchronisation (16 us); gb_on_bbox / gb_on_count read them from c->h_ints as before
+    const int* d_ints = static_cast<const int*>(G.ints.ptr);
+    if (b.state == GridBuild::WaitBbox) rc = fetch_ints(c, d_ints, 6, c->h_ints);
+    else rc = fetch_ints(c, d_ints + 6, kGridStatInts, c->h_ints + 6);
+    if (!rc) rc = gb_advance(c, b);
   }
   return rc;
 }

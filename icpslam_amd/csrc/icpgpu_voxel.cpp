@@ -18,8 +18,7 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   if (rc) return rc;
   int* d_ints = static_cast<int*>(c->vox_ints.ptr);
   HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints, d_ints, 6 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = fetch_ints(c, d_ints, 6, c->h_ints))) return rc;
   float lo[3], hi[3];
   decode_bbox(c->h_ints, lo, hi);
   if (bbox_enc_out) std::memcpy(bbox_enc_out, c->h_ints, 6 * sizeof(int));  // the input's box: it contains every centroid
@@ -75,13 +74,19 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
       return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    hipError_t se = hipStreamSynchronize(c->stream);
-    if (se != hipSuccess) {
+    if ((rc = fetch_ints(c, d_ints + 6, 3, c->h_ints + 6))) {
       c->vox_bins_zeroed = nullptr;
-      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(se));
+      return rc;
     }
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    {  // (the events lie in front of the posted kernel: complete by now; should the runtime not have noticed yet, wait for the second)
+      hipError_t te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+      if (te == hipErrorNotReady) {
+        (void)hipGetLastError();
+        HIP_TRY(c, hipEventSynchronize(c->ev[1]));
+        te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+      }
+      HIP_TRY(c, te);
+    }
     done = c->h_ints[8] == 0;
   }
   if (!done) {
