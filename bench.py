@@ -489,8 +489,9 @@ def main():
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": ev_bytes / (ev_ms * 1e-3) / 1e9,
                     "frac": ev_bytes / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_evaluation_ms": ev_ms,
                     "evaluations": int(pg.gicp_cost_launches), "algorithmic_bytes_per_evaluation": ev_bytes,
+                    "outer_iterations_solved_on_the_device": int(pg.gicp_device_solves),
                     "note": "one BFGS function/gradient evaluation = 88 B per correspondence (16 B source point, 16 B target point, 48 B "
-                            "Mahalanobis matrix, 8 B key); time = host wall, command written -> 13 sums merged.  LATENCY-bound: the "
+                            "Mahalanobis matrix, 8 B key); time = host wall, command written -> 13 sums merged (outer iterations the context's measured choice gives to the device solver, gicp_solve_kernel, count with their wall time / their evaluations: profile.gicp_device_solves).  LATENCY-bound: the "
                             "evaluations are dependent host <-> device round trips of ~6.5 us around ~1.4 us of device work (scripts/"
                             "pipeline_breakdown.py with ICPGPU_GICP_TIMING=1); the server keeps its correspondences in registers, so "
                             "the algorithmic bytes are not even re-read"},
