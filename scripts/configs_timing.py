@@ -48,8 +48,10 @@ with Context(0) as ctx:
     g, g_worst = sorted(reps)[3], max(reps)
     its = sum(r["iterations"] for r in res)
     c, _ = t_ms(lambda: [oracle.icp_align(p[0], p[1], oracle.default_params(), want_fitness=True) for p in pairs[:4]])
+    later = reps[1:]  # (the first 64-pair batch sizes every worker's buffers: the warm-up above ran 8 pairs only)
     print(f"C4  64 pairs of 50k (1/8 of 512), <=10 it + fitness, host buffers in: GPU median of 7 batches {g:.1f} ms = {64e3/g:.0f} pairs/s, "
-          f"{its*1e3/g:.0f} it/s (slowest batch {g_worst:.1f} ms = {64e3/g_worst:.0f} pairs/s) | "
+          f"{its*1e3/g:.0f} it/s (slowest batch {g_worst:.1f} ms = {64e3/g_worst:.0f} pairs/s; the batches in order: "
+          f"{' '.join('%.1f' % t for t in reps)} ms -- after the first: slowest / median = {max(later)/sorted(later)[len(later)//2]:.2f}) | "
           f"CPU oracle {c/4:.0f} ms per pair = {4e3/c:.2f} pairs/s on 1 core", flush=True)
     # C5: one GPU's share (250 consecutive pairs) of the 2000-scan sequence, 50k points per scan
     n_scans = int(os.environ.get("C5_SCANS", "251"))
