@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ICPGPU_FLAVOUR=dev: the development flavour (libicpgpu_dev.so, built with -DICPGPU_DEV_SWITCHES: kernel variants, tuning
 # constants and test modes behind environment switches -- icpslam_amd/csrc/icp_env.h).  A process loads ONE flavour; the
-# tests of the development modes run in sub-processes (tests/test_gpu_dev_flavour.py).  Default: the release library.
+# tests of the development modes run in sub-processes (tests/conftest.py: the dev_flavour fixture).  Default: the release library.
 FLAVOUR = "dev" if os.environ.get("ICPGPU_FLAVOUR", "") == "dev" else "release"
 LIB_PATH = os.path.join(_HERE, "libicpgpu_dev.so" if FLAVOUR == "dev" else "libicpgpu.so")
 if os.environ.get("ICPGPU_LIB_PATH"):   # A/B builds of an experiment (scripts/): an explicit library file
@@ -49,7 +49,8 @@ class Profile(C.Structure):
                 ("grid_bounded", C.c_uint64), ("gicp_eval_ms", C.c_double), ("gicp_eval_corr", C.c_uint64), ("gicp_cov_points", C.c_uint64),
                 ("targets_recognised", C.c_uint64), ("brute_bound_violations", C.c_uint64),
                 ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64),
-                ("grid_adopted", C.c_uint64)]
+                ("grid_adopted", C.c_uint64), ("sources_adopted", C.c_uint64), ("gicp_host_solves", C.c_uint64),
+                ("gicp_solver_choice", C.c_uint64)]
 
 
 class Pose(C.Structure):

@@ -83,8 +83,9 @@ struct GridIndex {
   uint64_t serial = 0;       // unique per completed build (grids change hands between c->grid and c->src_grid)
 };
 
-// The neighbour every query found in the last grid sweep (nn_quad_kernel): an upper bound for the next sweep of the same
-// queries over the same target, whatever the transform (icp_grid.hip).  `valid` is cleared at the start of every
+// The neighbour every query found in the last grid sweep (nn_quad_kernel), as its position in the grid's sorted copy (4 bytes
+// per query): an upper bound for the next sweep of the same queries over the same build of the same grid, whatever the
+// transform (icp_grid.hip).  `valid` is cleared at the start of every
 // alignment, so an alignment never depends on the one before it.
 struct PrevNeighbours {
   DeviceBuf buf;
@@ -92,6 +93,7 @@ struct PrevNeighbours {
   const void* src = nullptr;     // query array the entries are indexed by
   const void* sorted = nullptr;  // grid they were found in
   int n = 0;
+  int n_binned = 0;              // points in that grid's sorted copy (the positions stay below 16 x this)
   uint64_t grid_version = 0, src_version = 0;
 };
 
@@ -286,6 +288,14 @@ struct icpgpu_ctx {
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
   DeviceBuf vox_bins, vox_pub;   // ... of the direct (no library sort) path: self-cleaning histogram + group ranges; published counts
   size_t vox_last_n = 0;         // points of the last icpgpu_voxel_grid result (still in vox_out)
+  // ... what icpgpu_set_source needs to recognise that result when the caller hands it back as a host buffer (the reference's
+  // voxelFilterCloud -> setInputSource sequence, icp_odometer.cpp:177,193): its content fingerprint (taken on the device while
+  // the fetch's copy is in flight), the fingerprint of its 256 sampled points (from the fetched host copy), and the raw scan's
+  // bounding box, which contains every centroid (what a grid build needs of the cloud before its count pass)
+  bool vox_fp_valid = false;
+  unsigned long long vox_fp = 0, vox_sample_fp = 0;
+  bool vox_box_valid = false;
+  int vox_box[6] = {0, 0, 0, 0, 0, 0};
   void* vox_bins_zeroed = nullptr;  // the allocation (address, size) whose histogram is known to be zero
   size_t vox_bins_zeroed_cap = 0;
   void* vox_pub_zeroed = nullptr;
@@ -384,6 +394,7 @@ float threshold_from(double r2);
 // n <= 32 ints from device memory, queued behind everything the stream holds, into host_dst -- returns when they are there
 // (a posted kernel + a polled mailbox instead of hipMemcpyAsync + hipStreamSynchronize: icp_kernels.hip post_ints_kernel)
 int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst);
+unsigned long long sample_fingerprint(const float* xyzw, size_t n);
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
 int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
 int promote_internal(icpgpu_ctx* c);
@@ -395,7 +406,7 @@ int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, 
                const int* orig_index = nullptr, double knn_population = 0.0, double h_start = 0.0);
 int ensure_grid(icpgpu_ctx* c, float accept_thr);
 int grid_flags(const GridIndex& G, bool src_in_cell_order);
-int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, float4*& buf, bool& use);
+int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, unsigned int*& buf, bool& use);
 int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t, const Xform& T,
                  unsigned long long* keys, int* deferred = nullptr);
 int complete_deferred_keys(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, const float4* tgt_pts, int n_t,

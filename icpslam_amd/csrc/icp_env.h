@@ -1,11 +1,13 @@
 // icp_env.h -- environment switches of libicpgpu.so, in two classes.
 //
-// PRODUCTION switches are read by every build (std::getenv directly, documented in include/icpgpu.h):
+// PRODUCTION switches are read by every build (std::getenv directly; the list in include/icpgpu.h, section "environment",
+// and INTEGRATION.md repeat this one):
 //   ICPGPU_WAIT_TIMEOUT_MS   deadline of every host wait for the device (mailbox, gather); default 30 000
 //   ICPGPU_BATCH_THREADS / ICPGPU_BATCH_DEPTH   host threads of icpgpu_align_batch and alignments each drives
-//   ICPGPU_RECOGNISE=0       icpgpu_set_target always uploads (no content recognition)
+//   ICPGPU_RECOGNISE=0       icpgpu_set_target / icpgpu_set_source always upload (no content recognition)
 //   ICPGPU_GICP_SERVER=0     every GICP cost evaluation is its own kernel launch (no resident server)
-//   ICPGPU_GICP_DEVICE=1     GICP's inner BFGS runs in the device solver (gicp_solve_kernel) instead of on the host (same bits)
+//   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the device solver gicp_solve_kernel (1), or whichever
+//                            the context measures to be faster (auto, the default) -- same bits either way
 //   ICPGPU_MAILBOX=pairs|release   how results reach the host (default: self-test at context creation picks it)
 //   ICPGPU_DEBUG=1           diagnostics on stderr
 //   LOCAL_WORLD_SIZE         (torch.distributed.run) processes sharing this host's CPUs

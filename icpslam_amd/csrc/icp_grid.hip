@@ -354,7 +354,7 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
                                              const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                              const GridDesc& g, float accept_thr, unsigned long long* __restrict__ keys,
                                              double* __restrict__ partials, int* __restrict__ unmatched,
-                                             int* __restrict__ unmatched_count, float4* __restrict__ prev_nn, int use_prev,
+                                             int* __restrict__ unmatched_count, unsigned int* __restrict__ prev_nn, int use_prev,
                                              int cube_start, unsigned long long* __restrict__ count_candidates, int n_blocks,
                                              int bx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,19 +381,23 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
   bool lfin = false;
   const int il = k0 + (lane >> 2) * stride;
   const bool lvalid = (lane >> 2) < qpw && il < n_s;
-  // Temporal coherence: prev_nn[i] holds the neighbour point i found in the previous sweep over the SAME target (NaN:
-  // none).  Whatever the transform is now, that point is a target point, so its distance bounds the new neighbour's:
-  // only the part of the octant inside that ball is read (near convergence: 1-2 cells of the 8).
+  // Temporal coherence: prev_nn[i] holds the POSITION (byte offset into `sorted`) of the neighbour point i found in the
+  // previous sweep over the SAME target (kNoPrev: none).  Whatever the transform is now, that point is a target point, so
+  // its distance bounds the new neighbour's: only the part of the octant inside that ball is read (near convergence: 1-2
+  // cells of the 8).  4 bytes per source point each way (a float4 of coordinates until round 5: 6.4 MB of the sweep's
+  // 27.5 MB of HBM traffic at 200k x 200k); the point itself comes from `sorted`, which the search is reading anyway.
+  const char* __restrict__ sorted_bytes = reinterpret_cast<const char*>(sorted);
   float lbound = __builtin_nanf("");
   if (lvalid) {
     const float4 s = src[il];
-    float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (use_prev & 1) pq = prev_nn[il];
+    unsigned int ppos = kNoPrev;
+    if (use_prev & 1) ppos = prev_nn[il];
     xform_point(T, s.x, s.y, s.z, lpx, lpy, lpz);
     lfin = finite3(lpx, lpy, lpz);
     if (lfin) {
       cell_of(g, lpx, lpy, lpz, lcx, lcy, lcz);
-      if (use_prev & 1) {
+      if (ppos != kNoPrev) {
+        const float4 pq = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)ppos);
         lbound = dist2(pq.x, pq.y, pq.z, lpx, lpy, lpz);  // the expression consider() uses: the same bits when it is met again
       }
       octant_row_in_ball(cell_start, g, lpx, lpy, lpz, lcx, lcy, lcz, lane & 3, ball_cells_sq(g, lbound), llo, llen, lmargin);
@@ -418,7 +422,6 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
     slot_of_rank = __builtin_amdgcn_ds_permute((4 * rank + (lane & 3)) << 2, lane >> 2);
   }
 
-  const char* __restrict__ sorted_bytes = reinterpret_cast<const char*>(sorted);
   for (int pass = 0; pass < n_pass; ++pass) {
     const int ql = 4 * lane_get_i(slot_of_rank, 4 * (4 * pass + (lane >> 4)));  // preamble lane (row 0) of this group's point
     const int qi_src = k0 + (ql >> 2) * stride;                                 // its index in the source cloud
@@ -463,13 +466,7 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
     const unsigned long long win = __ballot(dbits == dmin && idx == imin);  // >= 1 lane per row
     const int owner = grp_base + __ffs((unsigned int)(win >> grp_base) & 0xFFFFu) - 1;
     unsigned long long gkey = ((unsigned long long)dmin << 32) | imin;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (FUSE_REDUCE || prev_nn) {
-      const float4 w = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)(unsigned int)lane_get_i((int)bpos, owner));
-      qx = w.x;
-      qy = w.y;
-      qz = w.z;
-    }
+    unsigned int wpos = (unsigned int)lane_get_i((int)bpos, owner);  // where the winner sits (its coordinates are read after the cubes)
     bool found = fin && __uint_as_float(dmin) <= lane_get_f(lsafe_sq, ql);  // an empty row has dmin = NaN bits: false
 
     // not certified by the octant: the wave-wide cube search, one point at a time
@@ -481,18 +478,15 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
       const int cx = __builtin_amdgcn_readlane(lcx, sl), cy = __builtin_amdgcn_readlane(lcy, sl),
                 cz = __builtin_amdgcn_readlane(lcz, sl);
       // the octant's winner (if any) seeds the search: it bounds the ball the cubes have to cover ...
-      LaneBest c{((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(gkey >> 32), gl) << 32) |
-                     (unsigned int)__builtin_amdgcn_readlane((int)gkey, gl),
-                 readlane_f(qx, gl), readlane_f(qy, gl), readlane_f(qz, gl)};
+      LanePos c{((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(gkey >> 32), gl) << 32) |
+                    (unsigned int)__builtin_amdgcn_readlane((int)gkey, gl),
+                (unsigned int)__builtin_amdgcn_readlane((int)wpos, gl)};
       // ... unless last sweep's neighbour is closer (it may lie outside the octant).  It enters with the highest index:
       // the cubes meet the point itself again, same distance bits, and its real index wins the tie.
       const float pb = readlane_f(lbound, sl);
       if (pb < __builtin_inff() && !(__uint_as_float((unsigned int)(c.key >> 32)) <= pb)) {
-        const float4 pq = prev_nn[k0 + (sl >> 2) * stride];  // not yet overwritten: this point's pass is this one
         c.key = ((unsigned long long)__float_as_uint(pb) << 32) | 0xFFFFFFFFull;
-        c.qx = pq.x;
-        c.qy = pq.y;
-        c.qz = pq.z;
+        c.pos = prev_nn[k0 + (sl >> 2) * stride];  // not yet overwritten: this point's pass is this one
       }
       // First cube radius.  With a previous neighbour the seed's distance D is (nearly) the neighbour's own, and the first
       // cube that can certify anything is the one of radius ceil(D / (63/64 h)): the smaller ones would only be walked to
@@ -511,18 +505,16 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
                                                   count_candidates ? &n_cand : nullptr);
       if (grp_base == gl) {
         gkey = c.key;
-        qx = c.qx;
-        qy = c.qy;
-        qz = c.qz;
+        wpos = c.pos;
         found = f2;
       }
     }
 
     if (prev_nn && sub == 0 && valid) {
       // the best point met, certified or not (beyond the gate it is still a target point, hence a bound for the next
-      // sweep -- getFitnessScore's ungated one in particular); NaN when nothing was met at all
-      const float bd = __uint_as_float((unsigned int)(gkey >> 32)), none = __builtin_nanf("");
-      prev_nn[qi_src] = (fin && bd == bd) ? make_float4(qx, qy, qz, 0.f) : make_float4(none, none, none, 0.f);
+      // sweep -- getFitnessScore's ungated one in particular); kNoPrev when nothing was met at all
+      const float bd = __uint_as_float((unsigned int)(gkey >> 32));
+      prev_nn[qi_src] = (fin && bd == bd) ? wpos : kNoPrev;
     }
     if constexpr (WRITE_KEYS) {
       if (sub == 0 && valid) keys[qi_src] = found ? gkey : kEmptyKey;
@@ -533,6 +525,8 @@ __device__ __forceinline__ void nn_quad_body(const float4* __restrict__ src, int
     if constexpr (FUSE_REDUCE) {
       const float d2 = __uint_as_float((unsigned int)(gkey >> 32));
       if (found && d2 <= accept_thr) {
+        const float4 w = *reinterpret_cast<const float4*>(sorted_bytes + (size_t)wpos);  // the winner itself
+        const float qx = w.x, qy = w.y, qz = w.z;
         // the lane's two factors are picked as FLOATS (selects on loop-invariant lane masks), then widened: the double-
         // precision ternaries compiled into a ladder of divergent branches (~40 instructions per pass)
         const float af = qi == 0 ? qx : qi == 1 ? qy : qi == 2 ? qz : qi == 3 ? d2 : 1.0f;
@@ -573,7 +567,7 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
                                                            const int* __restrict__ cell_start, GridDesc g, float accept_thr,
                                                            unsigned long long* __restrict__ keys,
                                                            double* __restrict__ partials, int* __restrict__ unmatched,
-                                                           int* __restrict__ unmatched_count, float4* __restrict__ prev_nn,
+                                                           int* __restrict__ unmatched_count, unsigned int* __restrict__ prev_nn,
                                                            int use_prev, int cube_start,
                                                            unsigned long long* __restrict__ count_candidates) {
   nn_quad_body<WRITE_KEYS, FUSE_REDUCE, LIST_UNMATCHED, PACK_SHORT_ROWS>(src, n_s, qpw, xcd_map, T, sorted, cell_start, g, accept_thr, keys,
@@ -721,7 +715,7 @@ int grid_search_blocks(int n_s) {
 hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream,
-                                 float4* prev_nn, bool use_prev) {
+                                 unsigned int* prev_nn, bool use_prev) {
   if (n_s <= 0) return hipSuccess;
   const int blocks = grid_search_blocks(n_s);
   const int qpw = queries_per_wave(n_s), xm = flags & kGridSrcInCellOrder;

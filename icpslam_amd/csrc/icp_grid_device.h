@@ -70,9 +70,18 @@ struct LaneBest {
   float qx, qy, qz;        // the candidate itself (for the fused reduction)
 };
 
+// The same with the candidate's POSITION (byte offset into `sorted`) instead of its coordinates: one register instead of
+// three through the cube search, and what nn_quad_kernel remembers of a point's neighbour for the next sweep (4 bytes per
+// source point instead of 16).  The coordinates are fetched once, from the position, when the search is over.
+struct LanePos {
+  unsigned long long key;
+  unsigned int pos;
+};
+
 // Both points are finite here (non-finite targets are never binned, non-finite queries never search), so d2 is a finite
 // float or +inf, never NaN: its bit pattern orders like its value and no NaN guard is needed.
-__device__ __forceinline__ void consider(const float4& q, float px, float py, float pz, LaneBest& b) {
+// (pos = the candidate's byte offset in `sorted`; the coordinate-keeping flavour ignores it)
+__device__ __forceinline__ void consider(const float4& q, unsigned int pos, float px, float py, float pz, LaneBest& b) {
   const float d = dist2(q.x, q.y, q.z, px, py, pz);
   const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
   if (key < b.key) {
@@ -82,11 +91,26 @@ __device__ __forceinline__ void consider(const float4& q, float px, float py, fl
     b.qz = q.z;
   }
 }
+__device__ __forceinline__ void consider(const float4& q, unsigned int pos, float px, float py, float pz, LanePos& b) {
+  const float d = dist2(q.x, q.y, q.z, px, py, pz);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q.w);
+  if (key < b.key) {
+    b.key = key;
+    b.pos = pos;
+  }
+}
+__device__ __forceinline__ void take_owner(LaneBest& b, int owner) {
+  b.qx = readlane_f(b.qx, owner);
+  b.qy = readlane_f(b.qy, owner);
+  b.qz = readlane_f(b.qz, owner);
+}
+__device__ __forceinline__ void take_owner(LanePos& b, int owner) { b.pos = (unsigned int)__builtin_amdgcn_readlane((int)b.pos, owner); }
 
 // wave-wide winner: key and candidate become wave-uniform; false when no lane holds a candidate.  The distance bits are
 // reduced first (6 DPP steps); only when several lanes tie on the distance is a second reduction over the original
 // indices needed (lowest index wins, the contract of DESIGN.md section 3).
-__device__ __forceinline__ bool merge_lanes(LaneBest& b) {
+template <class Best>
+__device__ __forceinline__ bool merge_lanes(Best& b) {
   const unsigned int dbits = (unsigned int)(b.key >> 32), idx = (unsigned int)b.key;
   const unsigned int dmin = wave_min_u32(dbits);
   if (dmin == 0xFFFFFFFFu) return false;  // every lane still holds kEmptyKey
@@ -100,9 +124,7 @@ __device__ __forceinline__ bool merge_lanes(LaneBest& b) {
   }
   const int owner = __ffsll((long long)tied) - 1;
   b.key = ((unsigned long long)dmin << 32) | imin;
-  b.qx = readlane_f(b.qx, owner);
-  b.qy = readlane_f(b.qy, owner);
-  b.qz = readlane_f(b.qz, owner);
+  take_owner(b, owner);
   return true;
 }
 
@@ -111,8 +133,9 @@ __device__ __forceinline__ bool merge_lanes(LaneBest& b) {
 // row's base address is scalar.  Lanes past the end of a row re-read its last entry (same cache line, no extra traffic)
 // instead of being masked: evaluating a target point twice cannot change an exact minimum, so there is no per-lane
 // bounds test, and both loads of a step are in flight together.
+template <class Best>
 __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, int lo, int len, unsigned long long mask,
-                                           unsigned int lane, float px, float py, float pz, LaneBest& b,
+                                           unsigned int lane, float px, float py, float pz, Best& b,
                                            unsigned int* n_cand = nullptr) {
   while (mask) {
     const int ra = __ffsll((long long)mask) - 1;
@@ -126,15 +149,20 @@ __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, in
       blen = __builtin_amdgcn_readlane(len, rb);
     }
     if (n_cand) *n_cand += (unsigned int)(alen + (blo != alo || blen != 1 ? blen : 0));  // (counting runs only; wave-uniform)
-    const float4* __restrict__ pa = sorted + alo;
-    const float4* __restrict__ pb = sorted + blo;
-    const float4 qa = pa[min(lane, (unsigned int)(alen - 1))];
-    const float4 qb = pb[min(lane, (unsigned int)(blen - 1))];
-    consider(qa, px, py, pz, b);
-    consider(qb, px, py, pz, b);
-    for (int k = 64; k < alen; k += 64)  // long rows (dense cells near the sensor)
-      consider((pa + k)[min(lane, (unsigned int)(alen - 1 - k))], px, py, pz, b);
-    for (int k = 64; k < blen; k += 64) consider((pb + k)[min(lane, (unsigned int)(blen - 1 - k))], px, py, pz, b);
+    const unsigned int ia = (unsigned int)alo + min(lane, (unsigned int)(alen - 1));
+    const unsigned int ib = (unsigned int)blo + min(lane, (unsigned int)(blen - 1));
+    const float4 qa = sorted[ia];
+    const float4 qb = sorted[ib];
+    consider(qa, ia << 4, px, py, pz, b);
+    consider(qb, ib << 4, px, py, pz, b);
+    for (int k = 64; k < alen; k += 64) {  // long rows (dense cells near the sensor)
+      const unsigned int i2 = (unsigned int)(alo + k) + min(lane, (unsigned int)(alen - 1 - k));
+      consider(sorted[i2], i2 << 4, px, py, pz, b);
+    }
+    for (int k = 64; k < blen; k += 64) {
+      const unsigned int i2 = (unsigned int)(blo + k) + min(lane, (unsigned int)(blen - 1 - k));
+      consider(sorted[i2], i2 << 4, px, py, pz, b);
+    }
   }
 }
 
@@ -143,8 +171,9 @@ __device__ __forceinline__ void sweep_rows(const float4* __restrict__ sorted, in
 // instead of 5).  Longer rows take the two-at-a-time path.  Measured: -10 % at 50k x 50k, -19 % at 5k x 5k, but +4 % at
 // 200k x 200k, so it is a template switch (the mere presence of this code in the
 // kernel costs the dense case 3 %) that the host picks by the target's cell population.
+template <class Best>
 __device__ __forceinline__ void sweep_rows_packed(const float4* __restrict__ sorted, int lo, int len, unsigned long long mask,
-                                                  unsigned int lane, float px, float py, float pz, LaneBest& b,
+                                                  unsigned int lane, float px, float py, float pz, Best& b,
                                                   unsigned int* n_cand = nullptr) {
   unsigned long long shortm = mask & __ballot(len <= 16);
   const unsigned long long longm = mask & ~shortm;
@@ -172,7 +201,8 @@ __device__ __forceinline__ void sweep_rows_packed(const float4* __restrict__ sor
     if (n_cand) *n_cand += (unsigned int)(n0 + (r1 != r0 ? n1 : 0) + (r2 != r0 ? n2 : 0) + (r3 != r0 ? n3 : 0));
     const int mylo = seg == 0 ? lo0 : seg == 1 ? lo1 : seg == 2 ? lo2 : lo3;
     const int mylen = seg == 0 ? n0 : seg == 1 ? n1 : seg == 2 ? n2 : n3;
-    consider(sorted[mylo + (int)min(sub, (unsigned int)(mylen - 1))], px, py, pz, b);
+    const unsigned int im = (unsigned int)mylo + min(sub, (unsigned int)(mylen - 1));
+    consider(sorted[im], im << 4, px, py, pz, b);
   }
   sweep_rows(sorted, lo, len, longm, lane, px, py, pz, b, n_cand);
 }
@@ -250,10 +280,10 @@ __device__ __forceinline__ void octant_row_in_ball(const int* __restrict__ cell_
 // used; `slack` bounds what those can be off by (two roundings of a value below max(nx, ny, nz): < n * 2^-23 per point,
 // query and target, three axes), and D itself is inflated by 1/32 against the rounding of dist2.  The pruning only
 // removes cells that cannot hold a point closer than D; the certification test is unchanged.
-template <bool PACK_SHORT_ROWS>
+template <bool PACK_SHORT_ROWS, class Best>
 __device__ __forceinline__ bool grow_cubes(const float4* __restrict__ sorted, const int* __restrict__ cell_start,
                                            const GridDesc& g, float px, float py, float pz, int cx, int cy, int cz,
-                                           unsigned int lane, LaneBest& b, int rho_first = 1, unsigned int* n_cand = nullptr) {
+                                           unsigned int lane, Best& b, int rho_first = 1, unsigned int* n_cand = nullptr) {
   const float fx = (px - g.ox) * g.inv_h, fy = (py - g.oy) * g.inv_h, fz = (pz - g.oz) * g.inv_h;
   const float slack = grid_slack(g);
   for (int rho = rho_first;; rho = min(2 * rho, g.r_max)) {

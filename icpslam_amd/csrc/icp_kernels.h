@@ -51,6 +51,7 @@ struct Xform {
 // the key is (d2, index) lexicographic, so a u64 min merges partial searches and breaks ties on the lowest index.
 static constexpr int kGridStatInts = 6;
 static constexpr unsigned long long kEmptyKey = 0xFFFFFFFFFFFFFFFFull;
+static constexpr unsigned int kNoPrev = 0xFFFFFFFFu;  // previous-neighbour position: none (launch_nn_grid_search)
 
 static constexpr int kReduceTerms = 17;   // n, Sp(3), Sq(3), Sqp(9), Sd2
 static constexpr int kMaxReduceBlocks = 1024;
@@ -180,7 +181,7 @@ struct BatchPair {  // what stays the same for a pair from sweep to sweep (a tab
   const float4* sorted;
   const int* cell_start;
   double* partials;
-  float4* prev_nn;
+  unsigned int* prev_nn;      // the pair's previous-neighbour positions (below)
   unsigned long long* flags;  // the pair's result mailbox (device alias of pinned host memory)
   unsigned long long* keys;   // ungated (getFitnessScore) sweep: the pair's key array, its list of unmatched points + counter
   int* unmatched;
@@ -205,12 +206,13 @@ hipError_t launch_reduce_final_batch(const BatchPair* d_pairs, const BatchStep& 
 hipError_t launch_nn_grid_search(const float4* src, int n_s, int flags, const Xform& T, const float4* sorted,
                                  const int* cell_start, const GridDesc& g, float accept_thr, unsigned long long* keys,
                                  double* partials, int* unmatched, int* unmatched_count, hipStream_t stream,
-                                 float4* prev_nn = nullptr, bool use_prev = false);
+                                 unsigned int* prev_nn = nullptr, bool use_prev = false);
 int grid_search_blocks(int n_s);
 // Counting runs only (process-wide, not thread-safe): every nn_quad_kernel launch adds the number of target points it
 // evaluates to *device_counter; nullptr switches the counting off again.
 void grid_count_candidates(unsigned long long* device_counter);
-// prev_nn (optional, n_s float4): the neighbour each point found, written by every sweep of nn_quad_kernel and, with
+// prev_nn (optional, n_s x 4 bytes): where in `sorted` (byte offset; kNoPrev: nowhere) the neighbour each point found sits,
+// written by every sweep of nn_quad_kernel and, with
 // use_prev, read back by the next one as an upper bound that prunes its search (valid for ANY transform, but only against
 // the same target points and the same src array).  True when launch_nn_grid_search would use it for this size.
 bool grid_search_keeps_prev(int n_s, int flags);

@@ -161,7 +161,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
         bool wants_fit = false;  // lock-step: its ungated fitness sweep is due
         bool waiting = false;  // lock-step: a sweep of it is in flight
         bool pack = false;
-        float4* prev = nullptr;
+        unsigned int* prev = nullptr;
       };
       std::vector<Slot> slots(depth);
       icpgpu_ctx* lead = ws[0];
@@ -327,7 +327,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
               icpgpu_ctx* w = sl.w;
               group_pack = sl.pack;
               bool use_prev = false;
-              float4* buf = nullptr;
+              unsigned int* buf = nullptr;
               if (prev_neighbours(w, w->grid, w->src.data(), (int)w->src.n, grid_flags(w->grid, false), buf, use_prev) || buf != sl.prev) {
                 fail(w, ICPGPU_ERR_HIP, "lock-step batch: previous-neighbour buffer moved");
                 return failed(ICPGPU_ERR_HIP, sl.pair, w);

@@ -472,8 +472,37 @@ int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
 }
 
 
+// setInputSource from a host buffer.  The reference filters every scan first and hands the filtered cloud over as the source
+// (`voxelFilterCloud(&curr_cloud_, ...)`, icp_odometer.cpp:177, then setInputSource at :193): when this context ran that filter
+// (icpgpu_voxel_grid / icpgpu::VoxelGrid::filter) the very bytes are still in HBM.  A buffer of the filtered cloud's size whose
+// content fingerprint equals the one taken when it was fetched is adopted from there -- a device-to-device copy queued on the
+// stream instead of an upload and a stream synchronisation -- together with the raw scan's bounding box, so that the grids
+// built over it need no bounding-box pass of their own: the sequence then costs what icpgpu_set_source_voxel_filtered costs.
+// Same bits in HBM either way; same ASSUMPTION and the same switch (ICPGPU_RECOGNISE=0) as icpgpu_set_target's recognition.
 int icpgpu_set_source(icpgpu_ctx* c, const float* xyzw, size_t n) {
   ENTER(c);
+  if (recognise_enabled() && c->vox_fp_valid && n > 0 && xyzw && n == c->vox_last_n && c->vox_out.ptr &&
+      sample_fingerprint(xyzw, n) == c->vox_sample_fp && icpgpu_fingerprint(xyzw, n) == c->vox_fp) {
+    if (c->src.buf.external) c->src.buf = DeviceBuf{};
+    int rc = ensure(c, c->src.buf, n * sizeof(float4));
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->src.buf.ptr, c->vox_out.ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+    c->src_version++;
+    c->src.n = n;
+    c->src.set = true;
+    c->src.sample_fp = c->vox_sample_fp;
+    c->src.sample_valid = true;
+    c->src.bbox_version = 0;
+    if (c->vox_box_valid) {  // a box that CONTAINS the centroids (icpgpu_set_source_voxel_filtered)
+      std::memcpy(c->src.bbox_enc, c->vox_box, sizeof(c->vox_box));
+      c->src.bbox_version = c->src_version;
+      c->src.bbox_exact = false;
+    }
+    c->src_fp = c->vox_fp;
+    c->src_fp_version = c->src_version;
+    c->prof.sources_adopted += 1;
+    return ICPGPU_OK;
+  }
   c->src_version++;
   return set_cloud_host(c, c->src, xyzw, n);
 }
@@ -693,6 +722,10 @@ int icpgpu_profile_get(icpgpu_ctx* c, icpgpu_profile* out) {
   int rc = resolve_sweep_timings(c);
   if (rc) return rc;
   if ((rc = resolve_cov_timing(c))) return rc;
+  // which inner solver this context's GICP alignments run on (icpgpu_gicp.cpp): forced modes answer at once, the measured mode
+  // once its timing has settled
+  const int mode = gicp_device_solver_mode();
+  c->prof.gicp_solver_choice = mode == 2 ? (uint64_t)c->gicp_choice : (mode == 1 && c->gicp_device_ok ? 2u : 1u);
   *out = c->prof;
   return ICPGPU_OK;
 }

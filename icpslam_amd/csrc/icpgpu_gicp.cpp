@@ -321,7 +321,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     const bool timed = c->timing_every <= 1 || (c->sweep_counter++ % (unsigned)c->timing_every) == 0;
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     if (grid_ready(c)) {
-      float4* prev = nullptr;  // each outer iteration's neighbours bound the next one's search
+      unsigned int* prev = nullptr;  // each outer iteration's neighbours bound the next one's search
       bool use_prev = false;
       int prc = prev_neighbours(c, c->grid, c->src.data(), n_s, grid_flags(c->grid, false), prev, use_prev);
       if (prc) return prc;
@@ -510,6 +510,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
         break;
       }
       const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
+      c->prof.gicp_host_solves += 1;
       mark(4);
       gicp_server_stop(c);
       mark(5);

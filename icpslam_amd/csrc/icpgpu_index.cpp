@@ -301,25 +301,27 @@ int grid_flags(const GridIndex& G, bool src_in_cell_order) {
 // The previous-neighbour buffer for a sweep of src_pts[0..n_q) over G, or nullptr when the kernel chosen for this size
 // keeps none (ICPGPU_PREV=0 switches the mechanism off: A/B measurements).  use = the entries come from a sweep of the
 // same queries over the same target points.
-int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, float4*& buf, bool& use) {
+int prev_neighbours(icpgpu_ctx* c, const GridIndex& G, const float4* src_pts, int n_q, int flags, unsigned int*& buf, bool& use) {
   static const bool enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_PREV"); return !e || std::atoi(e) != 0; }();
   buf = nullptr;
   use = false;
   if (!enabled || !grid_search_keeps_prev(n_q, flags)) return ICPGPU_OK;
   PrevNeighbours& P = c->prev;
   const void* before = P.buf.ptr;
-  int rc = ensure(c, P.buf, (size_t)n_q * sizeof(float4));
+  int rc = ensure(c, P.buf, (size_t)n_q * sizeof(unsigned int));
   if (rc) return rc;
   use = P.valid && P.buf.ptr == before && P.src == src_pts && P.n == n_q && P.sorted == G.sorted.ptr &&
-        P.grid_version == G.version && P.src_version == c->src_version;
+        P.grid_version == G.version && P.n_binned == G.n_binned && P.src_version == c->src_version;
   c->prof.grid_bounded += use ? 1 : 0;
   P.valid = true;
   P.src = src_pts;
   P.sorted = G.sorted.ptr;
   P.n = n_q;
   P.grid_version = G.version;
+  P.n_binned = G.n_binned;  // the entries are positions in the sorted copy: ANY of its points bounds a search, whichever build
+                            // of the grid put it there (a rebuild over the same target holds the same points, maybe elsewhere)
   P.src_version = c->src_version;
-  buf = static_cast<float4*>(P.buf.ptr);
+  buf = static_cast<unsigned int*>(P.buf.ptr);
   return ICPGPU_OK;
 }
 
@@ -341,7 +343,7 @@ int nn_keys_grid(icpgpu_ctx* c, GridIndex& G, const float4* src_pts, int n_s, co
   // cell rows for a few hundred queries.
   GridDesc g_open = G.g;
   g_open.r_max = std::min(4 * G.g.r_max, 48);
-  float4* prev = nullptr;
+  unsigned int* prev = nullptr;
   bool use_prev = false;
   if ((rc = prev_neighbours(c, G, src_pts, n_s, grid_flags(G, false), prev, use_prev))) return rc;
   HIP_TRY(c, launch_nn_grid_search(src_pts, n_s, grid_flags(G, false), T, static_cast<const float4*>(G.sorted.ptr),

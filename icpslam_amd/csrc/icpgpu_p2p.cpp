@@ -251,7 +251,7 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
     const int blocks = grid_search_blocks(n_q);
     if ((rc = ensure(c, c->partials, (size_t)blocks * kReduceTerms * sizeof(double)))) return rc;
     partials = static_cast<double*>(c->partials.ptr);
-    float4* prev = nullptr;
+    unsigned int* prev = nullptr;
     bool use_prev = false;
     if ((rc = prev_neighbours(c, c->grid, src_pts, n_q, grid_flags(c->grid, ordered), prev, use_prev))) return rc;
     std::chrono::steady_clock::time_point tl0;
@@ -331,7 +331,7 @@ int sweep_complete(icpgpu_ctx* c, SweepTicket& tk) {
   if (rc) return rc;
   const unsigned long long seq2 = ++c->sums_seq;
   HIP_TRY(c, launch_reduce(tk.red_src, tk.red_n, c->tgt.data(), keys, tk.T, tk.thr, static_cast<double*>(c->partials.ptr),
-                           c->h_sums_dev, c->h_flags_dev, seq2, c->stream));
+                           c->h_sums_dev, c->h_flags_dev, wire_seq(c, seq2), c->stream));
   c->prof.reduce_launches += 1;
   tk.few_host = nullptr;
   tk.seq = seq2;

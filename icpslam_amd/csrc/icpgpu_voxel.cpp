@@ -117,6 +117,26 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   return ICPGPU_OK;
 }
 
+// The filtered cloud (c->vox_out, m points) to the host.  The reference hands this very cloud back as the registration's
+// source a few lines later (icp_odometer.cpp:177 -> :193), so the copy is bracketed by what icpgpu_set_source needs to
+// recognise it: the content fingerprint, computed on the device while the copy is in flight (8 more bytes in the same
+// synchronisation), and the sample fingerprint of the fetched bytes (a microsecond).
+static int fetch_filtered(icpgpu_ctx* c, float* out_xyzw, size_t m) {
+  int rc = ensure(c, c->fp_acc, sizeof(unsigned long long));
+  if (rc) return rc;
+  auto* d_acc = static_cast<unsigned long long*>(c->fp_acc.ptr);
+  HIP_TRY(c, launch_fingerprint(static_cast<const float4*>(c->vox_out.ptr), (int)m, d_acc, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 8, d_acc, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  unsigned long long sum = 0;
+  std::memcpy(&sum, c->h_ints + 8, sizeof sum);
+  c->vox_fp = fp_finish(sum, (unsigned long long)m);
+  c->vox_sample_fp = sample_fingerprint(out_xyzw, m);
+  c->vox_fp_valid = true;
+  return ICPGPU_OK;
+}
+
 }  // namespace icpgpu_impl
 
 extern "C" {
@@ -127,17 +147,20 @@ int icpgpu_voxel_grid(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, fl
   if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
   *n_out = 0;
   c->vox_last_n = 0;
+  c->vox_fp_valid = c->vox_box_valid = false;
   int rc = ensure(c, c->vox_in, n * sizeof(float4));
   if (rc) return rc;
   if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   int m = 0;
   bool pass = false;
-  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass, nullptr))) return rc;
-  if (m && out_xyzw) {
-    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
+  int box[6];
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass, box))) return rc;
   c->vox_last_n = (size_t)m;  // out_xyzw == NULL: the filtered cloud waits in HBM for icpgpu_voxel_grid_fetch
+  if (m > 0) {
+    std::memcpy(c->vox_box, box, sizeof(box));
+    c->vox_box_valid = true;
+  }
+  if (m && out_xyzw && (rc = fetch_filtered(c, out_xyzw, (size_t)m))) return rc;
   *n_out = (size_t)m;
   return ICPGPU_OK;
 }
@@ -148,10 +171,7 @@ int icpgpu_voxel_grid_fetch(icpgpu_ctx* c, float* out_xyzw, size_t capacity, siz
   if (n_out) *n_out = m;
   if (m > capacity) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel_grid_fetch: %zu points, room for %zu", m, capacity);
   if (m && !out_xyzw) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
-  if (m) {
-    HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-  }
+  if (m) return fetch_filtered(c, out_xyzw, m);
   return ICPGPU_OK;
 }
 

@@ -37,7 +37,23 @@ extern "C" {
 #endif
 
 #define ICPGPU_VERSION_MAJOR 0
-#define ICPGPU_VERSION_MINOR 2
+#define ICPGPU_VERSION_MINOR 3 /* 0.3: icpgpu_profile grew (sources_adopted, gicp_host_solves, gicp_solver_choice); a caller built
+                                * against an older header passes a smaller icpgpu_profile -- compare icpgpu_version() first */
+
+/* ---- environment ---------------------------------------------------------------------------------
+ * Production switches, read by every build of libicpgpu.so (none of them changes a result):
+ *   ICPGPU_WAIT_TIMEOUT_MS        deadline of every host wait for the device (mailbox, gather); default 30000
+ *   ICPGPU_BATCH_THREADS          host threads of icpgpu_align_batch (default: chosen from the CPUs this process may use)
+ *   ICPGPU_BATCH_DEPTH            alignments each of those threads keeps in flight
+ *   ICPGPU_RECOGNISE=0            icpgpu_set_target / icpgpu_set_source always upload (no content recognition)
+ *   ICPGPU_GICP_SERVER=0          every GICP cost evaluation is its own kernel launch (no resident evaluation server)
+ *   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the resident device solver (1), or whichever the context
+ *                                 measures to be faster over its first alignments (auto, the default); same bits either way, the
+ *                                 choice is reported in icpgpu_profile.gicp_solver_choice
+ *   ICPGPU_MAILBOX=pairs|release  how results reach the host (default: a self-test at context creation picks it)
+ *   ICPGPU_DEBUG=1                diagnostics on stderr
+ *   LOCAL_WORLD_SIZE              (torch.distributed.run) processes sharing this host's CPUs
+ * Development switches (kernel variants, tuning constants, test modes) exist only in libicpgpu_dev.so: icpslam_amd/csrc/icp_env.h. */
 
 typedef struct icpgpu_ctx icpgpu_ctx; /* opaque */
 
@@ -147,6 +163,11 @@ typedef struct {
   uint64_t gicp_device_solves;     /* GICP outer iterations whose whole inner BFGS ran on the device (gicp_solve_kernel) */
   uint64_t grid_adopted;           /* GICP: targets whose correspondence search took over the grid their covariances were computed
                                     * over instead of building a second one (same keys: the search is exact whatever the cells) */
+  uint64_t sources_adopted;        /* icpgpu_set_source calls that found the buffer to be the context's last voxel-filter result,
+                                    * still in HBM (no upload, no bounding-box pass) -- version 0.3 */
+  uint64_t gicp_host_solves;       /* GICP outer iterations whose inner BFGS ran on the host (over the evaluation server) -- 0.3 */
+  uint64_t gicp_solver_choice;     /* ICPGPU_GICP_DEVICE=auto: 0 = the context is still timing both solvers, 1 = it settled on the
+                                    * host loop, 2 = on the device solver (forced modes report 1 / 2 at once) -- 0.3 */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -180,7 +201,9 @@ int icpgpu_set_target(icpgpu_ctx* ctx, const float* xyzw, size_t n);
  * context pool picks the context whose source has the new target's size).
  * ASSUMPTION: recognition compares sizes and the 64-bit fingerprint (an additive, non-cryptographic mix of every point's bits
  * and index), not the bytes: two different clouds of equal size collide with probability ~2^-64 per comparison, and an
- * adversarial cloud could be constructed.  ICPGPU_RECOGNISE=0 in the environment makes icpgpu_set_target always upload. */
+ * adversarial cloud could be constructed.  ICPGPU_RECOGNISE=0 in the environment makes icpgpu_set_target always upload.
+ * icpgpu_set_source recognises in the same way (and under the same switch) the result of the context's last icpgpu_voxel_grid
+ * when the caller hands it back: see icpgpu_voxel_grid below. */
 unsigned long long icpgpu_fingerprint(const float* xyzw, size_t n);
 int icpgpu_cloud_sizes(const icpgpu_ctx* ctx, size_t* n_source, size_t* n_target);
 /* same, for clouds already resident in this device's HBM (zero copy; must stay valid and

@@ -91,3 +91,58 @@ def test_a_cloud_registered_against_itself_survives_the_recognition(built):
         assert np.abs(r["T"] - np.eye(4, dtype=np.float32)).max() <= 1e-6
         idx, d2 = c.nn(np.eye(4))
         assert np.array_equal(idx, np.arange(40000)) and not d2.any()
+
+
+@pytest.mark.parametrize("method", ["p2p", "gicp"])
+def test_the_voxel_filters_result_is_adopted_as_the_source(built, method):
+    """voxelFilterCloud -> setInputSource (/root/reference/src/icpslam/icp_odometer.cpp:177,193): the filtered cloud the caller
+    hands back is still in HBM -- icpgpu_set_source adopts it (no upload, the raw scan's box for the grid builds) and nothing
+    about the results changes; a cloud that differs in one bit, or has another size, is uploaded as before."""
+    raw_a, raw_b, _ = synth.make_pair(120000, 120000, seed=51)
+    kw = dict(max_iterations=6)
+    if method == "gicp":
+        kw["method"] = GICP
+    with Context(0) as fresh:                      # upload path only: filter in one context, register in another
+        fa, fb = fresh.voxel_grid(raw_a, 0.2), fresh.voxel_grid(raw_b, 0.2)
+    with Context(0) as plain:
+        plain.set_params(plain.default_params(), **kw)
+        plain.set_target(fb)
+        plain.set_source(fa)
+        assert plain.profile().sources_adopted == 0
+        want = plain.align(want_fitness=True)
+    with Context(0) as c:
+        c.set_params(c.default_params(), **kw)
+        gb = c.voxel_grid(raw_b, 0.2)
+        assert np.array_equal(gb, fb)
+        c.set_target(gb)
+        ga = c.voxel_grid(raw_a, 0.2)
+        c.set_source(ga.copy())                    # another host buffer, the same bytes
+        assert c.profile().sources_adopted == 1 and c.n_source == ga.shape[0]
+        got = c.align(want_fitness=True)
+        assert np.array_equal(got["T"], want["T"]) and got["iterations"] == want["iterations"]
+        assert got["n_corr"] == want["n_corr"] and abs(got["fitness"] - want["fitness"]) <= 1e-12 * want["fitness"]
+        assert np.array_equal(c.voxel_grid(raw_a, 0.2), ga)          # the filter's own buffer is untouched by the adoption
+        # the next scan: the previous source comes back as the target (promote path), the new filtered scan is adopted again
+        c.set_target(ga.copy())
+        gb2 = c.voxel_grid(raw_b, 0.2)
+        c.set_source(gb2)
+        p = c.profile()
+        assert p.sources_adopted == 2 and p.targets_recognised >= 1
+        back = c.align(want_fitness=True)
+        with Context(0) as plain2:
+            plain2.set_params(plain2.default_params(), **kw)
+            plain2.set_target(fa)
+            plain2.set_source(fb)
+            want_back = plain2.align(want_fitness=True)
+        assert np.array_equal(back["T"], want_back["T"]) and back["n_corr"] == want_back["n_corr"]
+        # one bit off (in a sampled point, then in one only the full fingerprint sees), or one point short: uploaded
+        ga = c.voxel_grid(raw_a, 0.2)
+        m = ga.shape[0]
+        x = ga.copy(); x.view(np.uint32)[m // 2, 0] ^= 1
+        c.set_source(x)
+        y = ga.copy(); y.view(np.uint32)[m // 2 + 1, 2] ^= 1
+        c.set_source(y)
+        c.set_source(ga[:-1])
+        assert c.profile().sources_adopted == 2
+        idx, d2 = c.nn(np.eye(4))                  # ... and what was uploaded is what is searched
+        assert idx.shape[0] == m - 1
