@@ -257,6 +257,18 @@ def _load_json(name: str) -> dict:
         return {}
 
 
+def search_kernel_source_sha256() -> str:
+    """sha256 over the grid search kernel's sources (the files libicpgpu.so's nn_quad_kernel is built from): the committed PMC
+    summaries under profiles/ carry the hash of the sources they were collected on (scripts/kernel_hash.py is the same function
+    for the collection scripts), and the bench line says `pmc_stale` when they no longer match."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("icp_grid.hip", "icp_grid_device.h"):
+        with open(os.path.join(ROOT, "icpslam_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def run_multi_entry(a):
     """BASELINE config 4 through icpgpu_align_batch_multi (include/icpgpu.h; icp_multi.cpp): one process, `--gpus` device
     entries, contiguous shards of a.pairs_per_rank pairs each, one all-gather of the 184-byte records (RCCL; host-staged when
@@ -543,8 +555,15 @@ def main():
         alg_bytes_keys = 16.0 * (n_s + n_t) + 8.0 * n_s   # both clouds once + 8 B key per source point
         alg_bytes_fused = 16.0 * (n_s + n_t) + 64.0       # fused design lower bound
         used_grid = prof.grid_launches > 0
-        traffic = _load_json("pmc_traffic.json").get(a.workload, {})
-        issue_pmc = _load_json("pmc_issue.json").get(a.workload, {})
+        traffic_all, issue_all = _load_json("pmc_traffic.json"), _load_json("pmc_issue.json")
+        traffic = traffic_all.get(a.workload, {})
+        issue_pmc = issue_all.get(a.workload, {})
+        try:
+            src_hash = search_kernel_source_sha256()
+        except OSError:
+            src_hash = None
+        traffic_stale = traffic_all.get("kernel_source_sha256") != src_hash
+        issue_stale = issue_all.get("kernel_source_sha256") != src_hash
         brute_roofline = None
         if brute:
             def brute_entry(kernel, ms, note):
@@ -602,7 +621,11 @@ def main():
                 "kernel": "nn_quad_kernel<fused> (uniform-grid exact NN, four points per wave pass, + rejection + 17-term reduction)",
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": traffic.get("nn_grid_hbm_bytes_per_launch"),
-                "traffic_source": "STATIC: profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, committed), not measured in this run",
+                "traffic_source": "STATIC: profiles/pmc_traffic.json (builder-run rocprofv3 --pmc passes, committed), not measured in this run; "
+                                  "pmc_stale = the file was collected on other sources of the search kernel than the ones in this tree "
+                                  "(sha256 over icp_grid.hip + icp_grid_device.h, embedded by the collection scripts)",
+                "pmc_stale": bool(traffic_stale),
+                "kernel_source_sha256": src_hash,
                 "avg_launch_ms": g_ms, "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
                 "timed_launches_how": "HIP-event triples on the context's stream around one sweep in 13 (13 is coprime with the 10 sweeps of an "
                                       "alignment, so over the timed steps every sweep position -- the cold first one to the converged tenth -- "
@@ -640,6 +663,7 @@ def main():
                     "lane_slots_per_candidate": (valu * 64.0 / cand) if cand else None,
                     "lane_slots_def": "VALU wave-instructions x 64 lanes / target points evaluated: ~10 would be the distance + compare alone",
                     "pmc_source": "STATIC: profiles/pmc_issue.json (builder-run rocprofv3 --pmc, committed); only the launch time is live",
+                    "pmc_stale": bool(issue_stale),
                     "useful_tflops": (8.0 * cand / (g_ms * 1e-3) / 1e12) if cand else None,
                     "useful_flop_frac_of_fp32_peak": (8.0 * cand / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if cand else None,
                     "source": issue_pmc.get("_how", "profiles/pmc_issue.json")}

@@ -302,6 +302,9 @@ struct icpgpu_ctx {
   size_t vox_pub_zeroed_cap = 0;
   std::vector<icpgpu_ctx*> workers;  // align_batch: one sub-context (own stream + scratch) per host worker thread
   DeviceBuf batch_table;             // lock-step batch: the BatchPair table of the group this context leads
+  std::atomic<size_t> batch_table_cells{0};   // align_batch: the largest cell table any worker has needed (icpgpu_index.cpp)
+  std::atomic<size_t>* shared_table_cells = nullptr;  // a batch worker: its parent's batch_table_cells
+  std::vector<hipStream_t> group_streams;  // lock-step batch: one stream per group, created consecutively (icpgpu_batch.cpp)
   int host_share = 1;                // batch drivers of this process that share its CPUs with this context (icp_multi.cpp)
   std::string err;
 };
@@ -387,6 +390,7 @@ struct P2PRun {
 // icpgpu_context.cpp
 int fail(icpgpu_ctx* c, int code, const char* fmt, ...);
 int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes);
+extern std::atomic<unsigned long long> g_alloc_calls, g_alloc_us;  // allocations through ensure() and their host microseconds
 void release(DeviceBuf& b);
 Xform to_xform(const Mat4d& T);
 Xform to_xform(const float* T);

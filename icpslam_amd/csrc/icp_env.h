@@ -3,7 +3,8 @@
 // PRODUCTION switches are read by every build (std::getenv directly; the list in include/icpgpu.h, section "environment",
 // and INTEGRATION.md repeat this one):
 //   ICPGPU_WAIT_TIMEOUT_MS   deadline of every host wait for the device (mailbox, gather); default 30 000
-//   ICPGPU_BATCH_THREADS / ICPGPU_BATCH_DEPTH   host threads of icpgpu_align_batch and alignments each drives
+//   ICPGPU_BATCH_THREADS / ICPGPU_BATCH_DEPTH / ICPGPU_BATCH_GROUPS   icpgpu_align_batch: host threads, pairs per lock-step
+//                            group, groups in flight on the GPU (all threads together; default 8)
 //   ICPGPU_RECOGNISE=0       icpgpu_set_target / icpgpu_set_source always upload (no content recognition)
 //   ICPGPU_GICP_SERVER=0     every GICP cost evaluation is its own kernel launch (no resident server)
 //   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the device solver gicp_solve_kernel (1), or whichever

@@ -581,21 +581,22 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 template <bool PACK_SHORT_ROWS, bool OPEN>
 __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_quad_batch_kernel(const BatchPair* __restrict__ pairs, BatchStep step,
                                                                                                        int cube_start) {
-  const BatchPair& d = pairs[step.slot[blockIdx.y]];
+  // (Measured and dropped in round 5: XCD k taking the k-th eighth of the pair-major list of work units -- one pair per XCD and L2
+  // in a group of eight -- instead of an eighth of every pair: 4-7 % slower at every group size; profiles/r05_batch_groups.txt.)
+  const int by = (int)blockIdx.y, bx = (int)blockIdx.x;
+  const BatchPair& d = pairs[step.slot[by]];
   const int n_blocks = d.blocks;
-  if ((int)blockIdx.x >= n_blocks) return;
-  const Xform T = step.T[blockIdx.y];
+  if (bx >= n_blocks) return;
+  const Xform T = step.T[by];
   GridDesc g = d.g;
-  const int use_prev = (int)((step.use_prev_mask >> blockIdx.y) & 1u);
+  const int use_prev = (int)((step.use_prev_mask >> by) & 1u);
   if constexpr (OPEN) {
     g.r_max = d.r_max_open;
     nn_quad_body<true, false, true, PACK_SHORT_ROWS>(d.src, d.n_s, d.qpw, d.xcd_map, T, d.sorted, d.cell_start, g, 0.f, d.keys, nullptr,
-                                                     d.unmatched, d.unmatched_count, d.prev_nn, use_prev, cube_start, nullptr, n_blocks,
-                                                     (int)blockIdx.x);
+                                                     d.unmatched, d.unmatched_count, d.prev_nn, use_prev, cube_start, nullptr, n_blocks, bx);
   } else {
     nn_quad_body<false, true, false, PACK_SHORT_ROWS>(d.src, d.n_s, d.qpw, d.xcd_map, T, d.sorted, d.cell_start, g, d.accept_thr, nullptr,
-                                                      d.partials, nullptr, nullptr, d.prev_nn, use_prev, cube_start, nullptr, n_blocks,
-                                                      (int)blockIdx.x);
+                                                      d.partials, nullptr, nullptr, d.prev_nn, use_prev, cube_start, nullptr, n_blocks, bx);
   }
 }
 

@@ -90,13 +90,39 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   }
   n_threads = std::min(n_threads, n_pairs);
   depth = std::min(depth, (n_pairs + n_threads - 1) / n_threads);
-  const size_t n_ctx = n_threads * depth;
+  // lock-step: groups in flight on the GPU = n_threads x groups_per_thread, eight by default whatever the CPUs (a 50k-point
+  // group's sweep leaves the chip idle in its tail; measured at config 4's shape, 64 pairs: profiles/r05_batch_groups.txt).
+  // ICPGPU_BATCH_GROUPS sets the total.
+  size_t groups_per_thread = 1;
+  if (lockstep) {
+    size_t total = 8;
+    if (const char* v = std::getenv("ICPGPU_BATCH_GROUPS")) total = (size_t)std::max(1, std::atoi(v));
+    total = std::min(total, (n_pairs + depth - 1) / depth);
+    n_threads = std::min(n_threads, std::max<size_t>(1, total));
+    groups_per_thread = std::max<size_t>(1, (total + n_threads - 1) / n_threads);
+  }
+  const size_t per_thread = groups_per_thread * depth;
+  const size_t n_ctx = n_threads * per_thread;
   while (c->workers.size() < n_ctx) {
     icpgpu_ctx* w = nullptr;
     const int rc = icpgpu_create(&w, c->device);
     if (rc != ICPGPU_OK) return fail(c, rc, "align_batch: worker context: %s", icpgpu_last_error(nullptr));
+    w->shared_table_cells = &c->batch_table_cells;
     c->workers.push_back(w);
   }
+  // The groups' streams are created HERE, one after the other: the runtime spreads streams over its (four) hardware queues in
+  // creation order, and kernels of streams that share a hardware queue do not overlap.  Until round 5 a group ran on its lead
+  // worker's stream -- the (g x depth)-th stream the context created -- so that with a depth of 8 (or 4) EVERY group sat on the
+  // same hardware queue and the groups' sweeps ran one after the other: 4.1-4.5k pairs/s at config 4's shape where depths of
+  // 5 or 7 reached 5.1-5.5k (rocprofv3 kernel trace: 2 queues in use, mostly one search kernel at a time, against 4 queues and
+  // 2-4 kernels; profiles/r05_batch_groups.txt).
+  if (lockstep)
+    while (c->group_streams.size() < n_threads * groups_per_thread) {
+      hipStream_t st = nullptr;
+      HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      c->group_streams.push_back(st);
+    }
+  const auto t_call = std::chrono::steady_clock::now();
   std::atomic<size_t> next{0};
   std::atomic<bool> abort{false};
   struct ThreadError {  // one slot per host thread: nothing shared is written while the threads run
@@ -126,8 +152,8 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       abort.store(true);
       return;
     }
-    icpgpu_ctx* const* ws = &c->workers[t * depth];
-    for (size_t s = 0; s < depth; ++s) {
+    icpgpu_ctx* const* ws = &c->workers[t * per_thread];
+    for (size_t s = 0; s < per_thread; ++s) {
       ws[s]->params = c->params;
       ws[s]->nn_variant = c->nn_variant;
       // Every GICP worker's BFGS runs keep its workgroups resident and a host thread spinning.  8 workers fit the chip
@@ -151,6 +177,12 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     const double timeout_ms = wait_timeout_ms();
     if (lockstep) {
       // ---- lock-step groups ----------------------------------------------------------------------------------------
+      // A host thread leads `groups_per_thread` groups, each `depth` pairs on a stream of its own, as NON-BLOCKING state
+      // machines (fill -> index builds -> iterate): while one group's sweep is in flight the thread copies the next pair of
+      // another group in, takes that group's builds through a host round trip, or does its solves.  The number of groups in
+      // flight on the GPU is therefore decoupled from the number of CPUs the process may use (round 4: one group per thread,
+      // four threads at most -- 4.0k pairs/s at config 4's shape where eight such entries sharing the GPU reached 5.2k: the
+      // sweeps of one group leave the chip idle in their tails, more groups fill them).
       struct Slot {
         icpgpu_ctx* w = nullptr;
         size_t pair = 0;
@@ -163,155 +195,246 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
         bool pack = false;
         unsigned int* prev = nullptr;
       };
-      std::vector<Slot> slots(depth);
-      icpgpu_ctx* lead = ws[0];
-      hipStream_t gstream = lead->stream;
-      std::vector<hipStream_t> own(depth);
-      for (size_t s2 = 0; s2 < depth; ++s2) {
-        slots[s2].w = ws[s2];
-        own[s2] = ws[s2]->stream;
-        ws[s2]->stream = gstream;  // one queue for the group: builds, sweeps and fitness sweeps are ordered by it
-      }
-      struct Restore {
-        std::vector<hipStream_t>& own;
-        icpgpu_ctx* const* ws;
-        hipStream_t g;
-        ~Restore() {
-          (void)hipStreamSynchronize(g);
+      struct Group {
+        enum Phase { Fill, Build, Iterate, Retired } phase = Fill;
+        icpgpu_ctx* const* ws = nullptr;
+        icpgpu_ctx* lead = nullptr;
+        hipStream_t gstream = nullptr;  // copies, index builds, the table: the lead's own stream
+        hipStream_t sstream = nullptr;  // the sweeps (search + reduction + the fitness tail): the same stream (see below)
+        std::vector<hipStream_t> own;
+        std::vector<Slot> slots;
+        std::vector<BatchPair> table;
+        size_t n_slots = 0, live = 0, cap = 0;  // cap: pairs the current fill takes (the thread's first one is small: see below)
+        unsigned idle_spins = 0, step_counter = 0;
+        int timed_pairs = 0;  // pairs of the launch whose events are outstanding
+        size_t index = 0;     // the group's number among all groups of the job
+        bool filled_once = false;
+        unsigned long long sync_seq = 0;  // Build: the number the group's posted marker carries once its stage has drained
+        std::chrono::steady_clock::time_point bt0, bt1, bt2;
+        ~Group() {  // whatever way the thread leaves: the workers get their own streams back, nothing of the group in flight
+          if (sstream) (void)hipStreamSynchronize(sstream);
+          if (gstream) (void)hipStreamSynchronize(gstream);
           for (size_t i = 0; i < own.size(); ++i) ws[i]->stream = own[i];
         }
-      } restore{own, ws, gstream};
-      if (ensure(lead, lead->batch_table, depth * sizeof(BatchPair))) return failed(ICPGPU_ERR_OOM, 0, lead);
-      std::vector<BatchPair> table(depth);
-      auto sync_or_fail = [&](Slot& sl) {
-        const hipError_t e = hipStreamSynchronize(gstream);
-        if (e == hipSuccess) return true;
-        fail(sl.w, ICPGPU_ERR_HIP, "lock-step batch: %s", hipGetErrorString(e));
-        failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
-        return false;
       };
-      int timed_pairs = 0;          // pairs of the launch whose events are outstanding
-      unsigned step_counter = 0;
+      static const bool stagger_on = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_STAGGER"); return !e || std::atoi(e) != 0; }();
+      const size_t total_groups = n_threads * groups_per_thread;
+      std::vector<Group> groups(groups_per_thread);
+      for (size_t gi = 0; gi < groups_per_thread; ++gi) {
+        Group& G = groups[gi];
+        G.ws = ws + gi * depth;
+        G.index = gi * n_threads + t;  // (a thread's groups are far apart: its first one starts early, its last one late)
+        G.lead = G.ws[0];
+        G.gstream = c->group_streams[G.index];
+        // (Measured and dropped in round 5: the sweeps on a stream of the LOWEST priority, so that the small kernels of another group's
+        // index build -- 1-5 ms per group on a busy chip, 0.4 ms on an idle one -- are dispatched ahead of the waiting sweep
+        // workgroups: 15-25 % SLOWER in every configuration, copies stalling for milliseconds; profiles/r05_batch_groups.txt.)
+        G.sstream = G.gstream;
+        G.slots.resize(depth);
+        G.table.resize(depth);
+        G.own.resize(depth);
+        for (size_t s2 = 0; s2 < depth; ++s2) {
+          G.slots[s2].w = G.ws[s2];
+          G.own[s2] = G.ws[s2]->stream;
+          G.ws[s2]->stream = G.gstream;  // one queue for the group: builds, sweeps and fitness sweeps are ordered by it
+        }
+        if (ensure(G.lead, G.lead->batch_table, depth * sizeof(BatchPair))) return failed(ICPGPU_ERR_OOM, 0, G.lead);
+      }
       static const bool bt_on = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_TIMING"); return e && std::atoi(e) != 0; }();
+      static const bool bt_trace = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_TRACE"); return e && std::atoi(e) != 0; }();
       double bt_fill = 0, bt_build = 0, bt_iter = 0;
       size_t bt_groups = 0, bt_steps = 0;
       struct BtPrint {
         const bool& on; double &f, &b, &i; size_t &g, &st; size_t t;
         ~BtPrint() { if (on && g) fprintf(stderr, "[icpgpu] batch thread %zu: %zu groups, %zu steps; per group: fill (H2D) %.3f ms, index builds %.3f ms, iterations + fitness %.3f ms\n", t, g, st, f / g, b / g, i / g); }
       } bt_print{bt_on, bt_fill, bt_build, bt_iter, bt_groups, bt_steps, t};
-      for (;;) {
-        const auto bt0 = std::chrono::steady_clock::now();
-        // (1) fill the group
-        size_t n_slots = 0;
-        while (n_slots < depth && !abort.load()) {
-          const size_t k = next.fetch_add(1);
-          if (k >= n_pairs) break;
-          Slot& sl = slots[n_slots];
-          sl.pair = k;
-          sl.lock = sl.wants = sl.wants_fit = sl.waiting = false;
-          int rc = load_pair(sl.w, k, /*sync=*/false);
-          if (!rc) rc = p2p_prepare(sl.w, sl.run, nullptr, nullptr, want_fitness, &results[k]);
-          if (rc) return failed(rc, k, sl.w);
-          ++n_slots;
-        }
-        if (n_slots == 0 || abort.load()) return;
-        const auto bt1 = std::chrono::steady_clock::now();
-        // (2) the target grids, every build's host round trips shared by the group
-        for (size_t i = 0; i < n_slots; ++i) {
-          Slot& sl = slots[i];
-          sl.gb = GridBuild{};
-          if (sl.run.phase == P2PRun::Done) continue;  // empty target
-          icpgpu_ctx* w = sl.w;
-          const int mode = w->params.nn_mode;
-          const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && w->tgt.n >= kGridMinTarget);
-          const double cut = std::sqrt((double)sl.run.thr) * (1.0 + 1e-6);
-          if (!want || !(sl.run.thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
-            w->grid.usable = w->grid.built = false;
-            continue;
+
+      // One non-blocking step of a group.  1: something moved, 0: nothing did, 2: the group is retired (no pairs left), < 0: failed
+      // (the thread's error is set).
+      auto group_step = [&](Group& G) -> int {
+        icpgpu_ctx* lead = G.lead;
+        hipStream_t gstream = G.gstream;
+        std::vector<Slot>& slots = G.slots;
+        std::vector<BatchPair>& table = G.table;
+        size_t& n_slots = G.n_slots;
+        auto bail = [&](int rc, size_t k, icpgpu_ctx* w) { failed(rc, k, w); return -1; };
+        // queue a marker behind everything the group's stream holds: the stage has drained once the mailbox carries its number
+        auto post_marker = [&]() -> int {
+          G.sync_seq = ++lead->post_seq;
+          if (launch_post_ints(static_cast<const int*>(lead->batch_table.ptr), 1, lead->h_post_dev, wire_seq(lead, G.sync_seq), gstream) != hipSuccess) {
+            fail(lead, ICPGPU_ERR_HIP, "lock-step batch: marker launch");
+            return bail(ICPGPU_ERR_HIP, slots[0].pair, lead);
           }
-          const int rc = gb_begin(w, sl.gb, w->tgt, w->tgt_version, cut, /*adapt=*/true, w->grid);
-          if (rc) return failed(rc, sl.pair, w);
+          return 0;
+        };
+        if (G.phase == Group::Fill) {
+          // (1) fill the group, ONE pair per step (a pair's host -> device copies occupy the thread for ~0.2 ms: the other
+          // groups' mailboxes are looked at in between)
+          if (n_slots == 0) {
+            G.bt0 = std::chrono::steady_clock::now();
+            // Ramp-up: groups that start together stay in phase -- all copying, then all building, then all sweeping, the chip idle
+            // through the first two -- so the FIRST fill of the job's g-th group takes (g + 1) / n of a full group: the small ones
+            // sweep (short steps, but on an otherwise idle chip) while the larger ones are still being copied in, and from then on
+            // the groups finish and refill at different times.
+            G.cap = depth;
+            if (!G.filled_once && stagger_on) G.cap = std::max<size_t>(1, (depth * (G.index + 1) + total_groups - 1) / total_groups);
+            G.filled_once = true;
+          }
+          bool full = n_slots == G.cap;
+          if (!full && !abort.load()) {
+            const size_t k = next.fetch_add(1);
+            if (k < n_pairs) {
+              Slot& sl = slots[n_slots];
+              sl.pair = k;
+              sl.lock = sl.wants = sl.wants_fit = sl.waiting = false;
+              int rc = load_pair(sl.w, k, /*sync=*/false);
+              if (!rc) rc = p2p_prepare(sl.w, sl.run, nullptr, nullptr, want_fitness, &results[k]);
+              if (rc) return bail(rc, k, sl.w);
+              ++n_slots;
+              if (n_slots < G.cap) return 1;
+            }
+            full = true;  // (or no pair left: the group goes with what it has)
+          }
+          if (n_slots == 0 || abort.load()) {
+            G.phase = Group::Retired;
+            return 2;
+          }
+          G.bt1 = std::chrono::steady_clock::now();
+          // (2) the target grids, every build's host round trips shared by the group
+          for (size_t i = 0; i < n_slots; ++i) {
+            Slot& sl = slots[i];
+            sl.gb = GridBuild{};
+            if (sl.run.phase == P2PRun::Done) continue;  // empty target
+            icpgpu_ctx* w = sl.w;
+            const int mode = w->params.nn_mode;
+            const bool want = mode == ICPGPU_NN_GRID || (mode == ICPGPU_NN_AUTO && w->tgt.n >= kGridMinTarget);
+            const double cut = std::sqrt((double)sl.run.thr) * (1.0 + 1e-6);
+            if (!want || !(sl.run.thr > 0.f) || !std::isfinite(cut) || cut > 1e6) {
+              w->grid.usable = w->grid.built = false;
+              continue;
+            }
+            const int rc = gb_begin(w, sl.gb, w->tgt, w->tgt_version, cut, /*adapt=*/true, w->grid);
+            if (rc) return bail(rc, sl.pair, w);
+          }
+          if (post_marker()) return -1;
+          G.phase = Group::Build;
+          G.idle_spins = 0;
+          return 1;
         }
-        for (;;) {
+        if (G.phase == Group::Build) {
           bool pending = false;
           for (size_t i = 0; i < n_slots; ++i) pending = pending || slots[i].gb.state != GridBuild::Done;
-          if (!pending) break;
-          if (!sync_or_fail(slots[0])) return;
-          for (size_t i = 0; i < n_slots; ++i)
-            if (slots[i].gb.state != GridBuild::Done) {
-              const int rc = gb_advance(slots[i].w, slots[i].gb);
-              if (rc) return failed(rc, slots[i].pair, slots[i].w);
+          if (pending) {
+            // the stage's read-backs (hipMemcpyAsync into pinned memory, queued by the builds) have landed once the marker queued
+            // behind them has: polled in host memory, no runtime call and no sleeping wait
+            if ((lead->h_post[1] >> 24) != G.sync_seq) {
+              if ((++G.idle_spins & 0xFFFu) == 0) {
+                const hipError_t q = hipStreamQuery(gstream);
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                  fail(slots[0].w, ICPGPU_ERR_HIP, "lock-step batch: %s", hipGetErrorString(q));
+                  return bail(ICPGPU_ERR_HIP, slots[0].pair, slots[0].w);
+                }
+                if (q == hipSuccess && (lead->h_post[1] >> 24) != G.sync_seq) {  // drained without the marker: its pair was torn or lost -- fall back to the stream's word
+                  std::atomic_thread_fence(std::memory_order_acquire);
+                } else if (q == hipErrorNotReady) {
+                  return 0;
+                }
+              } else {
+                return 0;
+              }
             }
-        }
-        const auto bt2 = std::chrono::steady_clock::now();
-        // (3) who can iterate in lock-step; the others start their own first sweep
-        size_t live = 0;
-        for (size_t i = 0; i < n_slots; ++i) {
-          Slot& sl = slots[i];
-          if (sl.run.phase == P2PRun::Done) continue;
-          icpgpu_ctx* w = sl.w;
-          ++live;
-          const int n_s = (int)w->src.n;
-          const int flags = grid_flags(w->grid, false);
-          sl.lock = grid_ready(w) && n_s > 0 && w->src.n < kOrderSourceMin && source_order_mode() != 1 &&
-                    grid_search_batchable(n_s, flags) && sl.run.thr <= w->grid.cutoff * w->grid.cutoff;
-          sl.run.phase = P2PRun::Iterating;
-          sl.run.t_issue = std::chrono::steady_clock::now();
-          if (!sl.lock) {
-            int rc = ensure_source_order(w, sl.run.thr);
-            if (!rc) rc = sweep_issue(w, to_xform(sl.run.final_T), sl.run.thr, false, sl.run.ticket);
-            if (rc) return failed(rc, sl.pair, w);
-            continue;
+            std::atomic_thread_fence(std::memory_order_acquire);
+            G.idle_spins = 0;
+            for (size_t i = 0; i < n_slots; ++i)
+              if (slots[i].gb.state != GridBuild::Done) {
+                const int rc = gb_advance(slots[i].w, slots[i].gb);
+                if (rc) return bail(rc, slots[i].pair, slots[i].w);
+              }
+            pending = false;
+            for (size_t i = 0; i < n_slots; ++i) pending = pending || slots[i].gb.state != GridBuild::Done;
+            if (pending) {
+              if (post_marker()) return -1;
+              return 1;
+            }
           }
-          if (w->src_grid.version != w->src_version) w->src_grid.built = w->src_grid.usable = false;
-          const int blocks = grid_search_blocks(n_s);
-          int rc = ensure(w, w->partials, (size_t)blocks * kReduceTerms * sizeof(double));
-          bool use_prev = false;
-          if (!rc) rc = prev_neighbours(w, w->grid, w->src.data(), n_s, flags, sl.prev, use_prev);  // (allocates; the first sweep is cold)
-          if (rc) return failed(rc, sl.pair, w);
-          w->prev.valid = w->tile_seed.valid = false;
-          sl.pack = (flags & kGridPackShortRows) != 0;
-          if (!rc) rc = ensure(w, w->keys, (size_t)n_s * sizeof(unsigned long long));
-          if (!rc) rc = ensure(w, w->grid.unmatched, (size_t)(n_s + 1) * sizeof(int));
-          if (rc) return failed(rc, sl.pair, w);
-          BatchPair& bp = table[i];
-          bp.keys = static_cast<unsigned long long*>(w->keys.ptr);
-          bp.unmatched = static_cast<int*>(w->grid.unmatched.ptr);
-          bp.unmatched_count = bp.unmatched + n_s;
-          bp.r_max_open = std::min(4 * w->grid.g.r_max, 48);
-          bp.src = w->src.data();
-          bp.sorted = static_cast<const float4*>(w->grid.sorted.ptr);
-          bp.cell_start = static_cast<const int*>(w->grid.cell_start.ptr);
-          bp.partials = static_cast<double*>(w->partials.ptr);
-          bp.prev_nn = sl.prev;
-          bp.flags = w->h_flags_dev;
-          bp.g = w->grid.g;
-          bp.accept_thr = sl.run.thr;
-          bp.n_s = n_s;
-          bp.qpw = grid_search_qpw(n_s);
-          bp.xcd_map = 0;
-          bp.blocks = blocks;
-          sl.wants = true;
-        }
-        // one row-walk variant for the whole group (the packed walk of sparse targets is a speed choice, the neighbours are the
-        // same): the majority's, so that a step is ONE launch
-        {
-          int n_lock = 0, n_pack = 0;
-          for (size_t i = 0; i < n_slots; ++i)
-            if (slots[i].lock) {
-              ++n_lock;
-              n_pack += slots[i].pack ? 1 : 0;
+          G.bt2 = std::chrono::steady_clock::now();
+          // (3) who can iterate in lock-step; the others start their own first sweep
+          G.live = 0;
+          for (size_t i = 0; i < n_slots; ++i) {
+            Slot& sl = slots[i];
+            if (sl.run.phase == P2PRun::Done) continue;
+            icpgpu_ctx* w = sl.w;
+            ++G.live;
+            const int n_s = (int)w->src.n;
+            const int flags = grid_flags(w->grid, false);
+            sl.lock = grid_ready(w) && n_s > 0 && w->src.n < kOrderSourceMin && source_order_mode() != 1 &&
+                      grid_search_batchable(n_s, flags) && sl.run.thr <= w->grid.cutoff * w->grid.cutoff;
+            sl.run.phase = P2PRun::Iterating;
+            sl.run.t_issue = std::chrono::steady_clock::now();
+            if (!sl.lock) {
+              int rc = ensure_source_order(w, sl.run.thr);
+              if (!rc) rc = sweep_issue(w, to_xform(sl.run.final_T), sl.run.thr, false, sl.run.ticket);
+              if (rc) return bail(rc, sl.pair, w);
+              continue;
             }
-          const bool group_pack = 2 * n_pack >= n_lock && n_pack > 0;
-          for (size_t i = 0; i < n_slots; ++i) slots[i].pack = group_pack;
-        }
-        if (hipMemcpyAsync(lead->batch_table.ptr, table.data(), n_slots * sizeof(BatchPair), hipMemcpyHostToDevice, gstream) != hipSuccess) {
-          fail(lead, ICPGPU_ERR_HIP, "lock-step batch: table upload");
-          return failed(ICPGPU_ERR_HIP, slots[0].pair, lead);
+            if (w->src_grid.version != w->src_version) w->src_grid.built = w->src_grid.usable = false;
+            const int blocks = grid_search_blocks(n_s);
+            int rc = ensure(w, w->partials, (size_t)blocks * kReduceTerms * sizeof(double));
+            bool use_prev = false;
+            if (!rc) rc = prev_neighbours(w, w->grid, w->src.data(), n_s, flags, sl.prev, use_prev);  // (allocates; the first sweep is cold)
+            if (rc) return bail(rc, sl.pair, w);
+            w->prev.valid = w->tile_seed.valid = false;
+            sl.pack = (flags & kGridPackShortRows) != 0;
+            if (!rc) rc = ensure(w, w->keys, (size_t)n_s * sizeof(unsigned long long));
+            if (!rc) rc = ensure(w, w->grid.unmatched, (size_t)(n_s + 1) * sizeof(int));
+            if (rc) return bail(rc, sl.pair, w);
+            BatchPair& bp = table[i];
+            bp.keys = static_cast<unsigned long long*>(w->keys.ptr);
+            bp.unmatched = static_cast<int*>(w->grid.unmatched.ptr);
+            bp.unmatched_count = bp.unmatched + n_s;
+            bp.r_max_open = std::min(4 * w->grid.g.r_max, 48);
+            bp.src = w->src.data();
+            bp.sorted = static_cast<const float4*>(w->grid.sorted.ptr);
+            bp.cell_start = static_cast<const int*>(w->grid.cell_start.ptr);
+            bp.partials = static_cast<double*>(w->partials.ptr);
+            bp.prev_nn = sl.prev;
+            bp.flags = w->h_flags_dev;
+            bp.g = w->grid.g;
+            bp.accept_thr = sl.run.thr;
+            bp.n_s = n_s;
+            bp.qpw = grid_search_qpw(n_s);
+            bp.xcd_map = 0;
+            bp.blocks = blocks;
+            sl.wants = true;
+          }
+          // one row-walk variant for the whole group (the packed walk of sparse targets is a speed choice, the neighbours are the
+          // same): the majority's, so that a step is ONE launch
+          {
+            int n_lock = 0, n_pack = 0;
+            for (size_t i = 0; i < n_slots; ++i)
+              if (slots[i].lock) {
+                ++n_lock;
+                n_pack += slots[i].pack ? 1 : 0;
+              }
+            const bool group_pack = 2 * n_pack >= n_lock && n_pack > 0;
+            for (size_t i = 0; i < n_slots; ++i) slots[i].pack = group_pack;
+          }
+          if (hipMemcpyAsync(lead->batch_table.ptr, table.data(), n_slots * sizeof(BatchPair), hipMemcpyHostToDevice, gstream) != hipSuccess) {
+            fail(lead, ICPGPU_ERR_HIP, "lock-step batch: table upload");
+            return bail(ICPGPU_ERR_HIP, slots[0].pair, lead);
+          }
+          // the sweeps' stream takes over behind everything the builds' stream holds (the last build stage and the table are queued, not done)
+          if (G.sstream != gstream &&
+              (hipEventRecord(lead->ev[0], gstream) != hipSuccess || hipStreamWaitEvent(G.sstream, lead->ev[0], 0) != hipSuccess)) {
+            fail(lead, ICPGPU_ERR_HIP, "lock-step batch: stream hand-over");
+            return bail(ICPGPU_ERR_HIP, slots[0].pair, lead);
+          }
+          G.phase = Group::Iterate;
+          G.idle_spins = 0;
+          return 1;
         }
         // (4) iterate: one search launch + one reduction launch per step and row-walk class for the whole group
-        unsigned idle_spins = 0;
-        while (live > 0) {
+        if (G.live > 0) {
           // a step is launched when no lock-step sweep of the group is in flight any more (the step IS the batch; pairs in
           // their fitness sweep or on the single-pair path do not hold it up)
           bool lock_in_flight = false;
@@ -330,7 +453,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
               unsigned int* buf = nullptr;
               if (prev_neighbours(w, w->grid, w->src.data(), (int)w->src.n, grid_flags(w->grid, false), buf, use_prev) || buf != sl.prev) {
                 fail(w, ICPGPU_ERR_HIP, "lock-step batch: previous-neighbour buffer moved");
-                return failed(ICPGPU_ERR_HIP, sl.pair, w);
+                return bail(ICPGPU_ERR_HIP, sl.pair, w);
               }
               step.T[n_act] = to_xform(sl.run.final_T);
               step.seq[n_act] = wire_seq(w, ++w->sums_seq);
@@ -355,9 +478,9 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
                 sl.run.ticket.red_n = (int)w->src.n;
                 sl.run.ticket.T = step.T[n_act];
                 sl.run.ticket.thr = FLT_MAX;
-                if (hipMemsetAsync(table[i].unmatched_count, 0, sizeof(int), gstream) != hipSuccess) {
+                if (hipMemsetAsync(table[i].unmatched_count, 0, sizeof(int), G.sstream) != hipSuccess) {
                   fail(w, ICPGPU_ERR_HIP, "lock-step batch: memset");
-                  return failed(ICPGPU_ERR_HIP, sl.pair, w);
+                  return bail(ICPGPU_ERR_HIP, sl.pair, w);
                 }
               }
               ++n_act;
@@ -366,29 +489,29 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
             bt_steps += 1;
             // kernel timing, sampled like the single-pair path's: a launch's HIP-event time / its pairs = one pair's sweep
             auto take_timing = [&](bool wait) {
-              if (!timed_pairs) return;
+              if (!G.timed_pairs) return;
               if (wait) (void)hipEventSynchronize(lead->ev[3]);
               else if (hipEventQuery(lead->ev[3]) != hipSuccess) return;
               float ms = 0.f;
               if (hipEventElapsedTime(&ms, lead->ev[2], lead->ev[3]) == hipSuccess) {
                 lead->prof.grid_ms += (double)ms;  // (summed over the launch's pairs: grid_ms / grid_timed stays "per pair and sweep")
-                lead->prof.grid_timed += (uint64_t)timed_pairs;
+                lead->prof.grid_timed += (uint64_t)G.timed_pairs;
               }
-              timed_pairs = 0;
+              G.timed_pairs = 0;
             };
             take_timing(false);
-            const bool timed = kind == 0 && timed_pairs == 0 && (step_counter++ % 5u) == 0;
-            if (timed) (void)hipEventRecord(lead->ev[2], gstream);
+            const bool timed = kind == 0 && G.timed_pairs == 0 && (G.step_counter++ % 5u) == 0;
+            if (timed) (void)hipEventRecord(lead->ev[2], G.sstream);
             const BatchPair* d_table = static_cast<const BatchPair*>(lead->batch_table.ptr);
-            hipError_t e = launch_nn_grid_search_batch(d_table, step, n_act, max_blocks, group_pack, kind == 1, gstream);
+            hipError_t e = launch_nn_grid_search_batch(d_table, step, n_act, max_blocks, group_pack, kind == 1, G.sstream);
             if (timed) {
-              (void)hipEventRecord(lead->ev[3], gstream);
-              timed_pairs = n_act;
+              (void)hipEventRecord(lead->ev[3], G.sstream);
+              G.timed_pairs = n_act;
             }
-            if (e == hipSuccess && kind == 0) e = launch_reduce_final_batch(d_table, step, n_act, gstream);
+            if (e == hipSuccess && kind == 0) e = launch_reduce_final_batch(d_table, step, n_act, G.sstream);
             if (e != hipSuccess) {
               fail(lead, ICPGPU_ERR_HIP, "lock-step batch launch: %s", hipGetErrorString(e));
-              return failed(ICPGPU_ERR_HIP, slots[step.slot[0]].pair, lead);
+              return bail(ICPGPU_ERR_HIP, slots[step.slot[0]].pair, lead);
             }
             if (kind == 1) {
               // per pair: the few points the grid left unmatched (completed on the device), then the keys-path reduction into
@@ -398,19 +521,19 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
                 icpgpu_ctx* w = sl.w;
                 const BatchPair& bp = table[step.slot[a2]];
                 hipError_t e2 = launch_nn_brute_few(w->src.data(), bp.unmatched, bp.unmatched_count, 0, w->tgt.data(), (int)w->tgt.n,
-                                                    step.T[a2], bp.keys, reinterpret_cast<int*>(w->h_sums_dev + 20), gstream);
+                                                    step.T[a2], bp.keys, reinterpret_cast<int*>(w->h_sums_dev + 20), G.sstream);
                 int rc2 = e2 == hipSuccess ? ensure(w, w->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)) : ICPGPU_ERR_HIP;
                 if (!rc2 && launch_reduce(w->src.data(), (int)w->src.n, w->tgt.data(), bp.keys, step.T[a2], FLT_MAX,
-                                          static_cast<double*>(w->partials.ptr), w->h_sums_dev, w->h_flags_dev, step.seq[a2], gstream) != hipSuccess)
+                                          static_cast<double*>(w->partials.ptr), w->h_sums_dev, w->h_flags_dev, step.seq[a2], G.sstream) != hipSuccess)
                   rc2 = ICPGPU_ERR_HIP;
                 if (rc2) {
                   fail(w, rc2, "lock-step batch: fitness sweep");
-                  return failed(rc2, sl.pair, w);
+                  return bail(rc2, sl.pair, w);
                 }
               }
             }
           }
-          // wait for something to come back, then take everything that has
+          // take everything that has come back
           bool progressed = false;
           for (size_t i = 0; i < n_slots; ++i) {
             Slot& sl = slots[i];
@@ -420,52 +543,86 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
             sl.waiting = false;
             int deferred = 0;
             const int rc = p2p_advance(sl.w, sl.run, (sl.lock && sl.run.phase == P2PRun::Iterating) ? &deferred : nullptr);
-            if (rc) return failed(rc, sl.pair, sl.w);
+            if (rc) return bail(rc, sl.pair, sl.w);
             sl.wants = deferred == 1;
             sl.wants_fit = deferred == 2;
-            if (sl.run.phase == P2PRun::Done) --live;
+            if (sl.run.phase == P2PRun::Done) --G.live;
             progressed = true;
           }
           if (progressed) {
-            idle_spins = 0;
-            continue;
-          }
-          if ((++idle_spins & 0x3FFu) == 0) {  // nothing moved for a while: a faulted or hung kernel must not keep us here
-            const auto now = std::chrono::steady_clock::now();
-            const hipError_t q = hipStreamQuery(gstream);
-            for (size_t i = 0; i < n_slots; ++i) {
-              Slot& sl = slots[i];
-              if (sl.run.phase != P2PRun::Iterating && sl.run.phase != P2PRun::Fitness) continue;
-              if (q != hipSuccess && q != hipErrorNotReady) {
-                fail(sl.w, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
-                return failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+            G.idle_spins = 0;
+            if (G.live > 0) return 1;
+          } else {
+            if ((++G.idle_spins & 0x3FFu) == 0) {  // nothing moved for a while: a faulted or hung kernel must not keep us here
+              const auto now = std::chrono::steady_clock::now();
+              hipError_t q = hipStreamQuery(G.sstream);
+              if (q == hipSuccess || q == hipErrorNotReady) {
+                const hipError_t q2 = hipStreamQuery(gstream);
+                if (q2 != hipSuccess && q2 != hipErrorNotReady) q = q2;
               }
-              if (std::chrono::duration<double, std::milli>(now - sl.run.t_issue).count() > timeout_ms) {
-                fail(sl.w, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", timeout_ms);
-                return failed(ICPGPU_ERR_HIP, sl.pair, sl.w);
+              for (size_t i = 0; i < n_slots; ++i) {
+                Slot& sl = slots[i];
+                if (sl.run.phase != P2PRun::Iterating && sl.run.phase != P2PRun::Fitness) continue;
+                if (q != hipSuccess && q != hipErrorNotReady) {
+                  fail(sl.w, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+                  return bail(ICPGPU_ERR_HIP, sl.pair, sl.w);
+                }
+                if (std::chrono::duration<double, std::milli>(now - sl.run.t_issue).count() > timeout_ms) {
+                  fail(sl.w, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", timeout_ms);
+                  return bail(ICPGPU_ERR_HIP, sl.pair, sl.w);
+                }
               }
             }
+            return 0;
           }
-#if defined(__x86_64__)
-          __builtin_ia32_pause();
-#endif
         }
-        if (timed_pairs) {  // (the group is finished: its last timed launch is, too)
+        // the group is finished
+        if (G.timed_pairs) {  // (its last timed launch is, too)
           float ms = 0.f;
           if (hipEventSynchronize(lead->ev[3]) == hipSuccess && hipEventElapsedTime(&ms, lead->ev[2], lead->ev[3]) == hipSuccess) {
             lead->prof.grid_ms += (double)ms;
-            lead->prof.grid_timed += (uint64_t)timed_pairs;
+            lead->prof.grid_timed += (uint64_t)G.timed_pairs;
           }
-          timed_pairs = 0;
+          G.timed_pairs = 0;
+        }
+        if (bt_trace) {  // development flavour, ICPGPU_BATCH_TRACE=1: the round's phase boundaries, ms after the call started
+          const auto ms = [&](std::chrono::steady_clock::time_point tp) { return std::chrono::duration<double, std::milli>(tp - t_call).count(); };
+          fprintf(stderr, "[icpgpu] batch trace: thread %zu group %zu: %zu pairs | fill %.2f .. %.2f | builds .. %.2f | sweeps .. %.2f\n", t, G.index, n_slots,
+                  ms(G.bt0), ms(G.bt1), ms(G.bt2), ms(std::chrono::steady_clock::now()));
         }
         if (bt_on) {
           const auto bt3 = std::chrono::steady_clock::now();
-          bt_fill += std::chrono::duration<double, std::milli>(bt1 - bt0).count();
-          bt_build += std::chrono::duration<double, std::milli>(bt2 - bt1).count();
-          bt_iter += std::chrono::duration<double, std::milli>(bt3 - bt2).count();
+          bt_fill += std::chrono::duration<double, std::milli>(G.bt1 - G.bt0).count();
+          bt_build += std::chrono::duration<double, std::milli>(G.bt2 - G.bt1).count();
+          bt_iter += std::chrono::duration<double, std::milli>(bt3 - G.bt2).count();
           bt_groups += 1;
         }
+        n_slots = 0;
+        G.phase = Group::Fill;
+        return 1;
+      };
+      // ONE group of the thread fills at a time (the others wait their turn): its pairs are complete and iterating while the next
+      // group's are still being copied in, so the thread's groups run staggered -- copies under sweeps -- instead of in phase
+      size_t fill_owner = 0;
+      for (size_t retired = 0; retired < groups.size();) {
+        bool moved = false;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+          Group& G = groups[gi];
+          if (G.phase == Group::Retired) continue;
+          if (G.phase == Group::Fill && gi != fill_owner) {
+            if (groups[fill_owner].phase == Group::Fill) continue;
+            fill_owner = gi;
+          }
+          const int r = group_step(G);
+          if (r < 0) return;
+          if (r == 2) ++retired;
+          moved = moved || r != 0;
+        }
+#if defined(__x86_64__)
+        if (!moved) __builtin_ia32_pause();
+#endif
       }
+      return;
     }
     std::vector<P2PRun> runs(depth);
     std::vector<size_t> pair_of(depth, 0);
@@ -547,6 +704,12 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.grid_adopted += p.grid_adopted;
     if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;
     std::memset(&p, 0, sizeof(p));
+  }
+  {
+    static const bool trace = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_TRACE"); return e && std::atoi(e) != 0; }();
+    if (trace)
+      fprintf(stderr, "[icpgpu] batch trace: call of %zu pairs took %.2f ms; device allocations so far in this process: %llu, %.2f ms of host time\n", n_pairs,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), g_alloc_calls.load(), g_alloc_us.load() * 1e-3);
   }
   for (const ThreadError& e : errors)  // the first failure in thread order (each thread stops at its first)
     if (e.code != ICPGPU_OK) {

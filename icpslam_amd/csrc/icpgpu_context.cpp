@@ -24,6 +24,7 @@ int fail(icpgpu_ctx* c, int code, const char* fmt, ...) {
 }
 
 
+extern std::atomic<unsigned long long> g_alloc_calls, g_alloc_us;
 int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes) {
   if (b.external) {
     b.ptr = nullptr;
@@ -31,6 +32,7 @@ int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes) {
     b.external = false;
   }
   if (bytes <= b.cap) return ICPGPU_OK;
+  const auto t0 = std::chrono::steady_clock::now();
   if (b.ptr) HIP_TRY(c, hipFree(b.ptr));
   b.ptr = nullptr;
   b.cap = 0;
@@ -38,8 +40,13 @@ int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes) {
   if (want < 256) want = 256;
   HIP_TRY(c, hipMalloc(&b.ptr, want));
   b.cap = want;
+  g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+  g_alloc_us.fetch_add((unsigned long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
   return ICPGPU_OK;
 }
+// (process-wide: device allocations made through ensure() and the host microseconds they took -- hipFree synchronises the device;
+//  read by the batch scheduler's trace, ICPGPU_BATCH_TRACE in the development flavour)
+std::atomic<unsigned long long> g_alloc_calls{0}, g_alloc_us{0};
 
 void release(DeviceBuf& b) {
   if (b.ptr && !b.external) (void)hipFree(b.ptr);
@@ -449,6 +456,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
     if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->ev_ring)
     if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st : c->group_streams) (void)hipStreamDestroy(st);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return ICPGPU_OK;

@@ -141,12 +141,24 @@ int gb_issue_count(icpgpu_ctx* c, GridBuild& b) {
     return ICPGPU_OK;
   }
   const long long ncells = nx * ny * nz;
-  const int nb = (int)((ncells + kScanItems - 1) / kScanItems);
   int rc;
-  if ((rc = ensure(c, G.cell_start, (size_t)(ncells + 1) * sizeof(int)))) return rc;
+  // The cell table is the one buffer of a pair whose size depends on the pair's CONTENT (its box and cell size).  The workers
+  // of a batch are dealt different pairs in every call, so each of them kept meeting a table larger than any it had held --
+  // a hipFree (which synchronises the device) + hipMalloc in the middle of a running batch, for a dozen calls in a row (traced
+  // in round 5: 17-19 ms for a call with reallocations, 12 ms without).  Workers therefore size their tables by the largest
+  // ANY worker of the batch has needed, with room to spare: one growth per worker, in the call after the first.
+  size_t cells_alloc = (size_t)(ncells + 1);
+  if (c->shared_table_cells) {
+    size_t seen = c->shared_table_cells->load(std::memory_order_relaxed);
+    while (cells_alloc > seen && !c->shared_table_cells->compare_exchange_weak(seen, cells_alloc, std::memory_order_relaxed)) {}
+    const size_t floor_cells = std::max(seen, cells_alloc);
+    cells_alloc = std::min<size_t>(floor_cells + floor_cells / 4, (size_t)kMaxGridCells + 1);
+    cells_alloc = std::max(cells_alloc, (size_t)(ncells + 1));
+  }
+  if ((rc = ensure(c, G.cell_start, cells_alloc * sizeof(int)))) return rc;
   if ((rc = ensure(c, G.cell_of_point, (size_t)n_t * sizeof(int)))) return rc;
   if ((rc = ensure(c, G.rank, (size_t)n_t * sizeof(int)))) return rc;
-  if ((rc = ensure(c, G.block_sums, (size_t)(nb + 1) * sizeof(int)))) return rc;
+  if ((rc = ensure(c, G.block_sums, (cells_alloc / kScanItems + 2) * sizeof(int)))) return rc;
   HIP_TRY(c, launch_grid_count(b.cloud->data(), n_t, g, static_cast<int*>(G.cell_of_point.ptr), static_cast<int*>(G.rank.ptr),
                                static_cast<int*>(G.cell_start.ptr), static_cast<int*>(G.block_sums.ptr), d_ints + 6, c->stream));
   if (!b.post) HIP_TRY(c, hipMemcpyAsync(c->h_ints + 6, d_ints + 6, kGridStatInts * sizeof(int), hipMemcpyDeviceToHost, c->stream));

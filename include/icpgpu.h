@@ -44,7 +44,8 @@ extern "C" {
  * Production switches, read by every build of libicpgpu.so (none of them changes a result):
  *   ICPGPU_WAIT_TIMEOUT_MS        deadline of every host wait for the device (mailbox, gather); default 30000
  *   ICPGPU_BATCH_THREADS          host threads of icpgpu_align_batch (default: chosen from the CPUs this process may use)
- *   ICPGPU_BATCH_DEPTH            alignments each of those threads keeps in flight
+ *   ICPGPU_BATCH_DEPTH            pairs per lock-step group (point-to-point; default 8) / alignments a thread keeps in flight
+ *   ICPGPU_BATCH_GROUPS           lock-step groups in flight on the GPU, over all host threads together (default 8)
  *   ICPGPU_RECOGNISE=0            icpgpu_set_target / icpgpu_set_source always upload (no content recognition)
  *   ICPGPU_GICP_SERVER=0          every GICP cost evaluation is its own kernel launch (no resident evaluation server)
  *   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the resident device solver (1), or whichever the context

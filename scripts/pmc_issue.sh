@@ -13,8 +13,11 @@ for S in $SIZES; do
   python $R/scripts/count_candidates.py $S > $O/cand_$S.txt 2>&1
 done
 python - <<PY
-import csv, glob, collections, json, os
-out = {"_how": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ... --kernel-trace (own pass) over scripts/one_align.py <size> grid: mean per launch of "
+import csv, glob, collections, json, os, sys
+sys.path.insert(0, "$R/scripts")
+from kernel_hash import search_kernel_source_sha256
+out = {"kernel_source_sha256": search_kernel_source_sha256(),
+       "_how": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ... --kernel-trace (own pass) over scripts/one_align.py <size> grid: mean per launch of "
                "nn_quad_kernel<false,true,*> over the ten sweeps of each alignment; candidates = target points evaluated per launch "
                "(icpgpu_count_candidates, scripts/count_candidates.py); scripts/pmc_issue.sh"}
 for S in "$SIZES".split():

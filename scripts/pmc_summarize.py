@@ -3,6 +3,8 @@
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE
 reports half of a wide coalesced read (x2); WRITE_SIZE is left uncorrected."""
 import csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_hash import search_kernel_source_sha256
 
 root, size = sys.argv[1], sys.argv[2]
 KEY = "x".join(f"{int(v) // 1000}k" for v in size.split("x"))  # bench.py workload name, e.g. 200kx200k
@@ -36,7 +38,8 @@ def per_launch(mode, ctr):
 res = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (with --kernel-trace only) over "
                f"scripts/one_align.py {size} {{grid,brute}}; mean per launch of the named kernel. Units: the counters are in "
                "KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); "
-               "WRITE_SIZE is uncorrected (uncalibrated per the guide).", KEY: {}}
+               "WRITE_SIZE is uncorrected (uncalibrated per the guide).",
+       "kernel_source_sha256": search_kernel_source_sha256(), KEY: {}}
 blk = res[KEY]
 for mode in ("grid", "brute"):
     f, nf = per_launch(mode, "FETCH_SIZE")
