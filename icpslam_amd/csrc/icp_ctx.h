@@ -386,6 +386,24 @@ struct P2PRun {
   std::chrono::steady_clock::time_point t_start, t_issue;
 };
 
+// A GICP registration as a resumable run (icpgpu_gicp.cpp: gicp_run_begin / gicp_run_step): the counterpart of P2PRun for the
+// solver the reference instantiates, so that one host thread of icpgpu_align_batch keeps several registrations in flight.
+struct GicpRun {
+  enum Phase { Idle, Blocking, CovGrid, Solve, Fitness, Done } phase = Idle;
+  float guess[16], transformation[16], previous[16];
+  float thr = 0.f, thr_excl = 0.f;
+  int nr = 0, state = ICPGPU_NOT_CONVERGED, want_fitness = 0, cov_stage = 0;
+  bool converged = false, local = false;
+  unsigned n_corr = 0;
+  double mse = 0.0;
+  GridBuild gb;
+  unsigned long long marker = 0, seq0 = 0;
+  unsigned polls = 0;
+  SweepTicket ticket;
+  icpgpu_result* res = nullptr;
+  std::chrono::steady_clock::time_point t_start, t_issue;
+};
+
 // ---- helpers that cross unit boundaries -------------------------------------------------------------------------------------
 // icpgpu_context.cpp
 int fail(icpgpu_ctx* c, int code, const char* fmt, ...);
@@ -447,5 +465,7 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
 // icpgpu_gicp.cpp
 int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version);
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res);
+int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res);
+int gicp_run_step(icpgpu_ctx* c, GicpRun& r);  // < 0 error, 0 nothing yet, 1 moved on (r.phase == GicpRun::Done: finished)
 
 }  // namespace icpgpu_impl

@@ -82,11 +82,19 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   // group iterates); results are bit-identical to icpgpu_align's (same kernels' bodies, same workgroup -> point mapping).
   static const bool lockstep_on = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_LOCKSTEP"); return !e || std::atoi(e) != 0; }();
   const bool lockstep = lockstep_on && !gicp;
-  size_t n_threads = batch_threads(c, gicp ? 8 : 4), depth = 1;
+  // GICP: resumable runs leave the host free (two threads x four runs measured 1.72k pairs/s on 13k-point clouds, one x eight 1.6-1.7k,
+  // eight x one 1.5k: profiles/r05_gicp_batch.txt); without the device solver every run is a blocking host loop and wants its own thread
+  const bool gicp_runs = gicp && gicp_device_solver_mode() != 0 && c->gicp_device_ok;
+  size_t n_threads = batch_threads(c, gicp ? (gicp_runs ? 2 : 8) : 4), depth = 1;
   if (!gicp) {
     if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
     else depth = lockstep ? 8 : std::max<size_t>(2, (8 + n_threads - 1) / n_threads);
     if (lockstep) depth = std::min<size_t>(depth, (size_t)kBatchMax);
+  } else {
+    // GICP: kGicpRunsInFlight resumable runs over all threads (each keeps its solver's workgroups resident: eight of them, one
+    // per XCD, is what the chip holds with room for everybody's searches -- kMaxServerWorkers); ICPGPU_BATCH_DEPTH = runs per thread
+    if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
+    else depth = std::max<size_t>(1, (kMaxServerWorkers + n_threads - 1) / n_threads);
   }
   n_threads = std::min(n_threads, n_pairs);
   depth = std::min(depth, (n_pairs + n_threads - 1) / n_threads);
@@ -159,19 +167,49 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       // Every GICP worker's BFGS runs keep its workgroups resident and a host thread spinning.  8 workers fit the chip
       // with room for everybody's searches; 16 were measured 5x SLOWER than single launches (servers wait for slots other
       // servers hold until their 50 ms patience runs out).
-      ws[s]->gicp_server_allowed = n_threads <= kMaxServerWorkers;
+      ws[s]->gicp_server_allowed = n_threads * (gicp ? depth : 1) <= 2 * kMaxServerWorkers;
       // ... and each worker's evaluations get their share of the ~512 workgroups of that size the chip holds at once (64
       // apiece for 8 workers, as measured in round 1; a lone alignment uses up to 256)
-      ws[s]->gicp_blocks_most = std::max(16, std::min(kGicpDirectBlocks, 512 / (int)std::max<size_t>(1, n_threads)));
+      ws[s]->gicp_blocks_most = std::max(16, std::min(kGicpDirectBlocks, 512 / (int)std::max<size_t>(1, n_threads * (gicp ? depth : 1))));
     }
-    if (gicp) {  // one blocking alignment after the other
-      icpgpu_ctx* w = ws[0];
+    if (gicp) {
+      // GICP: `depth` resumable runs per thread, round-robin (GicpRun, icpgpu_gicp.cpp): the thread queues a run's next stage when
+      // its awaited result has arrived and looks at the others meanwhile -- until round 5 it was ONE blocking alignment per
+      // thread, its host spinning through every inner minimisation.  A run that cannot be resumable (no device solver on its
+      // context, or the solver gave up) is one blocking alignment inside its step.
+      std::vector<GicpRun> gruns(depth);
+      std::vector<size_t> pair_of(depth, 0);
+      bool exhausted = false;
       for (;;) {
-        const size_t k = next.fetch_add(1);
-        if (k >= n_pairs || abort.load()) return;
-        int rc = load_pair(w, k);
-        if (!rc) rc = align_gicp(w, nullptr, nullptr, want_fitness, &results[k]);
-        if (rc) return failed(rc, k, w);
+        bool progressed = false;
+        size_t in_flight = 0;
+        for (size_t s2 = 0; s2 < depth; ++s2) {
+          GicpRun& r = gruns[s2];
+          icpgpu_ctx* w = ws[s2];
+          if (r.phase == GicpRun::Idle || r.phase == GicpRun::Done) {
+            if (exhausted || abort.load()) continue;
+            const size_t k = next.fetch_add(1);
+            if (k >= n_pairs) {
+              exhausted = true;
+              continue;
+            }
+            pair_of[s2] = k;
+            int rc = load_pair(w, k, /*sync=*/false);
+            if (!rc) rc = gicp_run_begin(w, r, want_fitness, &results[k]);
+            if (rc) return failed(rc, k, w);
+            progressed = true;
+            if (r.phase != GicpRun::Done) ++in_flight;
+          } else {
+            const int st = gicp_run_step(w, r);
+            if (st < 0) return failed(st, pair_of[s2], w);
+            progressed = progressed || st > 0;
+            if (r.phase != GicpRun::Done) ++in_flight;
+          }
+        }
+        if (in_flight == 0 && (exhausted || abort.load())) return;
+#if defined(__x86_64__)
+        if (!progressed) __builtin_ia32_pause();
+#endif
       }
     }
     const double timeout_ms = wait_timeout_ms();
@@ -701,6 +739,8 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.targets_recognised += p.targets_recognised;
     c->prof.brute_bound_violations += p.brute_bound_violations;
     c->prof.gicp_device_solves += p.gicp_device_solves;
+    c->prof.gicp_host_solves += p.gicp_host_solves;
+    c->prof.sources_adopted += p.sources_adopted;
     c->prof.grid_adopted += p.grid_adopted;
     if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;
     std::memset(&p, 0, sizeof(p));

@@ -26,9 +26,14 @@ Xform xform_from_f16(const float f[16]) {
   return x;
 }
 
-// per-point covariances of `cloud` (20-NN in its own grid); cached per cloud version
-int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version) {
-  if (cov_version == version && cov.ptr) return ICPGPU_OK;
+// per-point covariances of `cloud` (20-NN in its own grid); cached per cloud version.  In two halves, so that a resumable run
+// (GicpRun, below) can take the grid build through its host round trips without blocking: cov_grid_begin starts the build of the
+// cloud's k-NN grid (needed = false: the covariances are cached, nothing to do), cov_launch -- once the build is Done -- queues
+// the covariance pass.  ensure_covariances is the two with the blocking build loop in between.
+static int cov_grid_begin(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, const DeviceBuf& cov, uint64_t cov_version,
+                          GridBuild& b, bool& needed) {
+  needed = !(cov_version == version && cov.ptr);
+  if (!needed) return ICPGPU_OK;
   // the covariance search has no distance cap; the grid only needs cells of a useful size: same rule as the NN grid
   const double cut = std::max(1e-3, c->params.max_correspondence_distance);
   // point-weighted cell population the covariance grid aims at.  8 until the kernel walked a cube level as one dense list of
@@ -43,26 +48,50 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   static const bool hint_enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_KNN_HINT"); return !e || std::atoi(e) != 0; }();
   const double cut_used = std::isfinite(cut) ? std::min(cut, 1e6) : 1.0;
   const double h_start = (hint_enabled && c->cov_h_hint > 0.0 && c->cov_h_hint_cut == cut_used) ? c->cov_h_hint : 0.0;
-  int rc = build_grid(c, cloud, version, cut_used, /*adapt=*/false, G, nullptr, knn_pop, h_start);
-  if (rc) return rc;
+  return gb_begin(c, b, cloud, version, cut_used, /*adapt=*/false, G, nullptr, knn_pop, h_start);
+}
+
+static int cov_launch(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version, bool timed) {
   if (G.usable) {
+    const double cut = std::max(1e-3, c->params.max_correspondence_distance);
     c->cov_h_hint = (double)G.g.h;
-    c->cov_h_hint_cut = cut_used;
+    c->cov_h_hint_cut = std::isfinite(cut) ? std::min(cut, 1e6) : 1.0;
   }
   if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
+  int rc;
   if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
-  if ((rc = resolve_cov_timing(c))) return rc;  // (the events are about to be reused: an alignment with two new clouds)
-  HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  if (timed) {
+    if ((rc = resolve_cov_timing(c))) return rc;  // (the events are about to be reused: an alignment with two new clouds)
+    HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+  }
   HIP_TRY(c, launch_gicp_covariances(cloud.data(), (int)cloud.n, static_cast<const float4*>(G.sorted.ptr),
                                      static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
-  // No synchronisation: what follows is queued behind the pass (it used to end with one only to time itself: the host sat out
-  // the ~0.1 ms of the kernel instead of queueing the search, the Mahalanobis kernel and the evaluation server meanwhile).
-  c->cov_timing_pending = true;
+  if (timed) {
+    HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    // No synchronisation: what follows is queued behind the pass (it used to end with one only to time itself: the host sat out
+    // the ~0.1 ms of the kernel instead of queueing the search, the Mahalanobis kernel and the evaluation server meanwhile).
+    c->cov_timing_pending = true;
+  }
   c->prof.gicp_cov_launches += 1;
   c->prof.gicp_cov_points += (uint64_t)cloud.n;
   cov_version = version;
   return ICPGPU_OK;
+}
+
+int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version) {
+  GridBuild b;
+  b.post = true;  // (the read-backs go through fetch_ints, as in build_grid)
+  bool needed = false;
+  int rc = cov_grid_begin(c, cloud, version, G, cov, cov_version, b, needed);
+  if (rc || !needed) return rc;
+  while (!rc && b.state != GridBuild::Done) {
+    const int* d_ints = static_cast<const int*>(G.ints.ptr);
+    if (b.state == GridBuild::WaitBbox) rc = fetch_ints(c, d_ints, 6, c->h_ints);
+    else rc = fetch_ints(c, d_ints + 6, kGridStatInts, c->h_ints + 6);
+    if (!rc) rc = gb_advance(c, b);
+  }
+  if (rc) return rc;
+  return cov_launch(c, cloud, version, G, cov, cov_version, /*timed=*/true);
 }
 
 // the duration of the last covariance pass into the profile (waits for its end if need be: callers sit behind a result anyway)
@@ -242,6 +271,30 @@ static int gicp_solve_blocks(int n_s, int most) {
   if (blocks > cap) blocks = cap;
   if (blocks > most) blocks = most;
   return blocks < 1 ? 1 : blocks;
+}
+
+// PCL's convergence measure of an outer iteration: the largest entry of |previous - transformation|, rotation entries weighed by
+// 1 / rotation_epsilon_, the others by 1 / transformation_epsilon_
+static double gicp_outer_delta(const float previous[16], const float transformation[16], double rot_eps, double trans_eps) {
+  double delta = 0.0;
+  for (int k = 0; k < 4; ++k)
+    for (int l = 0; l < 4; ++l) {
+      const double ratio = (k < 3 && l < 3) ? 1.0 / rot_eps : 1.0 / trans_eps;
+      delta = std::max(delta, ratio * std::fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]));
+    }
+  return delta;
+}
+// PCL's own composition of the result: R = previous.R * guess.R, t = previous.t + guess.t
+static void gicp_compose_final(const float previous[16], const float guess[16], float fin[16]) {
+  mat4f_identity(fin);
+  for (int r = 0; r < 3; ++r) {
+    for (int cc = 0; cc < 3; ++cc) {
+      float s = 0.f;
+      for (int k = 0; k < 3; ++k) s += previous[k * 4 + r] * guess[cc * 4 + k];
+      fin[cc * 4 + r] = s;
+    }
+    fin[12 + r] = previous[12 + r] + guess[12 + r];
+  }
 }
 
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res) {
@@ -545,12 +598,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     c->prof.grid_ms += grid_ready(c) ? ms : 0.0;
     c->prof.grid_timed += (timed && grid_ready(c)) ? 1 : 0;
     mark(6);
-    double delta = 0.0;
-    for (int k = 0; k < 4; ++k)
-      for (int l = 0; l < 4; ++l) {
-        const double ratio = (k < 3 && l < 3) ? 1.0 / rot_eps : 1.0 / P.transformation_epsilon;
-        delta = std::max(delta, ratio * std::fabs((double)previous[l * 4 + k] - (double)transformation[l * 4 + k]));
-      }
+    const double delta = gicp_outer_delta(previous, transformation, rot_eps, P.transformation_epsilon);
     ++nr;
     c->prof.iterations += 1;
     if (nr >= P.max_iterations || (delta < 1 && !P.force_iterations)) {
@@ -559,17 +607,8 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       std::memcpy(previous, transformation, sizeof(previous));
     }
   }
-  // PCL's own composition of the result: R = previous.R * guess.R, t = previous.t + guess.t
   float fin[16];
-  mat4f_identity(fin);
-  for (int r = 0; r < 3; ++r) {
-    for (int cc = 0; cc < 3; ++cc) {
-      float s = 0.f;
-      for (int k = 0; k < 3; ++k) s += previous[k * 4 + r] * guess[cc * 4 + k];
-      fin[cc * 4 + r] = s;
-    }
-    fin[12 + r] = previous[12 + r] + guess[12 + r];
-  }
+  gicp_compose_final(previous, guess, fin);
   std::memcpy(res->T, fin, sizeof(fin));
   for (int i = 0; i < 16; ++i) c->final_T[i] = (double)fin[i];
   c->have_final = true;
@@ -595,6 +634,307 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   res->t_device_ms = dev_ms;
   res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
   return ICPGPU_OK;
+}
+
+
+// ---- a GICP registration as a RESUMABLE run (icpgpu_align_batch: one host thread keeps several in flight) -------------------
+// align_gicp above is a blocking host loop: the index builds wait for their read-backs, every inner minimisation is ~30 dependent
+// host <-> device round trips (or one wait for the device solver).  A GicpRun is the same registration cut at its waits: the
+// covariance grids go through their host round trips as posted markers the host POLLS, every outer iteration is search +
+// Mahalanobis + the whole BFGS run in ONE resident kernel (gicp_solve_kernel, as align_gicp's device-solver branch launches it),
+// whose result granules the host polls, and the fitness sweep is a SweepTicket like point-to-point's.  Same kernels, same
+// arguments, same host arithmetic between them as align_gicp => the same bits (tests/test_gpu_gicp.py compares).
+// What a run cannot take -- a guess or an output cloud (the batch passes neither), a context without the device solver, a solver
+// that gives up (a gather timed out: co-residency lost) -- goes through align_gicp: gicp_run_begin says so (phase Blocking) and
+// gicp_run_step then runs the blocking function; results do not depend on the path, so a restart from scratch is safe.
+static unsigned long long run_post_marker(icpgpu_ctx* c, const int* d_any, int* rc) {
+  const unsigned long long number = ++c->post_seq;
+  *rc = ICPGPU_OK;
+  if (launch_post_ints(d_any, 1, c->h_post_dev, wire_seq(c, number), c->stream) != hipSuccess) *rc = fail(c, ICPGPU_ERR_HIP, "GICP run: marker launch");
+  return number;
+}
+static bool run_marker_seen(const icpgpu_ctx* c, unsigned long long number) { return (c->h_post[1] >> 24) == number; }
+
+static bool gicp_run_device_ok(const icpgpu_ctx* c) {
+  return gicp_device_solver_mode() != 0 && c->gicp_device_ok && c->gicp_server_allowed && c->gicp_slots && c->h_solve;
+}
+
+static int gicp_run_finish_early(icpgpu_ctx* c, GicpRun& r) {  // empty target / clouds smaller than k_correspondences_
+  c->final_T = mat4_identity();
+  c->have_final = true;
+  r.res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_start).count();
+  r.phase = GicpRun::Done;
+  return ICPGPU_OK;
+}
+
+// queue one outer iteration: correspondences, Mahalanobis matrices, the BFGS run
+static int gicp_run_queue_outer(icpgpu_ctx* c, GicpRun& r) {
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  auto* maha = static_cast<double*>(c->maha.ptr);
+  float TG[16];
+  mat4f_mul(r.transformation, r.guess, TG);
+  const Xform Tq = xform_from_f16(TG);
+  Rot3d R;
+  for (int rr = 0; rr < 3; ++rr)
+    for (int cc = 0; cc < 3; ++cc) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += (double)r.transformation[k * 4 + rr] * (double)r.guess[cc * 4 + k];
+      R.m[3 * rr + cc] = s;
+    }
+  int rc;
+  if (grid_ready(c)) {
+    unsigned int* prev = nullptr;  // each outer iteration's neighbours bound the next one's search
+    bool use_prev = false;
+    if ((rc = prev_neighbours(c, c->grid, c->src.data(), n_s, grid_flags(c->grid, false), prev, use_prev))) return rc;
+    HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, grid_flags(c->grid, false), Tq, static_cast<const float4*>(c->grid.sorted.ptr),
+                                     static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, r.thr, keys, nullptr, nullptr,
+                                     nullptr, c->stream, prev, use_prev));
+    c->prof.grid_launches += 1;
+  } else {
+    if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
+  }
+  HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, r.thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                     static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
+  Vec6 x = gicp_state_from_matrix(r.transformation);
+  const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
+  // the one-XCD variant wherever the run fits one XCD with its correspondences in registers (align_gicp also asks for 8 x nblk <=
+  // the context's share of the chip: a lone blocking alignment sizes its evaluation server by that share; the runs of a batch
+  // sit on their contexts' own XCDs, c->gicp_xcc, and leave after every outer iteration)
+  r.local = c->gicp_local_ok && nblk <= gicp_solve_local_blocks() && (long long)nblk * 1024 >= n_s;
+  r.seq0 = (c->gicp_solve_seq += 8192);
+  r.t_issue = std::chrono::steady_clock::now();
+  HIP_TRY(c, launch_gicp_solve(nblk, c->src.data(), n_s, c->tgt.data(), keys, r.thr_excl, xform_from_f16(r.guess), r.guess, maha, x.v, c->gicp_slots,
+                               c->h_solve_dev, wire_seq(c, r.seq0), 20, 1e-2, c->stream, r.local ? c->gicp_slots_local : nullptr,
+                               r.local ? c->gicp_owner : nullptr, c->gicp_xcc));
+  r.phase = GicpRun::Solve;
+  r.polls = 0;
+  return ICPGPU_OK;
+}
+
+// after the covariances: the search grid, the scratch, the first outer iteration
+static int gicp_run_start_outer(icpgpu_ctx* c, GicpRun& r) {
+  const int n_s = (int)c->src.n;
+  int rc;
+  if ((rc = ensure_grid(c, r.thr))) return rc;  // (GICP: adopts the grid the target's covariances were computed over -- no build)
+  if ((rc = ensure(c, c->keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+  if ((rc = ensure(c, c->maha, (size_t)n_s * 6 * sizeof(double)))) return rc;
+  if ((rc = ensure(c, c->partials, (size_t)kMaxReduceBlocks * kReduceTerms * sizeof(double)))) return rc;
+  return gicp_run_queue_outer(c, r);
+}
+
+// the next covariance grid that needs building (target first, then source), or on to the outer iterations
+static int gicp_run_next_cov(icpgpu_ctx* c, GicpRun& r) {
+  int rc;
+  while (r.cov_stage < 2) {
+    const bool tgt = r.cov_stage == 0;
+    const Cloud& cloud = tgt ? c->tgt : c->src;
+    GridIndex& G = tgt ? c->cov_grid_tgt : c->cov_grid_src;
+    DeviceBuf& cov = tgt ? c->cov_tgt : c->cov_src;
+    uint64_t& cov_version = tgt ? c->cov_tgt_version : c->cov_src_version;
+    const uint64_t version = tgt ? c->tgt_version : c->src_version;
+    bool needed = false;
+    r.gb = GridBuild{};
+    if ((rc = cov_grid_begin(c, cloud, version, G, cov, cov_version, r.gb, needed))) return rc;
+    if (needed && r.gb.state != GridBuild::Done) {  // a read-back is queued: poll the marker behind it
+      r.marker = run_post_marker(c, static_cast<const int*>(G.ints.ptr), &rc);
+      if (rc) return rc;
+      r.phase = GicpRun::CovGrid;
+      r.polls = 0;
+      r.t_issue = std::chrono::steady_clock::now();
+      return ICPGPU_OK;
+    }
+    if (needed && (rc = cov_launch(c, cloud, version, G, cov, cov_version, /*timed=*/false))) return rc;
+    r.cov_stage += 1;
+  }
+  return gicp_run_start_outer(c, r);
+}
+
+int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res) {
+  r = GicpRun{};
+  r.t_start = std::chrono::steady_clock::now();
+  r.res = res;
+  r.want_fitness = want_fitness;
+  if (!gicp_run_device_ok(c)) {  // no device solver on this context: the blocking function
+    r.phase = GicpRun::Blocking;
+    return ICPGPU_OK;
+  }
+  init_result(res);
+  c->prof.aligns += 1;
+  c->prev.valid = c->tile_seed.valid = false;  // every alignment starts cold
+  mat4f_identity(r.guess);
+  mat4f_identity(r.transformation);
+  mat4f_identity(r.previous);
+  {
+    int rc = resolve_sweep_timings(c, /*block=*/false);
+    if (rc) return rc;
+    c->dev_ms_accum = 0.0;
+    c->call_sweeps = c->call_timed = 0;
+  }
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  if (n_t == 0 || n_s < kGicpK || n_t < kGicpK) return gicp_run_finish_early(c, r);
+  // GICP keeps d2 < r^2 (strict): the largest float below r^2
+  const icpgpu_params& P = c->params;
+  const double r2 = P.max_correspondence_distance * P.max_correspondence_distance;
+  r.thr = threshold_from(r2);
+  if ((double)r.thr >= r2) r.thr = std::nextafterf(r.thr, -INFINITY);
+  r.thr_excl = std::nextafterf(r.thr, INFINITY);  // d2 < thr_excl  <=>  d2 <= thr
+  r.cov_stage = 0;
+  return gicp_run_next_cov(c, r);
+}
+
+static int gicp_run_restart_blocking(icpgpu_ctx* c, GicpRun& r) {
+  c->prof.aligns -= 1;  // (align_gicp counts the alignment again)
+  r.phase = GicpRun::Blocking;
+  return ICPGPU_OK;
+}
+
+// the registration is over: result record, fitness sweep or Done
+static int gicp_run_conclude(icpgpu_ctx* c, GicpRun& r) {
+  float fin[16];
+  gicp_compose_final(r.previous, r.guess, fin);
+  std::memcpy(r.res->T, fin, sizeof(fin));
+  for (int i = 0; i < 16; ++i) c->final_T[i] = (double)fin[i];
+  c->have_final = true;
+  r.res->converged = r.converged ? 1 : 0;
+  r.res->iterations = r.nr;
+  r.res->convergence_state = r.state;
+  r.res->n_correspondences = r.n_corr;
+  r.res->mse_last = r.mse;
+  if (r.want_fitness) {
+    r.phase = GicpRun::Fitness;
+    r.polls = 0;
+    r.t_issue = std::chrono::steady_clock::now();
+    return sweep_issue(c, xform_from_f16(fin), FLT_MAX, /*open_range=*/true, r.ticket);
+  }
+  r.res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_start).count();
+  r.phase = GicpRun::Done;
+  return ICPGPU_OK;
+}
+
+// One non-blocking step.  Returns < 0 on error, 0 when nothing has arrived yet, 1 when the run moved on (r.phase == Done: finished).
+int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
+  const icpgpu_params& P = c->params;
+  int rc;
+  switch (r.phase) {
+    case GicpRun::Blocking:
+      if ((rc = align_gicp(c, nullptr, nullptr, r.want_fitness, r.res))) return rc;
+      r.phase = GicpRun::Done;
+      return 1;
+    case GicpRun::CovGrid: {
+      if (!run_marker_seen(c, r.marker)) {
+        if ((++r.polls & 0x3FFu) != 0) return 0;
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for an index build: %s", hipGetErrorString(q));
+        if (q == hipErrorNotReady) {
+          if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count() > wait_timeout_ms())
+            return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for an index build (hung kernel?)", wait_timeout_ms());
+          return 0;
+        }
+        // (the stream has drained: the read-back is there whether or not the marker's pair shows -- the stream's word is as good)
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if ((rc = gb_advance(c, r.gb))) return rc;
+      const bool tgt = r.cov_stage == 0;
+      GridIndex& G = tgt ? c->cov_grid_tgt : c->cov_grid_src;
+      if (r.gb.state != GridBuild::Done) {
+        r.marker = run_post_marker(c, static_cast<const int*>(G.ints.ptr), &rc);
+        if (rc) return rc;
+        r.polls = 0;
+        return 1;
+      }
+      const Cloud& cloud = tgt ? c->tgt : c->src;
+      if ((rc = cov_launch(c, cloud, tgt ? c->tgt_version : c->src_version, G, tgt ? c->cov_tgt : c->cov_src,
+                           tgt ? c->cov_tgt_version : c->cov_src_version, /*timed=*/false)))
+        return rc;
+      r.cov_stage += 1;
+      if ((rc = gicp_run_next_cov(c, r))) return rc;
+      return 1;
+    }
+    case GicpRun::Solve: {
+      double out[24];
+      const int n = gicp_solve_out_granules();
+      bool all = true;
+      for (int k = 0; k < n; ++k) all = gicp_granule_read(c->h_solve + 2 * k, r.seq0, &out[k]) && all;
+      bool gave_up = false;
+      if (!all) {
+        if ((++r.polls & 0x3FFu) != 0) return 0;
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for the GICP device solver: %s", hipGetErrorString(q));
+        if (q == hipErrorNotReady) {
+          if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count() > wait_timeout_ms())
+            return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for the GICP device solver (hung kernel?)", wait_timeout_ms());
+          return 0;
+        }
+        all = true;
+        for (int k = 0; k < n; ++k) all = gicp_granule_read(c->h_solve + 2 * k, r.seq0, &out[k]) && all;
+        gave_up = !all;  // the stream went idle without an answer
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      const int status = gave_up ? (int)gicp::kDeviceError : (int)out[0];
+      if (status == gicp::kDeviceError) {  // a gather timed out (or the kernel never answered): as align_gicp records it, then that function
+        if (r.local) c->gicp_local_ok = false;
+        else c->gicp_device_ok = false;
+        if (std::getenv("ICPGPU_DEBUG"))
+          fprintf(stderr, "[icpgpu] gicp run: device solver%s gave up; this pair goes through the blocking path\n", r.local ? " (one XCD)" : "");
+        return gicp_run_restart_blocking(c, r) ? -1 : 1;
+      }
+      c->prof.gicp_device_solves += 1;
+      const double m = out[7], evals = out[10];
+      r.mse = m > 0 ? out[8] / m : 0.0;
+      r.n_corr = (unsigned)m;
+      c->prof.gicp_cost_launches += (uint64_t)evals;
+      c->prof.gicp_eval_corr += (uint64_t)(m * evals);
+      c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count();
+      std::memcpy(r.previous, r.transformation, sizeof(r.previous));
+      if (status == gicp::kNotEnoughPoints) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+        r.state = ICPGPU_CONV_NO_CORRESPONDENCES;
+        if ((rc = gicp_run_conclude(c, r))) return rc;
+        return 1;
+      }
+      if (status != gicp::kOk) {  // SolverDidntConvergeException
+        r.state = ICPGPU_NOT_CONVERGED;
+        if ((rc = gicp_run_conclude(c, r))) return rc;
+        return 1;
+      }
+      Vec6 x;
+      for (int k = 0; k < 6; ++k) x[k] = out[1 + k];
+      mat4f_identity(r.transformation);
+      gicp_apply_state(r.transformation, x);
+      const double delta = gicp_outer_delta(r.previous, r.transformation, 2e-3, P.transformation_epsilon);
+      ++r.nr;
+      c->prof.iterations += 1;
+      if (r.nr >= P.max_iterations || (delta < 1 && !P.force_iterations)) {
+        r.converged = true;
+        r.state = r.nr >= P.max_iterations ? ICPGPU_CONV_ITERATIONS : ICPGPU_CONV_TRANSFORM;
+        std::memcpy(r.previous, r.transformation, sizeof(r.previous));
+        if ((rc = gicp_run_conclude(c, r))) return rc;
+        return 1;
+      }
+      if ((rc = gicp_run_queue_outer(c, r))) return rc;
+      return 1;
+    }
+    case GicpRun::Fitness: {
+      if (!sweep_ready(c, r.ticket)) {
+        if ((++r.polls & 0x3FFu) == 0) {
+          const hipError_t q = hipStreamQuery(c->stream);
+          if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a reduction: %s", hipGetErrorString(q));
+          if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count() > wait_timeout_ms())
+            return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a kernel's result (hung kernel?)", wait_timeout_ms());
+        }
+        return 0;
+      }
+      if ((rc = sweep_complete(c, r.ticket))) return rc;
+      r.res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
+      if ((rc = resolve_sweep_timings(c, /*block=*/false))) return rc;
+      r.res->t_device_ms = 0.0;  // (not sampled on this path)
+      r.res->t_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_start).count();
+      r.phase = GicpRun::Done;
+      return 1;
+    }
+    default:
+      return 0;
+  }
 }
 
 }  // namespace icpgpu_impl

@@ -368,3 +368,46 @@ def test_adopted_grid_never_outlives_its_conditions(ctx):
     # built -- and kept: the covariances are cached, their grid is gone) and never seen by point-to-point; the new target's
     # covariance grid is adopted again
     assert adopted[:6] == [1, 1, 1, 1, 1, 1] and adopted[6] == 2, adopted
+
+
+@pytest.mark.parametrize("threads,runs", [(1, 8), (2, 3), (3, 1)])
+def test_gicp_batch_runs_equal_single_aligns(built, monkeypatch, threads, runs):
+    """icpgpu_align_batch in GICP mode keeps `runs` RESUMABLE registrations per host thread in flight (GicpRun, icpgpu_gicp.cpp:
+    covariance grids through polled markers, every outer iteration's BFGS inside the device solver, the fitness sweep a ticket) --
+    the solver the reference instantiates (icp_odometer.cpp:188) at the batch sizes of configs 4 / 5.  Every pair must come out
+    exactly as a single icpgpu_align gives it: ordinary pairs of several sizes, a cloud below k_correspondences_ (PCL leaves
+    T = I, not converged), clouds 500 m apart (no correspondence: NotEnoughPointsException), an empty target."""
+    from icpslam_amd import Context
+    monkeypatch.setenv("ICPGPU_BATCH_THREADS", str(threads))
+    monkeypatch.setenv("ICPGPU_BATCH_DEPTH", str(runs))
+    pairs = []
+    for k, n in enumerate([3000, 9000, 14000, 22000, 5000, 30000, 7000, 12000, 16000, 4000, 26000]):
+        s, t, _ = synth.make_pair(n, n + 500 * (k % 3), seed=700 + k)
+        pairs.append((s, t))
+    far = pairs[1][1].copy()
+    far[:, 2] += 500.0
+    pairs.insert(3, (pairs[1][0], far))                       # nothing within the gate
+    pairs.insert(6, (pairs[0][0][:10].copy(), pairs[0][1]))   # fewer points than neighbours per covariance
+    pairs.append((pairs[2][0], np.zeros((0, 4), np.float32)))  # empty target
+    with Context(0) as one:
+        one.set_params(one.default_params(), method=GICP, max_iterations=8)
+        want = []
+        for s, t in pairs:
+            one.set_source(s)
+            one.set_target(t)
+            want.append(one.align(want_fitness=True))
+    with Context(0) as c:
+        c.set_params(c.default_params(), method=GICP, max_iterations=8)
+        for _ in range(2):                                    # (the second call meets warm workers: cached sizes, old mailbox numbers)
+            c.profile_reset()
+            got = c.align_batch([p[0] for p in pairs], [p[1] for p in pairs], want_fitness=True)
+            prof = c.profile()
+            assert prof.gicp_device_solves > 0 and prof.gicp_host_solves == 0
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert np.array_equal(g["T"], w["T"]), k
+                assert (g["converged"], g["iterations"], g["state"], g["n_corr"]) == (w["converged"], w["iterations"], w["state"], w["n_corr"]), k
+                assert g["fitness"] == w["fitness"] or (np.isnan(g["fitness"]) and np.isnan(w["fitness"])), k
+    # (the special pairs are what they were meant to be)
+    assert want[3]["n_corr"] < 4 and not want[3]["converged"], want[3]
+    assert not want[6]["converged"] and want[6]["iterations"] == 0, want[6]
+    assert not want[-1]["converged"] and want[-1]["iterations"] == 0, want[-1]
