@@ -278,6 +278,8 @@ struct icpgpu_ctx {
   int timing_every = 13;      // time one sweep in 13 (coprime with the 10 / 30 iterations of the reference's aligns; 7 until round 2: an event triple costs 6-7 us)
   unsigned sweep_counter = 0;
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
+  void* h_stage = nullptr;   // pinned staging for results that go to the caller's pageable buffers (copy_to_host)
+  size_t h_stage_cap = 0;
   volatile unsigned long long* h_post = nullptr;  // mapped, coherent: 32 result pairs for fetch_ints (icpgpu_context.cpp)
   unsigned long long* h_post_dev = nullptr;
   unsigned long long post_seq = 0;
@@ -417,6 +419,7 @@ float threshold_from(double r2);
 // (a posted kernel + a polled mailbox instead of hipMemcpyAsync + hipStreamSynchronize: icp_kernels.hip post_ints_kernel)
 int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst);
 unsigned long long sample_fingerprint(const float* xyzw, size_t n);
+int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, const int* d_extra = nullptr, int n_extra = 0, int* extra_out = nullptr);
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
 int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
 int promote_internal(icpgpu_ctx* c);

@@ -393,8 +393,7 @@ int icpgpu_map_nn_target(icpgpu_ctx* c, const float* pose, const float* pose_inv
     if ((rc = build_grid(c, M.uniq, c->tgt_version, cut, /*adapt=*/true, c->grid, static_cast<const int*>(M.uniq_index.ptr)))) return rc;
   }
   if (nn_out_xyzw && m > 0) {
-    HIP_TRY(c, hipMemcpyAsync(nn_out_xyzw, c->tgt.buf.ptr, (size_t)m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = copy_to_host(c, nn_out_xyzw, c->tgt.buf.ptr, (size_t)m * sizeof(float4)))) return rc;
   }
   if (n_nn) *n_nn = (size_t)m;
   return ICPGPU_OK;

@@ -355,8 +355,7 @@ int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(c, launch_transform(c->src.data(), n_s, T, static_cast<float4*>(c->out.ptr), c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->out.ptr, (size_t)n_s * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if ((rc = copy_to_host(c, out_xyzw, c->out.ptr, (size_t)n_s * sizeof(float4)))) return rc;
   float ms = 0.f;
   HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
   c->prof.transform_launches += 1;

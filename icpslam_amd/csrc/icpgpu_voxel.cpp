@@ -126,11 +126,10 @@ static int fetch_filtered(icpgpu_ctx* c, float* out_xyzw, size_t m) {
   if (rc) return rc;
   auto* d_acc = static_cast<unsigned long long*>(c->fp_acc.ptr);
   HIP_TRY(c, launch_fingerprint(static_cast<const float4*>(c->vox_out.ptr), (int)m, d_acc, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out_xyzw, c->vox_out.ptr, m * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_ints + 8, d_acc, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int words[2] = {0, 0};  // the 64-bit sum rides on the copy's marker
+  if ((rc = copy_to_host(c, out_xyzw, c->vox_out.ptr, m * sizeof(float4), reinterpret_cast<const int*>(d_acc), 2, words))) return rc;
   unsigned long long sum = 0;
-  std::memcpy(&sum, c->h_ints + 8, sizeof sum);
+  std::memcpy(&sum, words, sizeof sum);
   c->vox_fp = fp_finish(sum, (unsigned long long)m);
   c->vox_sample_fp = sample_fingerprint(out_xyzw, m);
   c->vox_fp_valid = true;
