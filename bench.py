@@ -513,6 +513,20 @@ def main():
                     "clouds": int(pg.gicp_cov_launches), "algorithmic_bytes_per_cloud": cov_bytes,
                     "note": "gicp_cov_kernel + gicp_cov_finish_kernel per cloud (HIP events): 16 B read + 48 B written per point; the "
                             "time is the 20-NN selection over the cloud's own grid and the per-point 3x3 Jacobi SVD, not the bytes"}}
+        # (4) the same solver through icpgpu_align_batch: 32 voxel-filtered pairs as resumable runs (GicpRun: one or two host
+        #     threads keep eight registrations in flight, every outer iteration's BFGS inside the device solver)
+        gicp_batch = None
+        try:
+            fa, fb = ctx.voxel_grid(src, leaf), ctx.voxel_grid(tgt, leaf)
+            bs, bt = [fa, fb] * 16, [fb, fa] * 16
+            ctx.set_params(ctx.default_params(), method=GICP, max_iterations=a.iters, force_iterations=0)
+            ctx.align_batch(bs, bt, want_fitness=True)
+            tb = time.perf_counter()
+            for _ in range(3):
+                ctx.align_batch(bs, bt, want_fitness=True)
+            gicp_batch = 3 * len(bs) / (time.perf_counter() - tb)
+        except Exception as e:  # a secondary figure must not take the headline down
+            gicp_batch = repr(e)[:200]
         shim = shim_pipeline(src, tgt, leaf, a.iters, n_scans=n_e2e + 4)
         gicp_cpu = None if a.no_cpu_baseline else gicp_cpu_baseline(src, tgt, leaf, a.iters, a.cpu_seconds)
         extras["gicp"] = {"scan_pairs_per_sec_e2e": gicp,
@@ -527,6 +541,9 @@ def main():
                           "cpu_baseline": gicp_cpu,
                           "def": f"the same odometry loop with method = GICP (<= {a.iters} outer iterations, BFGS inner "
                                  "solver): what pcl::GeneralizedIterativeClosestPoint at icp_odometer.cpp:188 runs per scan",
+                          "batch_pairs_per_sec": gicp_batch,
+                          "batch_def": f"32 voxel-filtered ({leaf} m) pairs of the bench scans through icpgpu_align_batch in GICP mode, "
+                                       "<= 10 outer iterations + fitness each (resumable runs, icpgpu_gicp.cpp: GicpRun)",
                           "reference_pipeline_scans_per_sec": pipeline,
                           "reference_pipeline_def": f"per scan: VoxelGrid({leaf} m) of the raw {n_s}-point scan on the device "
                                                     f"(-> {ctx.n_target} points), then the GICP loop above on the filtered clouds: "

@@ -171,7 +171,7 @@ constexpr size_t kMaxServerWorkers = 8;
 // ICPGPU_GICP_DEVICE: where GICP's inner BFGS runs -- 0: on the host over the evaluation server; 1: inside a resident kernel
 // (icp_gicp.hip: gicp_solve_kernel); unset or "auto": MEASURED per context.  Same bits either way (tests/test_gpu_gicp.py,
 // 1 200 campaign registrations through both).  Which one is faster depends on the box: the host loop's evaluation is 6.8-8.3 us
-// with the box's PCIe and CPU, the kernel's 7.2-7.7 us wherever it runs -- so a context times a few
+// with the box's PCIe and CPU, the kernel's 7.2-7.7 us wherever it runs (EXPERIMENTS.md section 9-f1) -- so a context times a few
 // outer iterations each way (align_gicp) and keeps the faster; runs the one-XCD variant cannot take stay on the host.
 inline int gicp_device_solver_mode() {  // 0 host, 1 device, 2 measured
   static const int v = [] {

@@ -5,7 +5,7 @@
 // -- and since round 4 it runs INSIDE a kernel (icp_gicp.hip: gicp_solve_kernel) as well as on the host (the fallback path).
 // PCL takes its sines and cosines from the platform's libm (Eigen::AngleAxisf: std::cos/std::sin(float); computeRDerivative:
 // std::cos/std::sin(double)); libm results are not portable: glibc 2.35's sin / cos / sinf / cosf differ from the correctly
-// rounded value on 0.2 % / 0.1 % / 1.8 % / 0.7 % of random arguments (measured), and the device's
+// rounded value on 0.2 % / 0.1 % / 1.8 % / 0.7 % of random arguments (measured, EXPERIMENTS.md section 9-f1), and the device's
 // math library differs from both.  The arithmetic contract therefore says: these four are the CORRECTLY
 // ROUNDED functions.  The oracle computes them in binary128 (libquadmath) and rounds once; this file computes them in
 // double-double arithmetic:

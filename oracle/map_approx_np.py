@@ -1,6 +1,6 @@
 """map_approx_np.py -- restatement of PCL's OctreePointCloudSearch::approxNearestSearch as the reference's mapper uses it
 (/root/reference/src/icpslam/octree_mapper.cpp:72-90), to QUANTIFY the one deliberate deviation of the map row (SURVEY.md
-8(f4)): libicpgpu returns the EXACT nearest map point, PCL a heuristic one.  TEST INFRASTRUCTURE ONLY.
+8(f4), EXPERIMENTS.md section 9-f4): libicpgpu returns the EXACT nearest map point, PCL a heuristic one.  TEST INFRASTRUCTURE ONLY.
 
        ***  PARITY UNPINNED  ***  (PCL is not under /root/reference; restated from PCL 1.8's octree_pointcloud.hpp /
        octree_search.hpp as published: adoptBoundingBoxToPoint, genOctreeKeyforPoint, approxNearestSearchRecursive)

@@ -1,4 +1,4 @@
-// waitvalue_probe.cpp -- can the launch of the NEXT sweep be taken off the ICP iteration's critical path?  (open 1)
+// waitvalue_probe.cpp -- can the launch of the NEXT sweep be taken off the ICP iteration's critical path?  (EXPERIMENTS.md section 10, open 1)
 // A chain of dependent tiny kernels, each storing a tagged result into mapped host memory that the host polls:
 //   A: host sees result k, THEN calls hipLaunchKernelGGL(k + 1)                          (what align_p2p does today)
 //   B: [hipStreamWaitValue64(flag >= k + 1), kernel k + 1] are queued AHEAD; the host sees result k and writes the flag

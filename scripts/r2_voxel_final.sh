@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 2: the evidence behind DESIGN.md 9-f2 (voxel filter without the library sort) -> gpurun_out/r2v/
+# round 2: the evidence behind EXPERIMENTS.md section 9-f2 (voxel filter without the library sort) -> gpurun_out/r2v/
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r2v; mkdir -p $O; cd $R
 {
 echo "## device time (HIP events around the filter's launches, after the bounding box), direct path"

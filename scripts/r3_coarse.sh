@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: the kernel variant this script switches (ICPGPU_COARSE_CUBES) was measured and REMOVED (profiles/r03_two_level_experiment.txt):
+# NOTE: the kernel variant this script switches (ICPGPU_COARSE_CUBES) was measured and REMOVED (EXPERIMENTS.md section 5 (table of variants), profiles/r03_two_level_experiment.txt):
 # with the shipped library both settings run the same kernel.  Kept as the record of how the numbers were taken.
 # Round 3: the cube search of nn_quad_kernel over the coarse second grid level (ICPGPU_COARSE_CUBES=0: over the search grid)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r3_coarse}; mkdir -p $O; cd $R

@@ -1,5 +1,5 @@
 #!/bin/bash
-# NOTE: the kernel variant this script switches (ICPGPU_FLAT / ICPGPU_TWO_LEVEL / ICPGPU_SPLIT) was measured and REMOVED (DESIGN.md section 5 table,
+# NOTE: the kernel variant this script switches (ICPGPU_FLAT / ICPGPU_TWO_LEVEL / ICPGPU_SPLIT) was measured and REMOVED (EXPERIMENTS.md section 5 (table of variants),
 # profiles/r03_*): with the shipped library both settings run the same kernel.  Kept as the record of how the numbers were taken.
 # Round 3: second grid level in nn_quad_kernel -- parity, then per-sweep times with and without it
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-r3_two}; mkdir -p $O; cd $R

@@ -224,7 +224,7 @@ def test_gicp_server_variants_agree_bit_for_bit(tmp_path):
 def test_gicp_device_solver_runs_and_equals_the_host_solver_bit_for_bit(tmp_path):
     """Round 4: the whole inner BFGS of an outer iteration runs inside gicp_solve_kernel (icp_gicp.hip) -- the profile says so,
     one device solve per outer iteration (ICPGPU_GICP_DEVICE=1; by default a context measures both solvers and keeps the faster,
-    DESIGN.md 9-f1) -- and the host
+    EXPERIMENTS.md section 9-f1) -- and the host
     path (ICPGPU_GICP_DEVICE=0: the host's solver over the evaluation server, same source: icp_gicp_solver_impl.h) returns the same bits: transform, iterations, correspondences, fitness.  Sizes: one workgroup,
     several workgroups with the correspondences resident in registers, and the streaming variant (more than 64 x 1024)."""
     import os

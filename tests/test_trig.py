@@ -15,7 +15,7 @@ def test_product_trig_equals_binary128_rounded_once(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "trig_check.cpp"), "-o", exe, "-lquadmath"])
     n, bad_sin, bad_cos, bad_sinf, bad_cosf, far, libm_sin, libm_sinf = (int(v) for v in subprocess.check_output([exe, "400000"]).split())
     assert n == 400000
-    assert bad_sinf == 0 and bad_cosf == 0                    # float: none in 8 x 10^7 either
+    assert bad_sinf == 0 and bad_cosf == 0                    # float: none in 8 x 10^7 either (EXPERIMENTS.md section 9-f1)
     assert bad_sin + bad_cos <= 2 and far == 0                # double: ~1e-7 per call, never more than one ulp
     # the reason for the contract: glibc's sin differs from the correctly rounded value on ~0.2 % of arguments, sinf on ~1.8 %
     assert libm_sin > 50 * (bad_sin + bad_cos + 1) and libm_sinf > 1000
