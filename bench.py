@@ -427,6 +427,19 @@ def main():
     elapsed = time.perf_counter() - t0
     # (the collector stays off through the secondary measurements below: they are timed loops too)
     prof = ctx.profile()
+    # Right behind the timed region, on rank 0: a DENSE pass for the roofline -- the same alignments with EVERY sweep's kernel
+    # bracketed by HIP events (the timed region samples one sweep in 13, because the event records are barrier packets that cost
+    # 6-7 us apiece and would slow `value` down: 15 timed launches at the driver's --steps 20).  Reported beside the sampled figure.
+    dense = None
+    if rank == 0 and not batch and not a.no_extras:
+        ctx.profile_sampling(1)
+        ctx.profile_reset()
+        for _ in range(20):
+            ctx.align()
+        pd = ctx.profile()
+        if pd.grid_timed:
+            dense = {"avg_launch_ms": pd.grid_ms / pd.grid_timed, "timed_launches": int(pd.grid_timed), "alignments": 20}
+        ctx.profile_sampling(13)
     iters_done = int(prof.iterations)
     pairs_done = int(prof.aligns)
     if world > 1:
@@ -648,6 +661,10 @@ def main():
                                       "alignment, so over the timed steps every sweep position -- the cold first one to the converged tenth -- "
                                       "is sampled equally often); avg_launch_ms = their mean",
                 "algorithmic_bytes_per_launch": alg_bytes_fused,
+                "dense_pass": (dict(dense, achieved=alg_bytes_fused / (dense["avg_launch_ms"] * 1e-3) / 1e9,
+                                    frac=alg_bytes_fused / (dense["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    how="20 more alignments right behind the timed region with every sweep's launch between HIP events")
+                               if dense else None),
                 "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
                         "(SURVEY.md 8(d) fused lower bound).  An exact NN search does not stream; `issue` gives its VALU "
                         "issue rate against the SIMD-32 peak (it sits well below it: the kernel is latency / dependency "

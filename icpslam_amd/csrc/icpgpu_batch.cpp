@@ -365,14 +365,14 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
           if (pending) {
             // the stage's read-backs (hipMemcpyAsync into pinned memory, queued by the builds) have landed once the marker queued
             // behind them has: polled in host memory, no runtime call and no sleeping wait
-            if ((lead->h_post[1] >> 24) != G.sync_seq) {
+            if ((lead->h_post[1] >> 24) < G.sync_seq) {
               if ((++G.idle_spins & 0xFFFu) == 0) {
                 const hipError_t q = hipStreamQuery(gstream);
                 if (q != hipSuccess && q != hipErrorNotReady) {
                   fail(slots[0].w, ICPGPU_ERR_HIP, "lock-step batch: %s", hipGetErrorString(q));
                   return bail(ICPGPU_ERR_HIP, slots[0].pair, slots[0].w);
                 }
-                if (q == hipSuccess && (lead->h_post[1] >> 24) != G.sync_seq) {  // drained without the marker: its pair was torn or lost -- fall back to the stream's word
+                if (q == hipSuccess && (lead->h_post[1] >> 24) < G.sync_seq) {  // drained without the marker: its pair was torn or lost -- fall back to the stream's word
                   std::atomic_thread_fence(std::memory_order_acquire);
                 } else if (q == hipErrorNotReady) {
                   return 0;

@@ -653,7 +653,9 @@ static unsigned long long run_post_marker(icpgpu_ctx* c, const int* d_any, int* 
   if (launch_post_ints(d_any, 1, c->h_post_dev, wire_seq(c, number), c->stream) != hipSuccess) *rc = fail(c, ICPGPU_ERR_HIP, "GICP run: marker launch");
   return number;
 }
-static bool run_marker_seen(const icpgpu_ctx* c, unsigned long long number) { return (c->h_post[1] >> 24) == number; }
+// (>=: markers and fetch_ints' posts are numbered in the order they were queued on the context's one stream -- a later one showing
+//  means the awaited one has been written too)
+static bool run_marker_seen(const icpgpu_ctx* c, unsigned long long number) { return (c->h_post[1] >> 24) >= number; }
 
 static bool gicp_run_device_ok(const icpgpu_ctx* c) {
   return gicp_device_solver_mode() != 0 && c->gicp_device_ok && c->gicp_server_allowed && c->gicp_slots && c->h_solve;
