@@ -510,11 +510,6 @@ __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __re
 // Workgroup reduction of the lanes' accumulators into partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = the
 // sums' high parts, [14] = sum d2, [16..28] = their low parts.  The 13 double-double sums go through LDS: thread
 // (sum, chunk) adds the 16 lanes of its chunk in lane order, then thread `sum` adds the 16 chunk results in order.
-__device__ __forceinline__ void gicp_store_tagged(double* __restrict__ out, int entry, double value, unsigned long long tag) {
-  // ONE 16-byte store, written through to system memory (sc0 sc1): the server kernel never ends, nothing else would push
-  // a cached line out, and a release fence is exactly what this protocol is there to avoid
-  store_result_pair(out + 2 * entry, (unsigned long long)__double_as_longlong(value), tag);
-}
 // md (nullable): the workgroup's m and sum d2 from an EARLIER evaluation of the same correspondences (they do not depend on the
 // state): md[2] != 0 means md[0], md[1] are valid and the two wave reductions (twelve dependent cross-lane steps) are skipped;
 // otherwise they are computed and left there (thread kGicpSums keeps them).
@@ -546,10 +541,13 @@ __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, doub
   __syncthreads();
   double* out = partials + (size_t)blockIdx.x * kGicpPartialStride;
   if (threadIdx.x < 64) {
-    // wave 0: lane s < 13 adds the chunks of sum s, lane 13 has m and sum d2; then the 28 results are dealt to the lanes whose
-    // number is the entry's (two ds_bpermute per double), so that ONE store instruction writes the workgroup's whole answer --
-    // seven 64-byte requests towards the host instead of ten from four instructions (the answers of a run's workgroups reach
-    // the host over 1.2-2 us, the largest single item of an evaluation's wall time: icpgpu_gicp.cpp's stage timers)
+    // wave 0: lane s < 13 adds the chunks of sum s, lane 13 has m and sum d2; then the 28 results are dealt out as four ANSWER
+    // LINES of 64 bytes (icp_kernels.h: kGicpLine*): lanes 8 L .. 8 L + 6 hold values 7 L .. 7 L + 6, lane 8 L + 7 the line's tag =
+    // (evaluation number << 24) | the XOR of the values' 24-bit folds, and ONE 8-byte store instruction of 32 lanes writes the
+    // workgroup's whole answer -- four 64-byte requests towards the host where the 16-byte {value, tag} pairs of rounds 2-4
+    // took seven (the answers of a run's workgroups reach the host over 1.2-2 us, the largest single item of an evaluation's
+    // wall time, and the host's poll looks at 4 tags per workgroup instead of 28).  A line is valid or recognisably not in
+    // whatever order its bytes become visible, exactly like a pair.
     DD v{0.0, 0.0};
     double m = 0.0, d2 = 0.0;
     if (threadIdx.x < kGicpSums) {
@@ -565,11 +563,25 @@ __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, doub
         md[1] = d2;
       }
     }
-    const int e = (int)threadIdx.x;  // entry number
-    const double from_hi = __shfl(v.hi, e >= 1 ? e - 1 : 0, 64), from_lo = __shfl(v.lo, e >= 16 ? e - 16 : 0, 64);
+    const int lane = (int)threadIdx.x, pos = lane & 7;
+    const int slot = 7 * (lane >> 3) + pos;  // value number (pos < 7): 0 = m, 1..13 = high parts, 14 = sum d2, 15..27 = low parts
+    const double from_hi = __shfl(v.hi, min(max(slot - 1, 0), kGicpSums - 1), 64), from_lo = __shfl(v.lo, min(max(slot - 15, 0), kGicpSums - 1), 64);
     const double from_m = __shfl(m, kGicpSums, 64), from_d2 = __shfl(d2, kGicpSums, 64);
-    const double value = e == 0 ? from_m : e <= 13 ? from_hi : e == 14 ? from_d2 : from_lo;
-    if (e <= 28 && e != 15) gicp_store_tagged(out, e, value, tag);
+    const double value = slot == 0 ? from_m : slot <= 13 ? from_hi : slot == 14 ? from_d2 : from_lo;
+    const unsigned long long bits = pos < 7 ? (unsigned long long)__double_as_longlong(value) : 0ull;
+    unsigned int fold = (unsigned int)((bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull);
+    fold ^= (unsigned int)__shfl_xor((int)fold, 1, 64);
+    fold ^= (unsigned int)__shfl_xor((int)fold, 2, 64);
+    fold ^= (unsigned int)__shfl_xor((int)fold, 4, 64);  // every lane of the line: the XOR of its seven folds
+    const unsigned long long word = pos < 7 ? bits : (((tag & ~kMailboxReleaseBit) << 24) | (unsigned long long)fold);
+    unsigned long long* w = reinterpret_cast<unsigned long long*>(out) + lane;
+    if (tag & kMailboxReleaseBit) {  // the classic form: values, system-scope release, tags
+      if (lane < 8 * kGicpLines && pos < 7) __hip_atomic_store(w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      if (lane < 8 * kGicpLines && pos == 7) __hip_atomic_store(w, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (lane < 8 * kGicpLines) {
+      __hip_atomic_store(w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // written through to system memory (sc0 sc1)
+    }
   }
   if (md) md[2] = 1.0;
 }

@@ -246,7 +246,16 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
 // [2e, 2e + 1], written by ONE 16-byte store -- a pair is never seen half-written, so no flag and no system-scope release
 // (a write-back + a wait for the earlier stores' acknowledgements, 1-1.5 us) stands between the sums and the host; the host
 // takes a block's entry when its tag equals the evaluation's number.
+// Since round 5 a workgroup's answer is four ANSWER LINES of 64 bytes instead of 28 pairs: line L = doubles [8 L, 8 L + 8) of the
+// block's stride, seven values (numbers 7 L .. 7 L + 6 of: m, the 13 high parts, sum d2, the 13 low parts) and, in its last word,
+// the tag (evaluation number << 24) | XOR of the 24-bit folds of the seven values' bits -- written by ONE store instruction,
+// four 64-byte requests instead of seven; the host takes a block's lines when all four tags carry the evaluation's number and
+// their checksums (gicp_line_read).
 static constexpr int kGicpPartialStride = 64;
+static constexpr int kGicpLines = 4;
+inline unsigned long long gicp_line_fold(unsigned long long bits) { return (bits ^ (bits >> 24) ^ (bits >> 48)) & 0xFFFFFFull; }
+// host side: value number s (0 = m, 1..13 high parts, 14 = sum d2, 15..27 low parts) of a block whose lines have been validated
+inline double gicp_line_value(const volatile double* block, int s) { return block[8 * (s / 7) + (s % 7)]; }
 static constexpr int kGicpDirectBlocks = 256;  // capacity of the mailbox; gicp_direct_blocks() may use fewer
 int gicp_direct_blocks(int n_s, int most = kGicpDirectBlocks);
 hipError_t launch_gicp_cost_direct(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,

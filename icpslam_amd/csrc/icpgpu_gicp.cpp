@@ -170,26 +170,25 @@ static void gicp_server_stop(icpgpu_ctx* c) {
 }
 
 // 0: the flags arrived; 1: the stream went idle without them (the server gave up waiting); < 0: error
-// The entries a block publishes (icp_kernels.h: {value, tag} pairs): m, the 13 sums' high parts, sum d2, their low parts.
-static const int kGicpEntries[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
+// What a block publishes (icp_kernels.h: four answer lines of seven values + a tag): m, the 13 sums' high parts, sum d2, their low parts.
 static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
-  const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(mailbox);
-  // the numbers first (one compare per entry: this loop runs thousands of times per scan), the checksums only once every
-  // entry carries the number.  The pass over the numbers has NO early exit: the device's writes invalidate the host's cached
-  // copies of these lines (7 per workgroup), and a loop that leaves at the first stale entry fetches them one miss after the
-  // other -- without the branch the loads are independent and the misses overlap.
-  const volatile unsigned long long* w0 = w;
+  const volatile unsigned long long* w0 = reinterpret_cast<const volatile unsigned long long*>(mailbox);
+  // the numbers first (one compare per line, four lines per workgroup: this loop runs thousands of times per scan), the checksums
+  // only once every line carries the number.  The pass over the numbers has NO early exit: the device's writes invalidate the
+  // host's cached copies of these lines, and a loop that leaves at the first stale line fetches them one miss after the other
+  // -- without the branch the loads are independent and the misses overlap.
   unsigned long long stale = 0;
-  for (int b = 0; b < n_blocks; ++b) stale |= (w0[(size_t)b * kGicpPartialStride + 2 * 28 + 1] >> 24) ^ seq;  // one entry per workgroup: a cheap gate
-  if (stale) return false;  // (polling all entries instead -- fetching the lines as they arrive -- measured the same)
+  const volatile unsigned long long* w = w0;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
-    for (int e : kGicpEntries) stale |= (w[2 * e + 1] >> 24) ^ seq;
+    for (int L = 0; L < kGicpLines; ++L) stale |= (w[8 * L + 7] >> 24) ^ seq;
   if (stale) return false;
-  unsigned long long bits;
   w = w0;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
-    for (int e : kGicpEntries)
-      if (!mailbox_read(w + 2 * e, seq, &bits)) return false;  // a torn pair: looked at again on the next poll
+    for (int L = 0; L < kGicpLines; ++L) {
+      unsigned long long x = 0;
+      for (int k = 0; k < 7; ++k) x ^= gicp_line_fold(w[8 * L + k]);
+      if (w[8 * L + 7] != ((seq << 24) | x)) return false;  // a torn line: looked at again on the next poll
+    }
   return true;
 }
 // 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
@@ -201,7 +200,7 @@ static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, b
   for (unsigned spins = 1;; ++spins) {
     if (timing && !any_seen) {  // (development flavour: when does the FIRST workgroup's result show up, when the last?)
       const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(c->h_gicp);
-      for (int b = 0; b < n_blocks && !any_seen; ++b) any_seen = (w[(size_t)b * kGicpPartialStride + 2 * 28 + 1] >> 24) == seq;
+      for (int b = 0; b < n_blocks && !any_seen; ++b) any_seen = (w[(size_t)b * kGicpPartialStride + 8 * (kGicpLines - 1) + 7] >> 24) == seq;
       if (any_seen) t_any = std::chrono::steady_clock::now();
     }
     if (gicp_tags_ready(c->h_gicp, n_blocks, seq)) {
@@ -451,10 +450,10 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       {  // workgroup by workgroup, in double-double like the kernel (icp_gicp.hip): the 13 sums are rounded once, here
         double m = 0.0, d2 = 0.0, hi[13] = {}, lo[13] = {};
         const double* part = c->h_gicp;
-        for (int b = 0; b < nblk; ++b, part += kGicpPartialStride) {  // (entry e = doubles [2e] value, [2e + 1] tag)
-          m += part[0];
-          d2 += part[2 * 14];
-          for (int k = 0; k < 13; ++k) gicp_dd_add(hi[k], lo[k], part[2 * (1 + k)], part[2 * (16 + k)]);
+        for (int b = 0; b < nblk; ++b, part += kGicpPartialStride) {  // (value s of a block: icp_kernels.h, gicp_line_value)
+          m += gicp_line_value(part, 0);
+          d2 += gicp_line_value(part, 14);
+          for (int k = 0; k < 13; ++k) gicp_dd_add(hi[k], lo[k], gicp_line_value(part, 1 + k), gicp_line_value(part, 15 + k));
         }
         c->h_sums[0] = m;
         c->h_sums[14] = d2;
