@@ -1011,6 +1011,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __shared__ double s_sums[16];
   __shared__ int s_ok;
   __shared__ double s_table[128][4];
+  // (Measured and dropped in round 5: s_setprio 3 for this latency-bound wave and the evaluation server's -- no effect on an
+  //  evaluation's time, alone or with eight registrations in flight: profiles/r05_gicp_batch.txt.)
   const long long t_kernel0 = (long long)wall_clock64();
   int wid = (int)blockIdx.x, nw = (int)gridDim.x;
   if constexpr (LOCAL) {

@@ -393,7 +393,8 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     auto eval = [&](const Vec6& x, GicpEval& out) -> bool {
       float T[16];
       std::memcpy(T, guess, sizeof(T));
-      gicp_apply_state(T, x);
+      const gicp::Trig6 tr = gicp::trig6(x);  // the state's six sine / cosine pairs (correctly rounded, double-double: ~0.2 us on the
+      gicp::apply_state(T, x, tr);            //  host) once per evaluation: the transform here, the gradient below (as the device solver does)
       // ~300 evaluations per align, each a dependent launch: ONE kernel of a few workgroups whose partial sums land in the
       // polled host mailbox; the host adds them in workgroup order (deterministic)
       const auto t_eval0 = std::chrono::steady_clock::now();
@@ -474,7 +475,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       c->prof.gicp_eval_corr += (uint64_t)s[0];
       m_count = s[0];
       mse = s[0] > 0 ? s[14] / s[0] : 0.0;
-      gicp::eval_from_sums(x, s, out);
+      gicp::eval_from_sums(tr, s, out);
       return true;
     };
     // rigid_transformation_estimation_: the whole BFGS run on the device (gicp_solve_kernel), one result for the host to poll
