@@ -242,6 +242,7 @@ struct icpgpu_ctx {
   unsigned long long* h_solve_dev = nullptr;
   unsigned long long gicp_solve_seq = 0;
   bool gicp_device_ok = false;
+  bool gicp_resources_ready = false;  // ensure_gicp_resources has run (icpgpu_context.cpp)
   // measured mode: 0 = still timing both solvers, 1 = host, 2 = device; microseconds and evaluations of the timed inner
   // minimisations, [0] host [1] device (the first run of each is a warm-up and not counted)
   int gicp_choice = 0;
@@ -422,6 +423,9 @@ unsigned long long sample_fingerprint(const float* xyzw, size_t n);
 int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, const int* d_extra = nullptr, int n_extra = 0, int* extra_out = nullptr);
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
 int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
+int ensure_gicp_resources(icpgpu_ctx* c);
+int create_context(icpgpu_ctx** out_ctx, int device_id, bool with_stream);
+int ensure_stream(icpgpu_ctx* c);
 int promote_internal(icpgpu_ctx* c);
 // icpgpu_index.cpp
 int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,

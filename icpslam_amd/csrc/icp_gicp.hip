@@ -640,7 +640,8 @@ __global__ __launch_bounds__(256) void gicp_server_kernel(const float4* __restri
       unsigned int got = kGicpServerExit, word = 0u;
       const long long t0 = (long long)wall_clock64();
       // (One read in flight, 0.18 us each.  Four -- a hand-written loop behind s_waitcnt vmcnt(3) -- were measured in round 4 and
-      // made an evaluation SLOWER, 8.3 instead of 7.1 us.)
+      // made an evaluation SLOWER, 8.3 instead of 7.1 us.  Round 5, the other direction: an s_sleep of 128 / 384 clocks between
+      // polls changes nothing either, alone or with eight servers resident: profiles/r05_gicp_batch.txt.)
       const unsigned int* line = &cmd[threadIdx.x & 15];
       unsigned int polls_done = 0;
       for (unsigned int polls = 1;; ++polls) {

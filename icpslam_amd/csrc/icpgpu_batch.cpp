@@ -84,6 +84,10 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   const bool lockstep = lockstep_on && !gicp;
   // GICP: resumable runs leave the host free (two threads x four runs measured 1.72k pairs/s on 13k-point clouds, one x eight 1.6-1.7k,
   // eight x one 1.5k: profiles/r05_gicp_batch.txt); without the device solver every run is a blocking host loop and wants its own thread
+  if (gicp) {
+    const int grc = ensure_gicp_resources(c);
+    if (grc) return grc;
+  }
   const bool gicp_runs = gicp && gicp_device_solver_mode() != 0 && c->gicp_device_ok;
   size_t n_threads = batch_threads(c, gicp ? (gicp_runs ? 2 : 8) : 4), depth = 1;
   if (!gicp) {
@@ -111,12 +115,38 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   }
   const size_t per_thread = groups_per_thread * depth;
   const size_t n_ctx = n_threads * per_thread;
-  while (c->workers.size() < n_ctx) {
-    icpgpu_ctx* w = nullptr;
-    const int rc = icpgpu_create(&w, c->device);
-    if (rc != ICPGPU_OK) return fail(c, rc, "align_batch: worker context: %s", icpgpu_last_error(nullptr));
-    w->shared_table_cells = &c->batch_table_cells;
-    c->workers.push_back(w);
+  // Worker contexts are created on first use, by the batch threads in parallel (a context is a stream, two hundred events and a
+  // dozen pinned / fine-grained / device allocations: ~1 ms, and a batch wants up to 64 of them -- created one after the other by
+  // the calling thread they were most of the first call's time)
+  double create_ms = 0.0;
+  if (c->workers.size() < n_ctx) {
+    const auto t_create = std::chrono::steady_clock::now();
+    const size_t have = c->workers.size();
+    c->workers.resize(n_ctx, nullptr);
+    std::vector<int> create_rc(n_ctx, ICPGPU_OK);
+    std::vector<std::string> create_msg(n_ctx);  // (icpgpu_last_error(nullptr) is per thread: taken where it was set)
+    std::vector<std::thread> makers;
+    const size_t n_makers = std::min<size_t>(std::max<size_t>(1, n_threads), n_ctx - have);
+    for (size_t m = 0; m < n_makers; ++m)
+      makers.emplace_back([&, m] {
+        for (size_t i = have + m; i < n_ctx; i += n_makers) {
+          icpgpu_ctx* w = nullptr;
+          create_rc[i] = create_context(&w, c->device, /*with_stream=*/!lockstep);  // (lock-step workers run on their group's stream)
+          if (create_rc[i] == ICPGPU_OK) w->shared_table_cells = &c->batch_table_cells;
+          else create_msg[i] = icpgpu_last_error(nullptr);
+          c->workers[i] = w;
+        }
+      });
+    for (auto& th : makers) th.join();
+    for (size_t i = have; i < n_ctx; ++i)
+      if (create_rc[i] != ICPGPU_OK) {
+        const int rc = create_rc[i];
+        for (size_t k = have; k < n_ctx; ++k)
+          if (c->workers[k]) icpgpu_destroy(c->workers[k]);
+        c->workers.resize(have);
+        return fail(c, rc, "align_batch: worker context: %s", create_msg[i].c_str());
+      }
+    create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
   }
   // The groups' streams are created HERE, one after the other: the runtime spreads streams over its (four) hardware queues in
   // creation order, and kernels of streams that share a hardware queue do not overlap.  Until round 5 a group ran on its lead
@@ -124,12 +154,27 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   // same hardware queue and the groups' sweeps ran one after the other: 4.1-4.5k pairs/s at config 4's shape where depths of
   // 5 or 7 reached 5.1-5.5k (rocprofv3 kernel trace: 2 queues in use, mostly one search kernel at a time, against 4 queues and
   // 2-4 kernels; profiles/r05_batch_groups.txt).
-  if (lockstep)
-    while (c->group_streams.size() < n_threads * groups_per_thread) {
-      hipStream_t st = nullptr;
-      HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-      c->group_streams.push_back(st);
-    }
+  // (hipStreamCreate is 3-4 ms apiece on this runtime when called in a row -- scripts/probes/create_probe.cpp -- and well under a
+  //  millisecond each from several threads at once: the missing streams are created side by side, then appended in order)
+  if (lockstep && c->group_streams.size() < n_threads * groups_per_thread) {
+    const size_t have = c->group_streams.size(), want = n_threads * groups_per_thread;
+    std::vector<hipStream_t> fresh(want - have, nullptr);
+    std::vector<hipError_t> fresh_rc(want - have, hipSuccess);
+    std::vector<std::thread> makers;
+    for (size_t k = 0; k < fresh.size(); ++k)
+      makers.emplace_back([&, k] {
+        fresh_rc[k] = hipSetDevice(c->device);
+        if (fresh_rc[k] == hipSuccess) fresh_rc[k] = hipStreamCreateWithFlags(&fresh[k], hipStreamNonBlocking);
+      });
+    for (auto& th : makers) th.join();
+    for (size_t k = 0; k < fresh.size(); ++k)
+      if (fresh_rc[k] != hipSuccess) {
+        for (hipStream_t st : fresh)
+          if (st) (void)hipStreamDestroy(st);
+        return fail(c, ICPGPU_ERR_HIP, "align_batch: hipStreamCreate: %s", hipGetErrorString(fresh_rc[k]));
+      }
+    for (hipStream_t st : fresh) c->group_streams.push_back(st);
+  }
   const auto t_call = std::chrono::steady_clock::now();
   std::atomic<size_t> next{0};
   std::atomic<bool> abort{false};
@@ -172,6 +217,9 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       // apiece for 8 workers, as measured in round 1; a lone alignment uses up to 256)
       ws[s]->gicp_blocks_most = std::max(16, std::min(kGicpDirectBlocks, 512 / (int)std::max<size_t>(1, n_threads * (gicp ? depth : 1))));
     }
+    if (!lockstep)  // these paths run every worker on its own stream
+      for (size_t s = 0; s < per_thread; ++s)
+        if (ensure_stream(ws[s])) return failed(ICPGPU_ERR_HIP, 0, ws[s]);
     if (gicp) {
       // GICP: `depth` resumable runs per thread, round-robin (GicpRun, icpgpu_gicp.cpp): the thread queues a run's next stage when
       // its awaited result has arrived and looks at the others meanwhile -- until round 5 it was ONE blocking alignment per
@@ -748,8 +796,8 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   {
     static const bool trace = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_BATCH_TRACE"); return e && std::atoi(e) != 0; }();
     if (trace)
-      fprintf(stderr, "[icpgpu] batch trace: call of %zu pairs took %.2f ms; device allocations so far in this process: %llu, %.2f ms of host time\n", n_pairs,
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), g_alloc_calls.load(), g_alloc_us.load() * 1e-3);
+      fprintf(stderr, "[icpgpu] batch trace: call of %zu pairs took %.2f ms (+ %.2f ms creating worker contexts); device allocations so far in this process: %llu, %.2f ms of host time\n", n_pairs,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(), create_ms, g_alloc_calls.load(), g_alloc_us.load() * 1e-3);
   }
   for (const ThreadError& e : errors)  // the first failure in thread order (each thread stops at its first)
     if (e.code != ICPGPU_OK) {

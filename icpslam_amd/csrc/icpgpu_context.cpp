@@ -5,6 +5,8 @@
 // There is deliberately no CPU fallback: if HIP or the device is unusable every entry point fails loudly.
 #include "icp_ctx.h"
 
+#include <mutex>
+
 
 namespace icpgpu_impl {
 
@@ -222,121 +224,23 @@ int device_fingerprint(icpgpu_ctx* c, const Cloud& cl, uint64_t version, unsigne
   return ICPGPU_OK;
 }
 
-}  // namespace icpgpu_impl
 
-extern "C" {
-
-int icpgpu_version(void) { return ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR; }
-
-void icpgpu_default_params(icpgpu_params* p) {
-  if (!p) return;
-  std::memset(p, 0, sizeof(*p));
-  p->method = ICPGPU_P2P_SVD;
-  p->max_iterations = 10;                    // icp_odometer.h:65
-  p->transformation_epsilon = 1e-6;          // icp_odometer.h:64
-  p->max_correspondence_distance = 1.0;      // icp_odometer.h:63
-  p->euclidean_fitness_epsilon = -DBL_MAX;   // PCL default
-  p->min_correspondences = 3;                // PCL default
-  p->force_iterations = 0;
-  p->nn_mode = ICPGPU_NN_AUTO;
-  p->brute_variant = 0;
-}
-
-int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
-  if (!out_ctx) return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "out_ctx is null");
-  *out_ctx = nullptr;
-  int count = 0;
-  hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count <= 0)
-    return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "no HIP device available (%s); libicpgpu has no CPU fallback",
-                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-  if (device_id < 0 || device_id >= count)
-    return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "device_id %d out of range [0, %d)", device_id, count);
-  hipDeviceProp_t prop;
-  e = hipGetDeviceProperties(&prop, device_id);
-  if (e != hipSuccess) return fail(nullptr, ICPGPU_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-    return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "device %d is %s; libicpgpu is built for gfx950 (MI355X) only", device_id,
-                prop.gcnArchName);
-
-  icpgpu_ctx* c = new (std::nothrow) icpgpu_ctx();
-  if (!c) return fail(nullptr, ICPGPU_ERR_OOM, "out of host memory");
-  c->device = device_id;
-  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  icpgpu_default_params(&c->params);
-  if (const char* v = ICPGPU_DEV_ENV("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
-
-  auto bail = [&](const char* what, hipError_t err) {
-    std::string msg = std::string(what) + ": " + hipGetErrorString(err);
-    icpgpu_destroy(c);
-    return fail(nullptr, err == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "%s", msg.c_str());
-  };
-  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-  for (auto& ev : c->ev)
-    if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  // mailbox: 24 doubles the host keeps the current sums (and a few spare slots) in, then the 17 {sum, number} pairs the
-  // device writes (reduce_final_kernel)
-  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + 2 * kReduceTerms) * sizeof(double),
-                         hipHostMallocMapped | hipHostMallocCoherent)) !=  // fine-grained: the polled flags must become visible without a sync
-      hipSuccess)
-    return bail("hipHostMalloc", e);
-  std::memset(c->h_sums, 0, (24 + 2 * kReduceTerms) * sizeof(double));
-  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_sums_dev), c->h_sums, 0)) != hipSuccess)
-    return bail("hipHostGetDevicePointer", e);
-  c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
-  c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
-  {
-    // How result pairs leave the device (icp_kernels.h): ICPGPU_MAILBOX=pairs|release decides; otherwise the self-test does,
-    // once per device and process: 4096 pairs into one slot, read back concurrently; one torn pair selects the release form.
-    static std::atomic<int> verdict[64];  // 0 unknown, 1 pairs, 2 release
-    const int slot = device_id >= 0 && device_id < 64 ? device_id : 0;
-    int v = verdict[slot].load();
-    if (const char* m = std::getenv("ICPGPU_MAILBOX")) v = std::strcmp(m, "release") == 0 ? 2 : (std::strcmp(m, "pairs") == 0 ? 1 : v);
-    if (v == 0) {
-      volatile unsigned long long* pair = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 22);
-      unsigned long long* pair_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 22);
-      const int rounds = 4096;
-      pair[0] = pair[1] = 0;
-      if ((e = launch_mailbox_selftest(pair_dev, rounds, c->stream)) != hipSuccess) return bail("mailbox self-test", e);
-      unsigned long long torn = 0, seen = 0, last = 0;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (unsigned spins = 1;; ++spins) {
-        const unsigned long long tag = pair[1], bits = pair[0], tag2 = pair[1];
-        const unsigned long long n = tag >> 24;
-        if (tag == tag2 && n >= 1 && n <= (unsigned long long)rounds) {
-          if (tag != mailbox_tag(n, bits)) ++torn;
-          if (n != last) {
-            ++seen;
-            last = n;
-          }
-        }
-        if (n == (unsigned long long)rounds) break;
-        if ((spins & 0xFFFu) == 0 &&
-            (hipStreamQuery(c->stream) != hipErrorNotReady ||
-             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2000.0))
-          break;
-      }
-      if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("mailbox self-test", e);
-      v = torn ? 2 : 1;
-      if (std::getenv("ICPGPU_DEBUG"))
-        fprintf(stderr, "[icpgpu] mailbox self-test on device %d: %llu of %d pairs observed, %llu torn -> %s\n", device_id, seen, rounds, torn,
-                v == 2 ? "release form" : "16-byte pairs");
-      pair[0] = pair[1] = 0;
-      verdict[slot].store(v);
-    }
-    c->mailbox_release = v == 2;
-  }
+// GICP's resources -- the evaluation mailbox, the server's command line, the device solver's slots and result granules -- are
+// allocated when a context first registers in GICP mode (align_gicp, gicp_run_begin), not with the context: five allocations
+// and three synchronous memsets that a point-to-point batch worker never uses (icpgpu_align_batch creates up to 64 workers).
+int ensure_gicp_resources(icpgpu_ctx* c) {
+  if (c->gicp_resources_ready) return ICPGPU_OK;
+  hipError_t e;
   {
     const size_t n_flags_end = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8 + kGicpDirectBlocks;  // partials, gap, flags
     const size_t cmd_off = (n_flags_end + 7) & ~(size_t)7;                                        // 64-byte aligned
     const size_t n_d = cmd_off + 8;                                                              // + the server's command line
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_gicp), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
         hipSuccess)
-      return bail("hipHostMalloc", e);
+      return fail(c, e == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
     std::memset(c->h_gicp, 0, n_d * sizeof(double));
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_gicp_dev), c->h_gicp, 0)) != hipSuccess)
-      return bail("hipHostGetDevicePointer", e);
+      return fail(c, ICPGPU_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
     const size_t off = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8;
     c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
     c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
@@ -371,12 +275,162 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
       (void)hipGetLastError();
       c->gicp_cmd = nullptr;
     } else if ((e = hipMemset(c->gicp_cmd, 0, 4096)) != hipSuccess) {
-      return bail("hipMemset", e);
+      return fail(c, ICPGPU_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
     }
   }
-  c->ev_ring.assign((size_t)kEventRing * 3, nullptr);
-  for (auto& ev : c->ev_ring)
+  c->gicp_resources_ready = true;
+  return ICPGPU_OK;
+}
+
+}  // namespace icpgpu_impl
+
+extern "C" {
+
+int icpgpu_version(void) { return ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR; }
+
+void icpgpu_default_params(icpgpu_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->method = ICPGPU_P2P_SVD;
+  p->max_iterations = 10;                    // icp_odometer.h:65
+  p->transformation_epsilon = 1e-6;          // icp_odometer.h:64
+  p->max_correspondence_distance = 1.0;      // icp_odometer.h:63
+  p->euclidean_fitness_epsilon = -DBL_MAX;   // PCL default
+  p->min_correspondences = 3;                // PCL default
+  p->force_iterations = 0;
+  p->nn_mode = ICPGPU_NN_AUTO;
+  p->brute_variant = 0;
+}
+
+int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) { return create_context(out_ctx, device_id, /*with_stream=*/true); }
+
+}  // extern "C"
+
+namespace icpgpu_impl {
+
+// A context's own stream, for contexts created without one (batch workers: below)
+int ensure_stream(icpgpu_ctx* c) {
+  if (c->stream) return ICPGPU_OK;
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  return ICPGPU_OK;
+}
+
+// icpgpu_create.  with_stream = false: a batch worker that will run inside a lock-step group on the GROUP's stream
+// (icpgpu_batch.cpp) -- hipStreamCreate is 0.6-4 ms on this runtime (scripts/probes/create_probe.cpp; everything else a context
+// needs comes to ~0.1 ms), and a batch wants up to 64 workers but only eight streams; a worker that ends up on the round-robin
+// or GICP path gets its stream then (ensure_stream).
+int create_context(icpgpu_ctx** out_ctx, int device_id, bool with_stream) {
+  if (!out_ctx) return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "out_ctx is null");
+  *out_ctx = nullptr;
+  // The device's identity is looked up once per process and device: hipGetDeviceProperties alone is most of a millisecond, and
+  // icpgpu_align_batch creates up to 64 worker contexts on its first call.
+  struct DeviceInfo {
+    int state = 0;  // 0 unknown, 1 a gfx950 device, 2 looked up and unusable
+    int cus = 256;
+    char arch[64] = {0};
+  };
+  static std::mutex info_mutex;
+  static int info_count = -1;
+  static DeviceInfo info[64];
+  hipError_t e = hipSuccess;
+  int cus = 256;
+  {
+    std::lock_guard<std::mutex> lock(info_mutex);
+    if (info_count < 0) {
+      int count = 0;
+      e = hipGetDeviceCount(&count);
+      if (e != hipSuccess || count <= 0)
+        return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "no HIP device available (%s); libicpgpu has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+      info_count = count;
+    }
+    if (device_id < 0 || device_id >= info_count)
+      return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "device_id %d out of range [0, %d)", device_id, info_count);
+    DeviceInfo local;
+    DeviceInfo& di = device_id < 64 ? info[device_id] : local;
+    if (di.state == 0) {
+      hipDeviceProp_t prop;
+      e = hipGetDeviceProperties(&prop, device_id);
+      if (e != hipSuccess) return fail(nullptr, ICPGPU_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+      std::strncpy(di.arch, prop.gcnArchName, sizeof(di.arch) - 1);
+      di.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      di.state = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 2;
+    }
+    if (di.state != 1)
+      return fail(nullptr, ICPGPU_ERR_NO_DEVICE, "device %d is %s; libicpgpu is built for gfx950 (MI355X) only", device_id, di.arch);
+    cus = di.cus;
+  }
+
+  icpgpu_ctx* c = new (std::nothrow) icpgpu_ctx();
+  if (!c) return fail(nullptr, ICPGPU_ERR_OOM, "out of host memory");
+  c->device = device_id;
+  c->num_cus = cus;
+  icpgpu_default_params(&c->params);
+  if (const char* v = ICPGPU_DEV_ENV("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
+
+  auto bail = [&](const char* what, hipError_t err) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(err);
+    icpgpu_destroy(c);
+    return fail(nullptr, err == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "%s", msg.c_str());
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+  if (with_stream && (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  for (auto& ev : c->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  // mailbox: 24 doubles the host keeps the current sums (and a few spare slots) in, then the 17 {sum, number} pairs the
+  // device writes (reduce_final_kernel)
+  if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_sums), (24 + 2 * kReduceTerms) * sizeof(double),
+                         hipHostMallocMapped | hipHostMallocCoherent)) !=  // fine-grained: the polled flags must become visible without a sync
+      hipSuccess)
+    return bail("hipHostMalloc", e);
+  std::memset(c->h_sums, 0, (24 + 2 * kReduceTerms) * sizeof(double));
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_sums_dev), c->h_sums, 0)) != hipSuccess)
+    return bail("hipHostGetDevicePointer", e);
+  c->h_flags = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 24);
+  c->h_flags_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 24);
+  {
+    // How result pairs leave the device (icp_kernels.h): ICPGPU_MAILBOX=pairs|release decides; otherwise the self-test does,
+    // once per device and process: 4096 pairs into one slot, read back concurrently; one torn pair selects the release form.
+    static std::atomic<int> verdict[64];  // 0 unknown, 1 pairs, 2 release
+    const int slot = device_id >= 0 && device_id < 64 ? device_id : 0;
+    int v = verdict[slot].load();
+    if (const char* m = std::getenv("ICPGPU_MAILBOX")) v = std::strcmp(m, "release") == 0 ? 2 : (std::strcmp(m, "pairs") == 0 ? 1 : v);
+    if (v == 0 && !c->stream && (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if (v == 0) {
+      volatile unsigned long long* pair = reinterpret_cast<volatile unsigned long long*>(c->h_sums + 22);
+      unsigned long long* pair_dev = reinterpret_cast<unsigned long long*>(c->h_sums_dev + 22);
+      const int rounds = 4096;
+      pair[0] = pair[1] = 0;
+      if ((e = launch_mailbox_selftest(pair_dev, rounds, c->stream)) != hipSuccess) return bail("mailbox self-test", e);
+      unsigned long long torn = 0, seen = 0, last = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 1;; ++spins) {
+        const unsigned long long tag = pair[1], bits = pair[0], tag2 = pair[1];
+        const unsigned long long n = tag >> 24;
+        if (tag == tag2 && n >= 1 && n <= (unsigned long long)rounds) {
+          if (tag != mailbox_tag(n, bits)) ++torn;
+          if (n != last) {
+            ++seen;
+            last = n;
+          }
+        }
+        if (n == (unsigned long long)rounds) break;
+        if ((spins & 0xFFFu) == 0 &&
+            (hipStreamQuery(c->stream) != hipErrorNotReady ||
+             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2000.0))
+          break;
+      }
+      if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("mailbox self-test", e);
+      v = torn ? 2 : 1;
+      if (std::getenv("ICPGPU_DEBUG"))
+        fprintf(stderr, "[icpgpu] mailbox self-test on device %d: %llu of %d pairs observed, %llu torn -> %s\n", device_id, seen, rounds, torn,
+                v == 2 ? "release form" : "16-byte pairs");
+      pair[0] = pair[1] = 0;
+      verdict[slot].store(v);
+    }
+    c->mailbox_release = v == 2;
+  }
+  c->ev_ring.assign((size_t)kEventRing * 3, nullptr);  // (created when a slot is first timed: sweep_issue)
   c->pending.reserve(kEventRing);
   {
     void* hp = nullptr;
@@ -395,6 +449,10 @@ int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) {
   *out_ctx = c;
   return ICPGPU_OK;
 }
+
+}  // namespace icpgpu_impl
+
+extern "C" {
 
 int icpgpu_destroy(icpgpu_ctx* c) {
   if (c && c->pt_n)

@@ -312,6 +312,10 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     t_mark = now;
   };
   init_result(res);
+  {
+    const int grc = ensure_gicp_resources(c);
+    if (grc) return grc;
+  }
   c->prof.aligns += 1;
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   const icpgpu_params& P = c->params;
@@ -757,6 +761,10 @@ int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* r
   r.t_start = std::chrono::steady_clock::now();
   r.res = res;
   r.want_fitness = want_fitness;
+  {
+    const int grc = ensure_gicp_resources(c);
+    if (grc) return grc;
+  }
   if (!gicp_run_device_ok(c)) {  // no device solver on this context: the blocking function
     r.phase = GicpRun::Blocking;
     return ICPGPU_OK;

@@ -189,6 +189,8 @@ int sweep_issue(icpgpu_ctx* c, const Xform& T, float thr, bool open_range, Sweep
   const unsigned long long seq = ++c->sums_seq;
   // kernel timing is sampled: an event record is a barrier packet on the queue, three of them per sweep cost 6-7 us
   const bool timed = c->timing_every <= 1 || (c->sweep_counter++ % (unsigned)c->timing_every) == 0;
+  if (timed && !ev[0])  // the ring's events are created when a slot is first timed (192 events per context up front were a third of
+    for (int k = 0; k < 3; ++k) HIP_TRY(c, hipEventCreate(&ev[k]));  // icpgpu_create's millisecond, and a batch creates 64 contexts)
 #define EVREC(e) do { if (timed) HIP_TRY(c, hipEventRecord((e), c->stream)); } while (0)
   EVREC(ev[0]);
   const float4* red_src = nullptr;
