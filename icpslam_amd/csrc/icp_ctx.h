@@ -392,7 +392,12 @@ struct P2PRun {
 // A GICP registration as a resumable run (icpgpu_gicp.cpp: gicp_run_begin / gicp_run_step): the counterpart of P2PRun for the
 // solver the reference instantiates, so that one host thread of icpgpu_align_batch keeps several registrations in flight.
 struct GicpRun {
-  enum Phase { Idle, Blocking, CovGrid, Solve, Fitness, Done } phase = Idle;
+  enum Phase { Idle, Blocking, CovGrid, WantSolve, Solve, Fitness, Done } phase = Idle;
+  // combine: the run does not launch its outer iteration's solver itself -- it stops in WantSolve with `item` filled in, and the
+  // batch scheduler launches the solvers of all the runs that are ready in ONE kernel (gicp_solve_batch_kernel) on solve_stream
+  bool combine = false;
+  GicpSolveItem item{};
+  hipStream_t solve_stream = nullptr;  // where the run's solver was launched (its own stream unless combined)
   float guess[16], transformation[16], previous[16];
   float thr = 0.f, thr_excl = 0.f;
   int nr = 0, state = ICPGPU_NOT_CONVERGED, want_fitness = 0, cov_stage = 0;
@@ -472,7 +477,8 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
 // icpgpu_gicp.cpp
 int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version);
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res);
-int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res);
+int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res, bool combine = false);
 int gicp_run_step(icpgpu_ctx* c, GicpRun& r);  // < 0 error, 0 nothing yet, 1 moved on (r.phase == GicpRun::Done: finished)
+void gicp_run_solver_launched(icpgpu_ctx* c, GicpRun& r, hipStream_t solve_stream);  // WantSolve -> Solve (the scheduler launched r.item)
 
 }  // namespace icpgpu_impl

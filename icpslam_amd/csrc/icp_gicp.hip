@@ -1007,15 +1007,17 @@ struct DeviceEval {
   }
 };
 
+// The body of a run: `bx` of `n_launched` workgroups (blockIdx.x / gridDim.x of the single-run launch; in a batched launch the
+// run's own numbers).
 template <bool RESIDENT, bool LOCAL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gicp_solve_kernel(GicpSolveArgs A) {
+__device__ __forceinline__ void gicp_solve_body(const GicpSolveArgs& A, int bx, int n_launched) {
   __shared__ double s_sums[16];
   __shared__ int s_ok;
   __shared__ double s_table[128][4];
   // (Measured and dropped in round 5: s_setprio 3 for this latency-bound wave and the evaluation server's -- no effect on an
   //  evaluation's time, alone or with eight registrations in flight: profiles/r05_gicp_batch.txt.)
   const long long t_kernel0 = (long long)wall_clock64();
-  int wid = (int)blockIdx.x, nw = (int)gridDim.x;
+  int wid = bx, nw = n_launched;
   if constexpr (LOCAL) {
     // Eight times the workgroups the run needs are launched; a workgroup takes part iff the hardware says it sits on XCD
     // xcc_want -- round-robin dispatch puts workgroup b on XCD b % 8, so those are the ones with one residue and b / 8 numbers
@@ -1025,7 +1027,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned int xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     if ((int)(xcc & 0xFu) != A.xcc_want) return;
-    wid = (int)blockIdx.x >> 3;
+    wid = bx >> 3;
     nw = A.workers;
     if (wid >= nw) return;
     __shared__ int s_mine;
@@ -1088,6 +1090,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     granule_store(o + 2 * 19, 0.0, A.host_seq);
     granule_store(o + 2 * 0, (double)status, A.host_seq);
   }
+}
+
+template <bool RESIDENT, bool LOCAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gicp_solve_kernel(GicpSolveArgs A) {
+  gicp_solve_body<RESIDENT, LOCAL>(A, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several runs in ONE launch (icpgpu_align_batch in GICP mode): run = blockIdx.y, its own workgroups 0 .. workers - 1 (the
+// others leave at once), its own slots, mailbox and numbers -- the runs share nothing but the launch.  Why: the runtime puts
+// streams on four hardware queues and kernels that share a queue run one after the other, so with one resident solver kernel
+// per run and outer iteration no more than four registrations ever solved at the same time (1.7k pairs/s whatever the
+// scheduler, round 5: profiles/r05_gicp_batch.txt); one launch for all the runs that are ready lifts that.  Any placement
+// (fine-grained slots): the one-XCD variant's placement trick does not compose with blockIdx.y.
+struct GicpSolveBatchArgs {
+  GicpSolveArgs a[kGicpSolveBatchMax];
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gicp_solve_batch_kernel(GicpSolveBatchArgs B) {
+  const GicpSolveArgs& A = B.a[blockIdx.y];
+  if ((int)blockIdx.x >= A.workers) return;
+  gicp_solve_body<true, false>(A, (int)blockIdx.x, A.workers);
 }
 
 }  // namespace
@@ -1191,6 +1213,39 @@ hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float
   } else {
     hipLaunchKernelGGL((gicp_solve_kernel<false, false>), dim3(blocks), dim3(256), 0, stream, A);
   }
+  return hipGetLastError();
+}
+hipError_t launch_gicp_solve_batch(const GicpSolveItem* items, int n, int max_inner, double gradient_tol, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (n > kGicpSolveBatchMax) return hipErrorInvalidValue;
+  GicpSolveBatchArgs B;
+  int max_blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const GicpSolveItem& it = items[k];
+    if ((long long)it.blocks * 1024 < it.n_s) return hipErrorInvalidValue;  // resident shares only (the caller launches the others singly)
+    GicpSolveArgs& A = B.a[k];
+    A.src = it.src;
+    A.n_s = it.n_s;
+    A.tgt = it.tgt;
+    A.keys = it.keys;
+    A.thr = it.thr;
+    A.base = it.base;
+    for (int i = 0; i < 16; ++i) A.guess[i] = it.guess[i];
+    A.maha6 = it.maha6;
+    for (int i = 0; i < 6; ++i) A.x0[i] = it.x0[i];
+    A.slots = it.slots;
+    A.host_out = it.host_out;
+    A.seq0 = it.seq0 & ~kMailboxReleaseBit;
+    A.host_seq = it.seq0;
+    A.max_inner = max_inner;
+    A.gradient_tol = gradient_tol;
+    A.workers = it.blocks;
+    A.xcc_want = 0;
+    A.owner = nullptr;
+    max_blocks = it.blocks > max_blocks ? it.blocks : max_blocks;
+  }
+  for (int k = n; k < kGicpSolveBatchMax; ++k) B.a[k] = B.a[0];
+  hipLaunchKernelGGL(gicp_solve_batch_kernel, dim3(max_blocks, n), dim3(256), 0, stream, B);
   return hipGetLastError();
 }
 int gicp_solve_local_blocks() { return kSolveLocalBlocks; }

@@ -280,6 +280,25 @@ hipError_t launch_gicp_solve(int blocks, const float4* src, int n_s, const float
 // one-XCD variant (local_slots / owner given, <= gicp_solve_local_blocks() workgroups, correspondences resident): ordinary device
 // memory (gicp_solve_slot_bytes) for the granules, kGicpDirectBlocks words for the worker claims
 int gicp_solve_local_blocks();
+// Several runs' device solvers in one launch (gicp_solve_batch_kernel): every item a RESIDENT run (blocks x 1024 >= n_s) with its
+// own slots / host_out / numbers, as launch_gicp_solve takes them (seq0 may carry kMailboxReleaseBit); any placement.
+constexpr int kGicpSolveBatchMax = 8;
+struct GicpSolveItem {
+  const float4* src;
+  int n_s;
+  const float4* tgt;
+  const unsigned long long* keys;
+  float thr;
+  Xform base;
+  float guess[16];
+  const double* maha6;
+  double x0[6];
+  unsigned long long* slots;
+  unsigned long long* host_out;
+  unsigned long long seq0;
+  int blocks;
+};
+hipError_t launch_gicp_solve_batch(const GicpSolveItem* items, int n, int max_inner, double gradient_tol, hipStream_t stream);
 bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value);
 static constexpr unsigned int kGicpServerExit = 0xFFFFFFFFu;
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,

@@ -98,6 +98,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     // GICP: kGicpRunsInFlight resumable runs over all threads (each keeps its solver's workgroups resident: eight of them, one
     // per XCD, is what the chip holds with room for everybody's searches -- kMaxServerWorkers); ICPGPU_BATCH_DEPTH = runs per thread
     if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));
+    else if (gicp_runs) depth = std::max<size_t>(1, (16 + n_threads - 1) / n_threads);  // 16 runs in flight: their solvers leave in combined launches (below)
     else depth = std::max<size_t>(1, (kMaxServerWorkers + n_threads - 1) / n_threads);
   }
   n_threads = std::min(n_threads, n_pairs);
@@ -131,7 +132,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       makers.emplace_back([&, m] {
         for (size_t i = have + m; i < n_ctx; i += n_makers) {
           icpgpu_ctx* w = nullptr;
-          create_rc[i] = create_context(&w, c->device, /*with_stream=*/!lockstep);  // (lock-step workers run on their group's stream)
+          create_rc[i] = create_context(&w, c->device, /*with_stream=*/!(lockstep || gicp_runs));  // (lock-step workers run on their group's stream, GICP runs on their thread's)
           if (create_rc[i] == ICPGPU_OK) w->shared_table_cells = &c->batch_table_cells;
           else create_msg[i] = icpgpu_last_error(nullptr);
           c->workers[i] = w;
@@ -156,8 +157,11 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
   // 2-4 kernels; profiles/r05_batch_groups.txt).
   // (hipStreamCreate is 3-4 ms apiece on this runtime when called in a row -- scripts/probes/create_probe.cpp -- and well under a
   //  millisecond each from several threads at once: the missing streams are created side by side, then appended in order)
-  if (lockstep && c->group_streams.size() < n_threads * groups_per_thread) {
-    const size_t have = c->group_streams.size(), want = n_threads * groups_per_thread;
+  // (GICP runs: four streams per thread, created in a row = one per hardware queue: the combined solver launches on the first,
+  //  the runs' short kernels spread over the others)
+  const size_t streams_wanted = lockstep ? n_threads * groups_per_thread : (gicp_runs ? 4 * n_threads : 0);
+  if (c->group_streams.size() < streams_wanted) {
+    const size_t have = c->group_streams.size(), want = streams_wanted;
     std::vector<hipStream_t> fresh(want - have, nullptr);
     std::vector<hipError_t> fresh_rc(want - have, hipSuccess);
     std::vector<std::thread> makers;
@@ -217,7 +221,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       // apiece for 8 workers, as measured in round 1; a lone alignment uses up to 256)
       ws[s]->gicp_blocks_most = std::max(16, std::min(kGicpDirectBlocks, 512 / (int)std::max<size_t>(1, n_threads * (gicp ? depth : 1))));
     }
-    if (!lockstep)  // these paths run every worker on its own stream
+    if (!lockstep && !gicp_runs)  // these paths run every worker on its own stream
       for (size_t s = 0; s < per_thread; ++s)
         if (ensure_stream(ws[s])) return failed(ICPGPU_ERR_HIP, 0, ws[s]);
     if (gicp) {
@@ -225,9 +229,38 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
       // its awaited result has arrived and looks at the others meanwhile -- until round 5 it was ONE blocking alignment per
       // thread, its host spinning through every inner minimisation.  A run that cannot be resumable (no device solver on its
       // context, or the solver gave up) is one blocking alignment inside its step.
+      // With the device solver (gicp_runs): the solvers of the runs that are ready go out TOGETHER, one gicp_solve_batch_kernel
+      // launch on the thread's solve stream behind the runs' events -- a resident solver kernel per run would hold a hardware
+      // queue each, four registrations at most solving at any time.  The runs' short kernels (index builds, covariances, searches,
+      // fitness) go to three work streams, created right behind the solve stream and therefore on the three OTHER hardware queues:
+      // nothing short ever waits behind a solver.  (One work stream for all runs was tried first: every run's next step then
+      // queued behind every other run's covariance pass -- 0.5-1.1k pairs/s instead of 1.7k.)
       std::vector<GicpRun> gruns(depth);
       std::vector<size_t> pair_of(depth, 0);
       bool exhausted = false;
+      // Two solve streams, two work streams.  A solve stream takes a new launch only when the runs of its last one have all
+      // answered (launches on one stream run one after the other: a launch per ready run, issued at once, put every run behind
+      // every other -- 0.57k pairs/s); meanwhile the runs that become ready collect and leave together.
+      hipStream_t work_stream[2] = {nullptr, nullptr}, solve_stream[2] = {nullptr, nullptr};
+      std::vector<hipStream_t> own(depth, nullptr);
+      std::vector<int> solving_on(depth, -1);  // which solve stream a run's solver is on (-1: none)
+      struct RestoreStreams {
+        std::vector<hipStream_t>& own; icpgpu_ctx* const* ws; hipStream_t* w; hipStream_t* s2;
+        ~RestoreStreams() {
+          if (!s2[0]) return;
+          for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(s2[k]);
+          for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(w[k]);
+          for (size_t i = 0; i < own.size(); ++i) ws[i]->stream = own[i];
+        }
+      } restore_streams{own, ws, work_stream, solve_stream};
+      if (gicp_runs) {
+        for (int k = 0; k < 2; ++k) solve_stream[k] = c->group_streams[4 * t + k];
+        for (int k = 0; k < 2; ++k) work_stream[k] = c->group_streams[4 * t + 2 + k];
+        for (size_t s2 = 0; s2 < depth; ++s2) {
+          own[s2] = ws[s2]->stream;
+          ws[s2]->stream = work_stream[s2 % 2];
+        }
+      }
       for (;;) {
         bool progressed = false;
         size_t in_flight = 0;
@@ -243,7 +276,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
             }
             pair_of[s2] = k;
             int rc = load_pair(w, k, /*sync=*/false);
-            if (!rc) rc = gicp_run_begin(w, r, want_fitness, &results[k]);
+            if (!rc) rc = gicp_run_begin(w, r, want_fitness, &results[k], /*combine=*/gicp_runs);
             if (rc) return failed(rc, k, w);
             progressed = true;
             if (r.phase != GicpRun::Done) ++in_flight;
@@ -255,6 +288,44 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
           }
         }
         if (in_flight == 0 && (exhausted || abort.load())) return;
+        for (int ss = 0; gicp_runs && ss < 2; ++ss) {  // the solvers of every run that is ready: one launch, on a solve stream that is idle
+          bool busy = false;
+          for (size_t s2 = 0; s2 < depth; ++s2) {
+            if (solving_on[s2] == ss && gruns[s2].phase != GicpRun::Solve) solving_on[s2] = -1;  // (answered, or gave up)
+            busy = busy || solving_on[s2] == ss;
+          }
+          if (busy) continue;
+          GicpSolveItem items[kGicpSolveBatchMax];
+          size_t who[kGicpSolveBatchMax];
+          int n_ready = 0, blocks_sum = 0;
+          // (a solver workgroup takes a CU's one-wave-per-SIMD slot: the launches of all threads together stay below the chip's 256
+          //  CUs, or a run's workgroups would spin waiting for peers that have no CU yet)
+          const int blocks_cap = std::max(1, 240 / (int)n_threads);
+          for (size_t s2 = 0; s2 < depth && n_ready < kGicpSolveBatchMax; ++s2)
+            if (gruns[s2].phase == GicpRun::WantSolve && (n_ready == 0 || blocks_sum + gruns[s2].item.blocks <= blocks_cap)) {
+              items[n_ready] = gruns[s2].item;
+              blocks_sum += gruns[s2].item.blocks;
+              who[n_ready++] = s2;
+            }
+          if (n_ready) {
+            hipError_t e = hipSuccess;
+            for (int k = 0; k < n_ready && e == hipSuccess; ++k) {  // behind each run's own search and Mahalanobis kernels
+              icpgpu_ctx* w = ws[who[k]];
+              e = hipEventRecord(w->ev[0], w->stream);
+              if (e == hipSuccess) e = hipStreamWaitEvent(solve_stream[ss], w->ev[0], 0);
+            }
+            if (e == hipSuccess) e = launch_gicp_solve_batch(items, n_ready, 20, 1e-2, solve_stream[ss]);
+            if (e != hipSuccess) {
+              fail(ws[who[0]], ICPGPU_ERR_HIP, "GICP batch: solver launch: %s", hipGetErrorString(e));
+              return failed(ICPGPU_ERR_HIP, pair_of[who[0]], ws[who[0]]);
+            }
+            for (int k = 0; k < n_ready; ++k) {
+              gicp_run_solver_launched(ws[who[k]], gruns[who[k]], solve_stream[ss]);
+              solving_on[who[k]] = ss;
+            }
+            progressed = true;
+          }
+        }
 #if defined(__x86_64__)
         if (!progressed) __builtin_ia32_pause();
 #endif

@@ -704,6 +704,26 @@ static int gicp_run_queue_outer(icpgpu_ctx* c, GicpRun& r) {
                                      static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
   Vec6 x = gicp_state_from_matrix(r.transformation);
   const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
+  if (r.combine && (long long)nblk * 1024 >= n_s) {  // the scheduler launches it together with the other runs that are ready
+    GicpSolveItem& it = r.item;
+    it.src = c->src.data();
+    it.n_s = n_s;
+    it.tgt = c->tgt.data();
+    it.keys = keys;
+    it.thr = r.thr_excl;
+    it.base = xform_from_f16(r.guess);
+    std::memcpy(it.guess, r.guess, sizeof(it.guess));
+    it.maha6 = maha;
+    for (int k = 0; k < 6; ++k) it.x0[k] = x.v[k];
+    it.slots = c->gicp_slots;
+    it.host_out = c->h_solve_dev;
+    r.seq0 = (c->gicp_solve_seq += 8192);
+    it.seq0 = wire_seq(c, r.seq0);
+    it.blocks = nblk;
+    r.local = false;
+    r.phase = GicpRun::WantSolve;
+    return ICPGPU_OK;
+  }
   // the one-XCD variant wherever the run fits one XCD with its correspondences in registers (align_gicp also asks for 8 x nblk <=
   // the context's share of the chip: a lone blocking alignment sizes its evaluation server by that share; the runs of a batch
   // sit on their contexts' own XCDs, c->gicp_xcc, and leave after every outer iteration)
@@ -713,9 +733,18 @@ static int gicp_run_queue_outer(icpgpu_ctx* c, GicpRun& r) {
   HIP_TRY(c, launch_gicp_solve(nblk, c->src.data(), n_s, c->tgt.data(), keys, r.thr_excl, xform_from_f16(r.guess), r.guess, maha, x.v, c->gicp_slots,
                                c->h_solve_dev, wire_seq(c, r.seq0), 20, 1e-2, c->stream, r.local ? c->gicp_slots_local : nullptr,
                                r.local ? c->gicp_owner : nullptr, c->gicp_xcc));
+  r.solve_stream = c->stream;
   r.phase = GicpRun::Solve;
   r.polls = 0;
   return ICPGPU_OK;
+}
+
+void gicp_run_solver_launched(icpgpu_ctx* c, GicpRun& r, hipStream_t solve_stream) {
+  (void)c;
+  r.solve_stream = solve_stream;
+  r.t_issue = std::chrono::steady_clock::now();
+  r.phase = GicpRun::Solve;
+  r.polls = 0;
 }
 
 // after the covariances: the search grid, the scratch, the first outer iteration
@@ -756,8 +785,9 @@ static int gicp_run_next_cov(icpgpu_ctx* c, GicpRun& r) {
   return gicp_run_start_outer(c, r);
 }
 
-int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res) {
+int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res, bool combine) {
   r = GicpRun{};
+  r.combine = combine;
   r.t_start = std::chrono::steady_clock::now();
   r.res = res;
   r.want_fitness = want_fitness;
@@ -827,6 +857,8 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
   const icpgpu_params& P = c->params;
   int rc;
   switch (r.phase) {
+    case GicpRun::WantSolve:
+      return 0;  // (the scheduler's move: gicp_run_solver_launched)
     case GicpRun::Blocking:
       if ((rc = align_gicp(c, nullptr, nullptr, r.want_fitness, r.res))) return rc;
       r.phase = GicpRun::Done;
@@ -869,7 +901,7 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
       bool gave_up = false;
       if (!all) {
         if ((++r.polls & 0x3FFu) != 0) return 0;
-        const hipError_t q = hipStreamQuery(c->stream);
+        const hipError_t q = hipStreamQuery(r.solve_stream ? r.solve_stream : c->stream);
         if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for the GICP device solver: %s", hipGetErrorString(q));
         if (q == hipErrorNotReady) {
           if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count() > wait_timeout_ms())
@@ -891,6 +923,23 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
       }
       c->prof.gicp_device_solves += 1;
       const double m = out[7], evals = out[10];
+#if defined(ICPGPU_DEV_SWITCHES)
+      {  // development flavour, ICPGPU_BATCH_TRACE=1: where the device solver's microseconds go with several runs in flight
+        static const bool trace = [] { const char* e = std::getenv("ICPGPU_BATCH_TRACE"); return e && std::atoi(e) != 0; }();
+        if (trace) {
+          static std::atomic<unsigned long long> n_runs{0}, n_evals{0}, ph[7];
+          for (int k = 0; k < 6; ++k) ph[k].fetch_add((unsigned long long)(out[12 + k] * 100.0));
+          ph[6].fetch_add((unsigned long long)(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - r.t_issue).count() * 100.0));
+          n_evals.fetch_add((unsigned long long)evals);
+          if ((n_runs.fetch_add(1) & 1023u) == 1023u) {
+            const double ne = (double)n_evals.load();
+            fprintf(stderr, "[icpgpu] device solver, mean per evaluation over %llu runs: state -> transform %.2f | accumulate %.2f | reduce + publish %.2f | gather %.2f | "
+                            "gradient %.2f | kernel total %.2f us; host: launch -> result %.2f us\n", n_runs.load(), ph[0].load() * 0.01 / ne, ph[1].load() * 0.01 / ne,
+                    ph[2].load() * 0.01 / ne, ph[3].load() * 0.01 / ne, ph[4].load() * 0.01 / ne, ph[5].load() * 0.01 / ne, ph[6].load() * 0.01 / ne);
+          }
+        }
+      }
+#endif
       r.mse = m > 0 ? out[8] / m : 0.0;
       r.n_corr = (unsigned)m;
       c->prof.gicp_cost_launches += (uint64_t)evals;
