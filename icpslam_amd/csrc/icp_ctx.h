@@ -307,6 +307,7 @@ struct icpgpu_ctx {
   DeviceBuf batch_table;             // lock-step batch: the BatchPair table of the group this context leads
   std::atomic<size_t> batch_table_cells{0};   // align_batch: the largest cell table any worker has needed (icpgpu_index.cpp)
   std::atomic<size_t>* shared_table_cells = nullptr;  // a batch worker: its parent's batch_table_cells
+  size_t batch_presized_src = 0, batch_presized_tgt = 0, batch_presized_cells = 0;  // a batch worker: what its buffers were sized for up front
   std::vector<hipStream_t> group_streams;  // lock-step batch: one stream per group, created consecutively (icpgpu_batch.cpp)
   int host_share = 1;                // batch drivers of this process that share its CPUs with this context (icp_multi.cpp)
   std::string err;

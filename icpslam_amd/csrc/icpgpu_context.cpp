@@ -34,6 +34,10 @@ int ensure(icpgpu_ctx* c, DeviceBuf& b, size_t bytes) {
     b.external = false;
   }
   if (bytes <= b.cap) return ICPGPU_OK;
+  {
+    static const bool trace = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_ALLOC_TRACE"); return e && std::atoi(e) != 0; }();
+    if (trace) fprintf(stderr, "[icpgpu] alloc: %zu -> %zu bytes (context %p)\n", b.cap, bytes, (void*)c);
+  }
   const auto t0 = std::chrono::steady_clock::now();
   if (b.ptr) HIP_TRY(c, hipFree(b.ptr));
   b.ptr = nullptr;
