@@ -16,6 +16,7 @@ if os.environ.get("ICPGPU_LIB_PATH"):   # A/B builds of an experiment (scripts/)
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_NO_INPUT, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 P2P_SVD, GICP = 0, 1
+GICP_INNER_EXACT, GICP_INNER_QUADRATIC = 0, 1
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 STATE_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
                5: "NO_CORRESPONDENCES"}
@@ -25,7 +26,7 @@ class Params(C.Structure):
     _fields_ = [("method", C.c_int32), ("max_iterations", C.c_int32), ("transformation_epsilon", C.c_double),
                 ("max_correspondence_distance", C.c_double), ("euclidean_fitness_epsilon", C.c_double),
                 ("min_correspondences", C.c_int32), ("force_iterations", C.c_int32), ("nn_mode", C.c_int32),
-                ("brute_variant", C.c_int32)]
+                ("brute_variant", C.c_int32), ("gicp_inner", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -50,7 +51,7 @@ class Profile(C.Structure):
                 ("targets_recognised", C.c_uint64), ("brute_bound_violations", C.c_uint64),
                 ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64),
                 ("grid_adopted", C.c_uint64), ("sources_adopted", C.c_uint64), ("gicp_host_solves", C.c_uint64),
-                ("gicp_solver_choice", C.c_uint64)]
+                ("gicp_solver_choice", C.c_uint64), ("gicp_quadratic_solves", C.c_uint64)]
 
 
 class Pose(C.Structure):
@@ -66,6 +67,7 @@ EXPORTS = [
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_profile_set_sampling", "icpgpu_get_stream", "icpgpu_synchronize",
     "icpgpu_voxel_grid", "icpgpu_voxel_grid_fetch", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
+    "icpgpu_gicp_quadratic_eval", "icpgpu_gicp_quadratic_sums",
     "icpgpu_pose_from_matrix", "icpgpu_pose_to_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
     "icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes", "icpgpu_posegraph_get_pose",
@@ -129,6 +131,8 @@ def load():
     L.icpgpu_solve.argtypes = [dp, dp]
     L.icpgpu_transform.argtypes = [vp, fp, fp]
     L.icpgpu_gicp_covariances.argtypes = [vp, C.c_int, dp]
+    L.icpgpu_gicp_quadratic_eval.argtypes = [dp, fp, dp, dp, dp]
+    L.icpgpu_gicp_quadratic_sums.argtypes = [vp, fp, dp]
     L.icpgpu_voxel_grid.argtypes = [vp, fp, C.c_size_t, C.c_float, fp, C.POINTER(C.c_size_t)]
     L.icpgpu_voxel_grid_fetch.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]

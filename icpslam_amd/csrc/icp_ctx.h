@@ -243,6 +243,13 @@ struct icpgpu_ctx {
   unsigned long long gicp_solve_seq = 0;
   bool gicp_device_ok = false;
   bool gicp_resources_ready = false;  // ensure_gicp_resources has run (icpgpu_context.cpp)
+  // the quadratic inner solver (icpgpu_params.gicp_inner; icp_gicp_quadratic.h): the workgroups' partial sums, the counter of
+  // finished workgroups, the 2 x kGicpQuadSums result pairs (host, mapped) and the number the next pass's pairs carry
+  double* quad_partials = nullptr;
+  unsigned int* quad_done = nullptr;
+  volatile unsigned long long* h_quad = nullptr;
+  unsigned long long* h_quad_dev = nullptr;
+  unsigned long long quad_seq = 0;
   // measured mode: 0 = still timing both solvers, 1 = host, 2 = device; microseconds and evaluations of the timed inner
   // minimisations, [0] host [1] device (the first run of each is a warm-up and not counted)
   int gicp_choice = 0;
@@ -430,6 +437,8 @@ int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, cons
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
 int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
 int ensure_gicp_resources(icpgpu_ctx* c);
+int ensure_gicp_quadratic_resources(icpgpu_ctx* c);
+bool gicp_inner_quadratic(const icpgpu_ctx* c);  // params.gicp_inner, or ICPGPU_GICP_INNER's override
 int create_context(icpgpu_ctx** out_ctx, int device_id, bool with_stream);
 int ensure_stream(icpgpu_ctx* c);
 int promote_internal(icpgpu_ctx* c);

@@ -9,10 +9,12 @@
 //   ICPGPU_GICP_SERVER=0     every GICP cost evaluation is its own kernel launch (no resident server)
 //   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the device solver gicp_solve_kernel (1), or whichever
 //                            the context measures to be faster (auto, the default) -- same bits either way
+//   ICPGPU_GICP_INNER=exact|quadratic   overrides icpgpu_params.gicp_inner (the ONE switch that moves a result: QUADRATIC stays
+//                            within the stated tolerance of EXACT, not on its bits -- include/icpgpu.h: icpgpu_gicp_inner)
 //   ICPGPU_MAILBOX=pairs|release   how results reach the host (default: self-test at context creation picks it)
 //   ICPGPU_DEBUG=1           diagnostics on stderr
 //   LOCAL_WORLD_SIZE         (torch.distributed.run) processes sharing this host's CPUs
-// None of them changes a result.
+// None of the others changes a result.
 //
 // DEVELOPMENT switches -- kernel variants, tuning constants, test modes that evaluate every pair, and a few that deliberately
 // produce WRONG results to price a stage (ICPGPU_SKIP_UNCERT, *_NO_EXACT) -- exist only in the flavour compiled with

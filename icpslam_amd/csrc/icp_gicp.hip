@@ -338,6 +338,31 @@ __global__ __launch_bounds__(256) void gicp_cov_finish_kernel(int n, double* __r
 }
 
 // ---- Mahalanobis matrices --------------------------------------------------------------------------------------
+// M = (C_t + R C_s R^T)^-1 of one correspondence, upper triangle (a, b: the two covariances' upper triangles)
+__device__ __forceinline__ void gicp_maha_of(const double* __restrict__ a, const double* __restrict__ b, const Rot3d& R, double* __restrict__ M) {
+  const double C1[9] = {a[0], a[1], a[2], a[1], a[3], a[4], a[2], a[4], a[5]};
+  double RC[9], S[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) RC[3 * r + c] = R.m[3 * r] * C1[c] + R.m[3 * r + 1] * C1[3 + c] + R.m[3 * r + 2] * C1[6 + c];
+  const double C2[9] = {b[0], b[1], b[2], b[1], b[3], b[4], b[2], b[4], b[5]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      S[3 * r + c] = RC[3 * r] * R.m[3 * c] + RC[3 * r + 1] * R.m[3 * c + 1] + RC[3 * r + 2] * R.m[3 * c + 2] + C2[3 * r + c];
+  // inverse by adjugate; the result of inverting a (numerically) symmetric matrix is stored as its upper triangle
+  const double c00 = S[4] * S[8] - S[5] * S[7], c01 = S[5] * S[6] - S[3] * S[8], c02 = S[3] * S[7] - S[4] * S[6];
+  const double id = 1.0 / (S[0] * c00 + S[1] * c01 + S[2] * c02);
+  M[0] = c00 * id;
+  M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
+  M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
+  M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
+  M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
+  M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
+}
+
 __global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned long long* __restrict__ keys, float thr,
                                                         Rot3d R, const double* __restrict__ cov_s,
                                                         const double* __restrict__ cov_t, double* __restrict__ maha6) {
@@ -347,8 +372,9 @@ __global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned 
   const unsigned int j = (unsigned int)key;
   const float d2 = __uint_as_float((unsigned int)(key >> 32));
   if (j == 0xFFFFFFFFu || !(d2 < thr)) return;
-  const double* a = cov_s + (size_t)i * 6;
-  const double* b = cov_t + (size_t)j * 6;
+  gicp_maha_of(cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, R, maha6 + (size_t)i * 6);
+}
+#if 0
   const double C1[9] = {a[0], a[1], a[2], a[1], a[3], a[4], a[2], a[4], a[5]};
   double RC[9], S[9];
 #pragma unroll
@@ -372,6 +398,7 @@ __global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned 
   M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
   M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
 }
+#endif
 
 // ---- one BFGS evaluation ---------------------------------------------------------------------------------------
 // terms: 0 = m, 1 = sum r^T M r, 2..4 = sum M r, 5..13 = sum (base p)(M r)^T (row-major), 14 = sum d2 of the NN sweep
@@ -599,6 +626,134 @@ __global__ __launch_bounds__(256) void gicp_cost_kernel(const float4* __restrict
   gicp_accumulate(acc, src, n_s, tgt, keys, thr, T, base, maha6);
   (void)flags;
   gicp_block_reduce_store(acc, partials, seq);
+}
+
+// ---- the quadratic form of an outer iteration (icp_gicp_quadratic.h) ------------------------------------------------------------
+// ONE pass over the correspondences per outer iteration instead of one per BFGS evaluation: the 73 coefficient sums of the cost as
+// a quadratic form in the entries of T, plus m and sum d2 -- sum number n of kGicpQuadSums:
+//   n = pair(e, e') * 6 + tri(c, d)   sum p~_e p~_e' M_cd     (pairs e <= e' of p~ = (p.x, p.y, p.z, 1); M's upper triangle)   0..59
+//   n = 60 + e * 3 + c                 sum p~_e (M q)_c                                                                       60..71
+//   n = 72                             sum q^T M q                                 n = 73: m (count)        n = 74: sum d2
+// The Mahalanobis matrix of a correspondence is computed here (gicp_maha_of: the operations of gicp_maha_kernel) and never stored.
+// Every sum is an exact double-double sum of its float64 terms, like the sums of an evaluation.  A thread keeps its first
+// correspondence in registers and walks the sums thirteen at a time (the workgroup reduction's LDS tile holds thirteen), so clouds
+// up to 256 x gridDim.x points -- the reference's voxel-filtered scans -- read their inputs once.
+struct QuadPoint {
+  bool use;
+  double p[4], q[3], M[6], Mq[3], cq, d2;
+};
+__device__ __forceinline__ void quad_point_load(QuadPoint& P, int i, const float4* __restrict__ src, const float4* __restrict__ tgt,
+                                                const unsigned long long* __restrict__ keys, float thr, const Rot3d& R,
+                                                const double* __restrict__ cov_s, const double* __restrict__ cov_t) {
+  const unsigned long long key = keys[i];
+  const unsigned int j = (unsigned int)key;
+  const float d2 = __uint_as_float((unsigned int)(key >> 32));
+  P.use = j != 0xFFFFFFFFu && d2 < thr;
+  if (!P.use) return;
+  const float4 s = src[i], q = tgt[j];
+  gicp_maha_of(cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, R, P.M);
+  P.p[0] = (double)s.x; P.p[1] = (double)s.y; P.p[2] = (double)s.z; P.p[3] = 1.0;
+  P.q[0] = (double)q.x; P.q[1] = (double)q.y; P.q[2] = (double)q.z;
+  P.Mq[0] = P.M[0] * P.q[0] + P.M[1] * P.q[1] + P.M[2] * P.q[2];
+  P.Mq[1] = P.M[1] * P.q[0] + P.M[3] * P.q[1] + P.M[4] * P.q[2];
+  P.Mq[2] = P.M[2] * P.q[0] + P.M[4] * P.q[1] + P.M[5] * P.q[2];
+  P.cq = P.q[0] * P.Mq[0] + P.q[1] * P.Mq[1] + P.q[2] * P.Mq[2];
+  P.d2 = (double)d2;
+}
+template <int N>
+__device__ __forceinline__ double quad_term(const QuadPoint& P) {  // term N of one correspondence
+  if constexpr (N < 60) {
+    constexpr int pair = N / 6, k = N % 6;
+    constexpr int e = pair < 4 ? 0 : pair < 7 ? 1 : pair < 9 ? 2 : 3;
+    constexpr int f = pair < 4 ? pair : pair < 7 ? pair - 3 : pair < 9 ? pair - 5 : 3;
+    return (P.p[e] * P.p[f]) * P.M[k];  // the product of two floats is exact
+  } else if constexpr (N < 72) {
+    return P.p[(N - 60) / 3] * P.Mq[(N - 60) % 3];
+  } else if constexpr (N == 72) {
+    return P.cq;
+  } else if constexpr (N == 73) {
+    return 1.0;
+  } else {
+    return P.d2;
+  }
+}
+template <int G, int K>
+__device__ __forceinline__ void quad_add_group(DD (&acc)[13], const QuadPoint& P) {
+  if constexpr (K < 13 && 13 * G + K < kGicpQuadSums) {
+    dd_add_term(acc[K], quad_term<13 * G + K>(P));
+    quad_add_group<G, K + 1>(acc, P);
+  }
+}
+// partials[block][kGicpQuadSums] (DD); the last workgroup to finish adds the workgroups' partials and publishes the kGicpQuadSums
+// (hi, lo) pairs as 2 x kGicpQuadSums result pairs numbered seq in host_out (gicp_granule_read on the host)
+template <int G>
+__device__ __forceinline__ void quad_group(const QuadPoint& mine, int i_next, int stride, const float4* __restrict__ src, int n_s,
+                                           const float4* __restrict__ tgt, const unsigned long long* __restrict__ keys, float thr,
+                                           const Rot3d& R, const double* __restrict__ cov_s, const double* __restrict__ cov_t,
+                                           DD* __restrict__ out, DD (*s_lane)[16][17], DD (*s_chunk)[16]) {
+  DD acc[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) acc[k].hi = acc[k].lo = 0.0;
+  if (mine.use) quad_add_group<G, 0>(acc, mine);
+  for (int i = i_next; i < n_s; i += stride) {  // larger clouds: the further correspondences of this lane, read again per group
+    QuadPoint P;
+    quad_point_load(P, i, src, tgt, keys, thr, R, cov_s, cov_t);
+    if (P.use) quad_add_group<G, 0>(acc, P);
+  }
+#pragma unroll
+  for (int k = 0; k < 13; ++k) s_lane[k][threadIdx.x & 15][threadIdx.x >> 4] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 13 * 16) {
+    const int k = threadIdx.x >> 4, c = threadIdx.x & 15;
+    DD x[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) x[l] = s_lane[k][l][c];
+    s_chunk[k][c] = dd_sum16(x);
+  }
+  __syncthreads();
+  if (threadIdx.x < 13 && 13 * G + (int)threadIdx.x < kGicpQuadSums) {
+    DD x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = s_chunk[threadIdx.x][c];
+    out[13 * G + threadIdx.x] = dd_sum16(x);
+  }
+  // (the next group's writes to s_lane come behind this group's second barrier, its writes to s_chunk behind its own first one)
+}
+__global__ __launch_bounds__(256) void gicp_quadratic_kernel(const float4* __restrict__ src, int n_s, const float4* __restrict__ tgt,
+                                                             const unsigned long long* __restrict__ keys, float thr, Rot3d R,
+                                                             const double* __restrict__ cov_s, const double* __restrict__ cov_t,
+                                                             DD* __restrict__ partials, unsigned int* __restrict__ done,
+                                                             unsigned long long* __restrict__ host_out, unsigned long long seq) {
+  __shared__ DD s_lane[13][16][17];
+  __shared__ DD s_chunk[13][16];
+  __shared__ bool s_last;
+  const int stride = (int)gridDim.x * 256, i0 = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  QuadPoint mine;
+  mine.use = false;
+  if (i0 < n_s) quad_point_load(mine, i0, src, tgt, keys, thr, R, cov_s, cov_t);
+  DD* out = partials + (size_t)blockIdx.x * kGicpQuadSums;
+  quad_group<0>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<1>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<2>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<3>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<4>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<5>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  // the last workgroup to get here adds everybody's partials (device-scope release / acquire around the counter)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) *done = 0u;  // ready for the next launch (launches of one context are ordered by its stream)
+  if (threadIdx.x < kGicpQuadSums) {
+    DD a{0.0, 0.0};
+    for (unsigned int b = 0; b < gridDim.x; ++b) {
+      a = dd_add(a, partials[(size_t)b * kGicpQuadSums + threadIdx.x]);
+    }
+    store_result_pair(host_out + 2 * (2 * threadIdx.x), (unsigned long long)__double_as_longlong(a.hi), seq);
+    store_result_pair(host_out + 2 * (2 * threadIdx.x + 1), (unsigned long long)__double_as_longlong(a.lo), seq);
+  }
 }
 
 // ---- resident evaluation server ------------------------------------------------------------------------------------
@@ -1126,6 +1281,18 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
                                    const double* cov_t, double* maha6, hipStream_t stream) {
   if (n_s <= 0) return hipSuccess;
   hipLaunchKernelGGL(gicp_maha_kernel, dim3((n_s + 255) / 256), dim3(256), 0, stream, n_s, keys, thr, R, cov_s, cov_t, maha6);
+  return hipGetLastError();
+}
+
+int gicp_quadratic_blocks(int n_s) {
+  const int b = (n_s + 255) / 256;
+  return b < 1 ? 1 : b > kGicpQuadBlocks ? kGicpQuadBlocks : b;
+}
+hipError_t launch_gicp_quadratic(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                                 const Rot3d& R, const double* cov_s, const double* cov_t, double* partials, unsigned int* done,
+                                 unsigned long long* host_out, unsigned long long seq, hipStream_t stream) {
+  hipLaunchKernelGGL(gicp_quadratic_kernel, dim3(gicp_quadratic_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, R, cov_s,
+                     cov_t, reinterpret_cast<DD*>(partials), done, host_out, seq);
   return hipGetLastError();
 }
 

@@ -1,6 +1,8 @@
 // icp_gicp_solver.cpp -- the host instantiation of icp_gicp_solver_impl.h (see icp_gicp_solver.h).
 #include "icp_gicp_solver.h"
 
+#include "icp_gicp_quadratic.h"
+
 namespace icpgpu {
 
 void gicp_apply_state(float t[16], const Vec6& x) { gicp::apply_state(t, x); }
@@ -25,6 +27,48 @@ GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double g
     case gicp::kDidNotConverge: return GicpSolve::DidNotConverge;
     default: return GicpSolve::DeviceError;
   }
+}
+
+
+namespace {
+struct QuadEval {
+  const gicp::QuadForm& Q;
+  const float* base16;
+  int evaluations = 0;
+  bool operator()(const Vec6& x, GicpEval& out) {
+    float T[16];
+    std::memcpy(T, base16, sizeof(T));
+    const gicp::Trig6 tr = gicp::trig6(x);
+    gicp::apply_state(T, x, tr);
+    double s[15];
+    gicp::quad_form_sums(Q, T, s);
+    gicp::eval_from_sums(tr, s, out);
+    ++evaluations;
+    return true;
+  }
+};
+}  // namespace
+
+GicpSolve gicp_minimize_quadratic(const double* sums, const float base16[16], Vec6& x, int max_inner, double gradient_tol,
+                                  int* evaluations) {
+  gicp::QuadForm Q;
+  gicp::quad_form_load(Q, sums, base16);
+  QuadEval eval{Q, base16};
+  const gicp::Status st = gicp::minimize(eval, x, max_inner, gradient_tol, nullptr);
+  if (evaluations) *evaluations = eval.evaluations;
+  switch (st) {
+    case gicp::kOk: return GicpSolve::Ok;
+    case gicp::kNotEnoughPoints: return GicpSolve::NotEnoughPoints;
+    case gicp::kDidNotConverge: return GicpSolve::DidNotConverge;
+    default: return GicpSolve::DeviceError;
+  }
+}
+
+void gicp_quadratic_eval(const double* sums, const float base16[16], const Vec6& x, GicpEval& out) {
+  gicp::QuadForm Q;
+  gicp::quad_form_load(Q, sums, base16);
+  QuadEval eval{Q, base16};
+  eval(x, out);
 }
 
 }  // namespace icpgpu

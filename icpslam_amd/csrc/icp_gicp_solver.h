@@ -29,4 +29,13 @@ enum class GicpSolve { Ok, NotEnoughPoints, DidNotConverge, DeviceError };
 // at_x (nullable): value and gradient at the start point if the caller already has them (saves one evaluation)
 GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double gradient_tol, const GicpEval* at_x = nullptr);
 
+
+// The same minimisation over the QUADRATIC FORM of an outer iteration (icp_gicp_quadratic.h): no device evaluation at all, the 73
+// sums the device collected once are all it needs.  sums: kGicpQuadSums double-double numbers as (hi, lo) pairs; base16: the
+// column-major float 4x4 PCL calls base_transformation_.  evaluations (nullable): how many cost evaluations the run took.
+GicpSolve gicp_minimize_quadratic(const double* sums, const float base16[16], Vec6& x, int max_inner, double gradient_tol,
+                                  int* evaluations = nullptr);
+// one evaluation of that form (tests: the algebra against a per-point evaluation)
+void gicp_quadratic_eval(const double* sums, const float base16[16], const Vec6& x, GicpEval& out);
+
 }  // namespace icpgpu

@@ -300,6 +300,17 @@ struct GicpSolveItem {
 };
 hipError_t launch_gicp_solve_batch(const GicpSolveItem* items, int n, int max_inner, double gradient_tol, hipStream_t stream);
 bool gicp_granule_read(const volatile unsigned long long* g, unsigned long long seq, double* value);
+// The quadratic form of an outer iteration (icp_gicp_quadratic.h, icp_gicp.hip: gicp_quadratic_kernel): kGicpQuadSums
+// double-double sums over the correspondences whose key passes d2 < thr, Mahalanobis matrices computed on the way (R: the rotation
+// launch_gicp_mahalanobis takes).  partials: gicp_quadratic_blocks(n_s) x kGicpQuadSums x 2 doubles of device memory, done: a zeroed
+// device word; host_out: 2 x kGicpQuadSums result pairs (16 B each) numbered seq -- pair 2 n the high part of sum n, 2 n + 1 its low
+// part (gicp_granule_read).
+static constexpr int kGicpQuadSums = 75;
+static constexpr int kGicpQuadBlocks = 256;
+int gicp_quadratic_blocks(int n_s);
+hipError_t launch_gicp_quadratic(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
+                                 const Rot3d& R, const double* cov_s, const double* cov_t, double* partials, unsigned int* done,
+                                 unsigned long long* host_out, unsigned long long seq, hipStream_t stream);
 static constexpr unsigned int kGicpServerExit = 0xFFFFFFFFu;
 hipError_t launch_gicp_server(int blocks, const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                               const Xform& base, const double* maha6, double* host_partials, unsigned long long* host_flags,

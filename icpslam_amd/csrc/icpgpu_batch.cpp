@@ -919,6 +919,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     c->prof.brute_bound_violations += p.brute_bound_violations;
     c->prof.gicp_device_solves += p.gicp_device_solves;
     c->prof.gicp_host_solves += p.gicp_host_solves;
+    c->prof.gicp_quadratic_solves += p.gicp_quadratic_solves;
     c->prof.sources_adopted += p.sources_adopted;
     c->prof.grid_adopted += p.grid_adopted;
     if (p.brute_bound_worst > c->prof.brute_bound_worst) c->prof.brute_bound_worst = p.brute_bound_worst;

@@ -286,6 +286,35 @@ int ensure_gicp_resources(icpgpu_ctx* c) {
   return ICPGPU_OK;
 }
 
+// the quadratic inner solver's buffers, when a context first uses it
+int ensure_gicp_quadratic_resources(icpgpu_ctx* c) {
+  if (c->h_quad) return ICPGPU_OK;
+  hipError_t e;
+  const size_t part_bytes = (size_t)kGicpQuadBlocks * kGicpQuadSums * 2 * sizeof(double);
+  const size_t out_bytes = (size_t)2 * kGicpQuadSums * 16;
+  void* h = nullptr;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&c->quad_partials), part_bytes)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&c->quad_done), 64)) != hipSuccess || (e = hipMemset(c->quad_done, 0, 64)) != hipSuccess ||
+      (e = hipHostMalloc(&h, out_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+    return fail(c, e == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "quadratic GICP solver buffers: %s", hipGetErrorString(e));
+  std::memset(h, 0, out_bytes);
+  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_quad_dev), h, 0)) != hipSuccess) {
+    (void)hipHostFree(h);
+    return fail(c, ICPGPU_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+  }
+  c->h_quad = static_cast<volatile unsigned long long*>(h);
+  return ICPGPU_OK;
+}
+
+bool gicp_inner_quadratic(const icpgpu_ctx* c) {
+  static const int forced = [] {  // ICPGPU_GICP_INNER=exact|quadratic overrides the parameter
+    const char* e = std::getenv("ICPGPU_GICP_INNER");
+    if (!e || !*e) return -1;
+    return (e[0] == 'q' || e[0] == 'Q' || e[0] == '1') ? 1 : 0;
+  }();
+  return forced >= 0 ? forced == 1 : c->params.gicp_inner == ICPGPU_GICP_INNER_QUADRATIC;
+}
+
 }  // namespace icpgpu_impl
 
 extern "C" {
@@ -304,6 +333,7 @@ void icpgpu_default_params(icpgpu_params* p) {
   p->force_iterations = 0;
   p->nn_mode = ICPGPU_NN_AUTO;
   p->brute_variant = 0;
+  p->gicp_inner = ICPGPU_GICP_INNER_EXACT;
 }
 
 int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) { return create_context(out_ctx, device_id, /*with_stream=*/true); }
@@ -549,6 +579,9 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   if (c->gicp_slots_local) (void)hipFree(c->gicp_slots_local);
   if (c->gicp_owner) (void)hipFree(c->gicp_owner);
   if (c->h_solve) (void)hipHostFree(const_cast<unsigned long long*>(c->h_solve));
+  if (c->h_quad) (void)hipHostFree(const_cast<unsigned long long*>(c->h_quad));
+  if (c->quad_partials) (void)hipFree(c->quad_partials);
+  if (c->quad_done) (void)hipFree(c->quad_done);
   if (c->h_ints) (void)hipHostFree(c->h_ints);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_post) (void)hipHostFree(const_cast<unsigned long long*>(c->h_post));
@@ -569,6 +602,8 @@ int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* p) {
   if (p->method != ICPGPU_P2P_SVD && p->method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad method");
   if (p->nn_mode < ICPGPU_NN_AUTO || p->nn_mode > ICPGPU_NN_GRID) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad nn_mode");
   if (p->brute_variant < 0 || p->brute_variant > 2) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad brute_variant");
+  if (p->gicp_inner != ICPGPU_GICP_INNER_EXACT && p->gicp_inner != ICPGPU_GICP_INNER_QUADRATIC)
+    return fail(c, ICPGPU_ERR_INVALID_ARG, "bad gicp_inner (a caller built against icpgpu.h < 0.4 passes a shorter icpgpu_params)");
   c->params = *p;
   return ICPGPU_OK;
 }

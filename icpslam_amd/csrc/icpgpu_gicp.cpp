@@ -260,6 +260,39 @@ static int wait_solve_result(icpgpu_ctx* c, unsigned long long seq, double* out)
   return 0;
 }
 
+// The quadratic form of an outer iteration (gicp_quadratic_kernel): 2 x kGicpQuadSums result pairs numbered `seq`.  all_there()
+// is also what a resumable run polls.
+static bool quad_sums_read(const icpgpu_ctx* c, unsigned long long seq, double* sums) {
+  bool all = true;
+  for (int k = 0; k < 2 * kGicpQuadSums; ++k) all = gicp_granule_read(c->h_quad + 2 * k, seq, &sums[k]) && all;
+  return all;
+}
+static int wait_quad_sums(icpgpu_ctx* c, unsigned long long seq, double* sums) {
+  std::chrono::steady_clock::time_point t0;
+  for (unsigned spins = 1;; ++spins) {
+    // (the last pair the kernel stores first: nothing else needs looking at until it is there)
+    double probe;
+    if (gicp_granule_read(c->h_quad + 2 * (2 * kGicpQuadSums - 1), seq, &probe) && quad_sums_read(c, seq, sums)) break;
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (quad_sums_read(c, seq, sums)) break;
+        return fail(c, ICPGPU_ERR_HIP, "the GICP quadratic pass finished without publishing its sums");
+      }
+      if (q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for the GICP quadratic pass: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for the GICP quadratic pass (hung kernel?)", wait_timeout_ms());
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
 // workgroups of a device-solver run: one per 1024 correspondences while every lane's share stays one quad in registers; larger
 // clouds stream their shares with at most kSolveStreamBlocks workgroups (every workgroup gathers every other's 28 granules per
 // evaluation: the gather grows with the count)
@@ -319,6 +352,11 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   c->prof.aligns += 1;
   const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
   const icpgpu_params& P = c->params;
+  const bool quadratic = gicp_inner_quadratic(c);  // the inner minimisation on the quadratic form (icp_gicp_quadratic.h)
+  if (quadratic) {
+    const int qrc = ensure_gicp_quadratic_resources(c);
+    if (qrc) return qrc;
+  }
   c->prev.valid = c->tile_seed.valid = false;  // every alignment starts cold
   float guess[16];
   if (guess_in) std::memcpy(guess, guess_in, sizeof(guess));
@@ -387,8 +425,9 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     } else {
       if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
     }
-    HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
-                                       static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
+    if (!quadratic)
+      HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                         static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     mark(2);
 
@@ -485,9 +524,42 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     // rigid_transformation_estimation_: the whole BFGS run on the device (gicp_solve_kernel), one result for the host to poll
     Vec6 x = gicp_state_from_matrix(transformation);
     bool solved = false, leave_outer_loop = false;
+    if (quadratic) {
+      // ... or on the host over the quadratic form: ONE pass over the correspondences (Mahalanobis matrices on the way), 150
+      // numbers to wait for, then BFGS without a device round trip
+      const auto t_q0 = std::chrono::steady_clock::now();
+      const unsigned long long seq = ++c->quad_seq;
+      HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                       static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
+                                       wire_seq(c, seq), c->stream));
+      double sums[2 * kGicpQuadSums];
+      if ((rc = wait_quad_sums(c, seq, sums))) return rc;
+      mark(3);
+      const double m = sums[2 * 73], d2 = sums[2 * 74];
+      m_count = m;
+      mse = m > 0 ? d2 / m : 0.0;
+      n_corr = (unsigned)m;
+      std::memcpy(previous, transformation, sizeof(previous));
+      if (n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+        state = ICPGPU_CONV_NO_CORRESPONDENCES;
+        break;
+      }
+      int evals = 0;
+      const GicpSolve sr = gicp_minimize_quadratic(sums, guess, x, 20, 1e-2, &evals);
+      mark(4);
+      c->prof.gicp_quadratic_solves += 1;
+      c->prof.gicp_cost_launches += (uint64_t)evals;
+      c->prof.gicp_eval_corr += (uint64_t)(m * evals);
+      c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q0).count();
+      if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
+        state = ICPGPU_NOT_CONVERGED;
+        break;
+      }
+      solved = true;
+    }
     // which solver: forced by ICPGPU_GICP_DEVICE, or (default) the one this context has measured to be faster on this box --
     // until it knows, inner minimisations alternate and are timed (same bits either way, so nothing but time depends on it)
-    bool try_device = c->gicp_device_ok && c->gicp_server_allowed;
+    bool try_device = !quadratic && c->gicp_device_ok && c->gicp_server_allowed;
     bool timing_this_run = false;
     if (try_device && gicp_device_solver_mode() == 2) {
       const int nblk = gicp_solve_blocks(n_s, c->gicp_blocks_most);
@@ -1013,6 +1085,56 @@ int icpgpu_gicp_covariances(icpgpu_ctx* c, int of_target, double* out6) {
   HIP_TRY(c, hipMemcpyAsync(out6, cov.ptr, cl.n * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return resolve_cov_timing(c);
+}
+
+int icpgpu_gicp_quadratic_sums(icpgpu_ctx* c, const float* T, double* sums150) {
+  ENTER(c);
+  if (!sums150) return fail(c, ICPGPU_ERR_INVALID_ARG, "null output");
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "gicp_quadratic_sums: clouds not set");
+  const int n_s = (int)c->src.n, n_t = (int)c->tgt.n;
+  if (n_s < kGicpK || n_t < kGicpK) return fail(c, ICPGPU_ERR_INVALID_ARG, "GICP needs at least %d points per cloud", kGicpK);
+  int rc;
+  if ((rc = ensure_gicp_resources(c)) || (rc = ensure_gicp_quadratic_resources(c))) return rc;
+  if ((rc = ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version))) return rc;
+  if ((rc = ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version))) return rc;
+  const double r2 = c->params.max_correspondence_distance * c->params.max_correspondence_distance;
+  float thr = threshold_from(r2);
+  if ((double)thr >= r2) thr = std::nextafterf(thr, -INFINITY);
+  const float thr_excl = std::nextafterf(thr, INFINITY);
+  if ((rc = ensure_grid(c, thr))) return rc;
+  if ((rc = ensure(c, c->keys, (size_t)n_s * sizeof(unsigned long long)))) return rc;
+  auto* keys = static_cast<unsigned long long*>(c->keys.ptr);
+  float guess[16];
+  if (T) std::memcpy(guess, T, sizeof(guess));
+  else mat4f_identity(guess);
+  const Xform Tq = xform_from_f16(guess);
+  Rot3d R;
+  for (int r = 0; r < 3; ++r)
+    for (int cc = 0; cc < 3; ++cc) R.m[3 * r + cc] = (double)guess[cc * 4 + r];
+  c->prev.valid = false;
+  if (grid_ready(c)) {
+    HIP_TRY(c, launch_nn_grid_search(c->src.data(), n_s, grid_flags(c->grid, false), Tq, static_cast<const float4*>(c->grid.sorted.ptr),
+                                     static_cast<const int*>(c->grid.cell_start.ptr), c->grid.g, thr, keys, nullptr, nullptr, nullptr, c->stream));
+  } else {
+    if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
+  }
+  const unsigned long long seq = ++c->quad_seq;
+  HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                   static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
+                                   wire_seq(c, seq), c->stream));
+  if ((rc = wait_quad_sums(c, seq, sums150))) return rc;
+  return resolve_cov_timing(c);
+}
+
+int icpgpu_gicp_quadratic_eval(const double* sums150, const float* base16, const double* x6, double* f, double* g6) {
+  if (!sums150 || !base16 || !x6 || !f || !g6) return ICPGPU_ERR_INVALID_ARG;
+  icpgpu::Vec6 x;
+  for (int k = 0; k < 6; ++k) x[k] = x6[k];
+  icpgpu::GicpEval e;
+  icpgpu::gicp_quadratic_eval(sums150, base16, x, e);
+  *f = e.f;
+  for (int k = 0; k < 6; ++k) g6[k] = e.g[k];
+  return ICPGPU_OK;
 }
 
 }  // extern "C"

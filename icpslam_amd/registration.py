@@ -231,6 +231,14 @@ class Context:
         full[:, 2, 0], full[:, 2, 1], full[:, 2, 2] = out[:, 2], out[:, 4], out[:, 5]
         return full
 
+    def gicp_quadratic_sums(self, T=None) -> np.ndarray:
+        """(75, 2) the sums of GICP's quadratic inner objective at transform T as (hi, lo) pairs (icp_gicp_quadratic.h) -- the
+        device half of params.gicp_inner = GICP_INNER_QUADRATIC, for tests."""
+        out = np.zeros((75, 2), np.float64)
+        Tb = None if T is None else _colmajor16(T)
+        self._check(self._L.icpgpu_gicp_quadratic_sums(self._h, None if Tb is None else _fp(Tb), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     # the step before the path (icp_odometer.cpp:96-101) ---------------------------------------------------------
     def voxel_grid(self, cloud, leaf: float) -> np.ndarray:
         cloud = _as_cloud(cloud)

@@ -37,11 +37,12 @@ extern "C" {
 #endif
 
 #define ICPGPU_VERSION_MAJOR 0
-#define ICPGPU_VERSION_MINOR 3 /* 0.3: icpgpu_profile grew (sources_adopted, gicp_host_solves, gicp_solver_choice); a caller built
-                                * against an older header passes a smaller icpgpu_profile -- compare icpgpu_version() first */
+#define ICPGPU_VERSION_MINOR 4 /* 0.4: icpgpu_params.gicp_inner, icpgpu_profile.gicp_quadratic_solves; 0.3: icpgpu_profile grew
+                                * (sources_adopted, gicp_host_solves, gicp_solver_choice); a caller built against an older header
+                                * passes smaller structs -- compare icpgpu_version() first */
 
 /* ---- environment ---------------------------------------------------------------------------------
- * Production switches, read by every build of libicpgpu.so (none of them changes a result):
+ * Production switches, read by every build of libicpgpu.so (none of them changes a result, except ICPGPU_GICP_INNER):
  *   ICPGPU_WAIT_TIMEOUT_MS        deadline of every host wait for the device (mailbox, gather); default 30000
  *   ICPGPU_BATCH_THREADS          host threads of icpgpu_align_batch (default: chosen from the CPUs this process may use)
  *   ICPGPU_BATCH_DEPTH            pairs per lock-step group (point-to-point; default 8) / alignments a thread keeps in flight
@@ -51,6 +52,8 @@ extern "C" {
  *   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the resident device solver (1), or whichever the context
  *                                 measures to be faster over its first alignments (auto, the default); same bits either way, the
  *                                 choice is reported in icpgpu_profile.gicp_solver_choice
+ *   ICPGPU_GICP_INNER=exact|quadratic  overrides icpgpu_params.gicp_inner (see icpgpu_gicp_inner below: QUADRATIC moves a GICP
+ *                                 result within the stated tolerance, not bit for bit)
  *   ICPGPU_MAILBOX=pairs|release  how results reach the host (default: a self-test at context creation picks it)
  *   ICPGPU_DEBUG=1                diagnostics on stderr
  *   LOCAL_WORLD_SIZE              (torch.distributed.run) processes sharing this host's CPUs
@@ -72,6 +75,17 @@ typedef enum {
  * octree_mapper.cpp:104); BASELINE.json's north_star specifies point-to-point ICP
  * (pcl::IterativeClosestPoint semantics), which is the primary mode. */
 typedef enum { ICPGPU_P2P_SVD = 0, ICPGPU_GICP = 1 } icpgpu_method;
+
+/* GICP's inner minimisation (PCL: estimateRigidTransformationBFGS, ~35 cost evaluations per outer iteration).
+ *   EXACT      every evaluation is a pass over the correspondences with PCL's arithmetic (points transformed in float32); the
+ *              registration is bit-identical to the CPU restatement the tests compare with.  The default.
+ *   QUADRATIC  the correspondences are reduced ONCE per outer iteration to the 73 coefficients of the quadratic form the cost is
+ *              when the transformed points are taken as real numbers; BFGS -- the same solver -- then runs on the host without a
+ *              device round trip (2-3x the scans/s of the reference's pipeline).  The result differs from EXACT's by what PCL's
+ *              float32 rounding of the transformed points contributes: within 1e-4 / 1e-3 m on most pairs, about as far from
+ *              PCL's evaluation as that evaluation moves when its own sums are re-ordered (profiles/r05_gicp_quadratic.txt).
+ * ICPGPU_GICP_INNER=exact|quadratic in the environment overrides the parameter (an unchanged binary can opt in). */
+typedef enum { ICPGPU_GICP_INNER_EXACT = 0, ICPGPU_GICP_INNER_QUADRATIC = 1 } icpgpu_gicp_inner;
 
 /* Correspondence search strategy; every mode returns the exact nearest neighbour. */
 typedef enum {
@@ -101,6 +115,7 @@ typedef struct {
   int32_t nn_mode;                    /* icpgpu_nn_mode */
   int32_t brute_variant;              /* brute-force search: 0 = matrix-core kernel for large clouds (default: lower bound on the bf16
                                        * matrix path), 1 = plain-VALU kernel always, 2 = the bound in f32 MFMAs; identical results */
+  int32_t gicp_inner;                 /* icpgpu_gicp_inner (GICP only); 0 = EXACT */
 } icpgpu_params;
 
 typedef struct {
@@ -169,6 +184,7 @@ typedef struct {
   uint64_t gicp_host_solves;       /* GICP outer iterations whose inner BFGS ran on the host (over the evaluation server) -- 0.3 */
   uint64_t gicp_solver_choice;     /* ICPGPU_GICP_DEVICE=auto: 0 = the context is still timing both solvers, 1 = it settled on the
                                     * host loop, 2 = on the device solver (forced modes report 1 / 2 at once) -- 0.3 */
+  uint64_t gicp_quadratic_solves;  /* GICP outer iterations solved on the quadratic form (icpgpu_params.gicp_inner = QUADRATIC) -- 0.4 */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -266,6 +282,13 @@ int icpgpu_transform(icpgpu_ctx* ctx, const float* T, float* out_xyzw);
 /* a11 (GICP mode): per-point regularised covariances U diag(1,1,1e-3) U^T of the 20 nearest neighbours
  * (pcl::GeneralizedIterativeClosestPoint::computeCovariances); out6 = n x {xx, xy, xz, yy, yz, zz}. */
 int icpgpu_gicp_covariances(icpgpu_ctx* ctx, int of_target, double* out6);
+/* One evaluation of the QUADRATIC inner objective on the host (no device): sums = 75 double-double numbers as (hi, lo) pairs
+ * (icpslam_amd/csrc/icp_gicp_quadratic.h: 60 A, 12 Bq, cq, m, sum d2), base16 = the guess (column-major float 4x4), x = (tx, ty,
+ * tz, roll, pitch, yaw) -> f and its gradient as BFGS sees them.  A diagnostic entry: tests check the algebra with it. */
+int icpgpu_gicp_quadratic_eval(const double* sums150, const float* base16, const double* x6, double* f, double* g6);
+/* The device half of the same mode, alone: correspondences of T * source in the target (d2 < max_correspondence_distance^2), their
+ * Mahalanobis matrices at T's rotation, and the 75 sums of the quadratic form as (hi, lo) pairs.  Diagnostic entry (tests). */
+int icpgpu_gicp_quadratic_sums(icpgpu_ctx* ctx, const float* T, double* sums150);
 
 /* ---- the step before the path: voxel-grid down-sampling -------------------- */
 /* replaces IcpOdometer::voxelFilterCloud = pcl::VoxelGrid<PointXYZ>::filter with leaf (L, L, L)

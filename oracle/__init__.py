@@ -18,7 +18,7 @@ P2P_SVD, GICP = 0, 1
 NN_KDTREE, NN_BRUTE = 0, 1
 PREC_F64, PREC_PCL_F32 = 0, 1
 ARITH_FMA, ARITH_FLANN = 0, 1
-GICP_SUMS_EXACT, GICP_SUMS_SEQUENTIAL, GICP_SUMS_SEQUENTIAL_REVERSED = 0, 1, 2
+GICP_SUMS_EXACT, GICP_SUMS_SEQUENTIAL, GICP_SUMS_SEQUENTIAL_REVERSED, GICP_SUMS_SMOOTH = 0, 1, 2, 3
 STATE_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
                5: "NO_CORRESPONDENCES"}
 

@@ -331,6 +331,7 @@ typedef struct {
   const double* maha; /* indexed by SOURCE index, 9 doubles each */
   float base[16];     /* base_transformation_ = guess */
   int sequential;     /* 1: ORC_GICP_SUMS_SEQUENTIAL, PCL's plain float64 loop instead of the exact sums; 2: ..._REVERSED */
+  int smooth;         /* 1: ORC_GICP_SUMS_SMOOTH, exact sums of the QUADRATIC objective (see eval_sums) */
 } gicp_problem;
 
 /* Order-independent sums.  PCL adds the cost and the gradient terms in plain float64, one after the other; BFGS then
@@ -392,6 +393,33 @@ static void eval_sums(const gicp_problem* P, const double x[6], double* f, doubl
   }
   sum3 acc = {0, 0, 0}, gts[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, Rms[9];
   for (int k = 0; k < 9; ++k) Rms[k].hi = Rms[k].mid = Rms[k].lo = 0.0;
+  if (P->smooth) {
+    /* ORC_GICP_SUMS_SMOOTH: the objective WITHOUT the float32 rounding of the transformed points.  PCL applies the float matrix T
+     * to every source point in float32 (a 3e-6 m noise per point at 50 m); with T p and base p taken as real numbers (here:
+     * float64, from the same float matrix) the cost of an outer iteration is an exact QUADRATIC form in T's twelve entries --
+     * what the GPU's quadratic inner solver (icpgpu_params.gicp_inner = 1) evaluates on the host from 73 sums collected once. */
+    for (int i = 0; i < P->m; ++i) {
+      const float* ps = P->src + 4 * (size_t)P->si[i];
+      const float* pt = P->tgt + 4 * (size_t)P->ti[i];
+      double pp[3], pb[3];
+      for (int r = 0; r < 3; ++r) {
+        pp[r] = (double)T[r] * ps[0] + (double)T[4 + r] * ps[1] + (double)T[8 + r] * ps[2] + (double)T[12 + r];
+        pb[r] = (double)P->base[r] * ps[0] + (double)P->base[4 + r] * ps[1] + (double)P->base[8 + r] * ps[2] + (double)P->base[12 + r];
+      }
+      const double res[3] = {pp[0] - (double)pt[0], pp[1] - (double)pt[1], pp[2] - (double)pt[2]};
+      const double* M = P->maha + 9 * (size_t)P->si[i];
+      double temp[3];
+      for (int r = 0; r < 3; ++r) temp[r] = M[3 * r] * res[0] + M[3 * r + 1] * res[1] + M[3 * r + 2] * res[2];
+      sum3_add(&acc, res[0] * temp[0] + res[1] * temp[1] + res[2] * temp[2]);
+      for (int r = 0; r < 3; ++r) sum3_add(&gts[r], temp[r]);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) sum3_add(&Rms[3 * r + c], pb[r] * temp[c]);
+    }
+    *f = sum3_value(&acc);
+    for (int r = 0; r < 3; ++r) gt[r] = sum3_value(&gts[r]);
+    for (int k = 0; k < 9; ++k) Rm[k] = sum3_value(&Rms[k]);
+    return;
+  }
   for (int i = 0; i < P->m; ++i) {
     const float* ps = P->src + 4 * (size_t)P->si[i];
     const float* pt = P->tgt + 4 * (size_t)P->ti[i];
@@ -825,6 +853,7 @@ int orc_gicp_align(const float* src, size_t n_s, const float* tgt, size_t n_t, c
   prob.src = src; prob.tgt = tgt; prob.si = si; prob.ti = ti; prob.maha = maha;
   memcpy(prob.base, guess, sizeof(guess));
   prob.sequential = seq;
+  prob.smooth = P->gicp_sums == ORC_GICP_SUMS_SMOOTH;
   tl_trig_cr = seq == 0; /* EXACT: correctly rounded sines / cosines; PCL's evaluation: this platform's libm */
   while (!converged) {
     float TG[16];

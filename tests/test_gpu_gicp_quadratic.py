@@ -1,0 +1,138 @@
+"""GPU tests of GICP's QUADRATIC inner solver (icpgpu_params.gicp_inner = GICP_INNER_QUADRATIC; icp_gicp_quadratic.h,
+gicp_quadratic_kernel): what PCL's estimateRigidTransformationBFGS computes inside every outer iteration
+(/root/reference/src/icpslam/icp_odometer.cpp:198), with the ~35 passes over the correspondences replaced by ONE.
+
+The mode is NOT bit-identical to the oracle's PCL restatement (it leaves out PCL's float32 rounding of the transformed points), so
+the tests are of three kinds: the device sums against NumPy (tight), the registration against the oracle's restatement of the SAME
+objective (GICP_SUMS_SMOOTH; tight on most pairs, BFGS amplifies the last bits on a few), and against PCL's evaluation with the
+BASELINE tolerance as the yardstick (statistical, like tests/test_gpu_gicp.py::test_gicp_vs_pcl_ordered_evaluation)."""
+import numpy as np
+import pytest
+
+import oracle
+from icpslam_amd import GICP, GICP_INNER_EXACT, GICP_INNER_QUADRATIC, synth
+
+pytestmark = pytest.mark.gpu
+R_TOL, T_TOL = 1e-4, 1e-3
+PAIRS = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (3, 3)]
+TRI = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+
+
+def _cmp(got, ref):
+    return (float(np.abs(np.asarray(got["T"], np.float64)[:3, :3] - np.asarray(ref["T"], np.float64)[:3, :3]).max()),
+            float(np.linalg.norm(np.asarray(got["T"], np.float64)[:3, 3] - np.asarray(ref["T"], np.float64)[:3, 3])))
+
+
+@pytest.mark.parametrize("n,seed,gate", [(6000, 3, 1.0), (22000, 5, 1.0), (70000, 7, 0.5)])
+def test_quadratic_sums_match_numpy(ctx, n, seed, gate):
+    """gicp_quadratic_kernel against NumPy on the same correspondences (icpgpu_nn's, exact), the same covariances
+    (icpgpu_gicp_covariances) and a float64 Mahalanobis inverse: every one of the 75 sums to 1e-9 of its magnitude; m exactly.
+    (70 000 points: more than one correspondence per lane, the streamed branch of the kernel.)"""
+    src, tgt, _ = synth.make_pair(n, n + 1000, seed=seed)
+    ctx.set_params(ctx.default_params(), method=GICP, max_correspondence_distance=gate)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    T = synth.pose_matrix(0.05, -0.03, 0.01, 0.002, -0.001, 0.004).astype(np.float32)
+    got = ctx.gicp_quadratic_sums(T)
+    idx, d2 = ctx.nn(T)
+    Cs, Ct = ctx.gicp_covariances(False), ctx.gicp_covariances(True)
+    use = (idx >= 0) & (d2.astype(np.float64) < gate * gate)
+    R = T[:3, :3].astype(np.float64)
+    S = Ct[idx[use]] + R @ Cs[use] @ R.T
+    M = np.linalg.inv(S)
+    M = 0.5 * (M + M.transpose(0, 2, 1))
+    p = np.concatenate([src[use, :3].astype(np.float64), np.ones((use.sum(), 1))], axis=1)
+    q = tgt[idx[use], :3].astype(np.float64)
+    Mq = np.einsum("ncd,nd->nc", M, q)
+    ref = np.zeros(75)
+    mag = np.zeros(75)
+    for pi, (e, f) in enumerate(PAIRS):
+        for k, (c, d) in enumerate(TRI):
+            t = p[:, e] * p[:, f] * M[:, c, d]
+            ref[pi * 6 + k], mag[pi * 6 + k] = t.sum(), np.abs(t).sum()
+    for e in range(4):
+        for c in range(3):
+            t = p[:, e] * Mq[:, c]
+            ref[60 + e * 3 + c], mag[60 + e * 3 + c] = t.sum(), np.abs(t).sum()
+    t = np.einsum("nc,nc->n", q, Mq)
+    ref[72], mag[72] = t.sum(), np.abs(t).sum()
+    ref[73], mag[73] = use.sum(), use.sum()
+    ref[74], mag[74] = d2[use].astype(np.float64).sum(), d2[use].astype(np.float64).sum()
+    val = got[:, 0] + got[:, 1]
+    assert val[73] == use.sum()
+    # the adjugate inverse of the kernel and np.linalg.inv agree to ~1e-13 relative on these well-conditioned matrices
+    assert np.all(np.abs(val - ref) <= 1e-9 * mag + 1e-12), np.abs(val - ref) / (mag + 1e-300)
+
+
+def _random_pair(seed):
+    rng = np.random.default_rng(90_000 + seed)
+    n_s, n_t = int(rng.integers(3_000, 12_000)), int(rng.integers(3_000, 12_000))
+    gate = float(rng.choice([0.5, 1.0, 2.0]))
+    src, tgt, _ = synth.make_pair(n_s, n_t, seed=seed)
+    return src, tgt, gate
+
+
+def test_quadratic_registration_vs_oracle_and_pcl_order(ctx):
+    """120 random pairs (the family of test_gicp_vs_pcl_ordered_evaluation), three comparisons:
+    * against the oracle's restatement of the SAME objective (GICP_SUMS_SMOOTH): the two agree to ~1e-12 per evaluation, BFGS and the
+      outer loop's stop amplify that on some pairs -- at least 85 % bit-identical transforms' worth of agreement (dt <= 1e-6 m),
+      at least 97 % within the BASELINE tolerance;
+    * against PCL's own evaluation (GICP_SUMS_SEQUENTIAL): offline (scripts/r5/quadratic_costing.py, 200 pairs) the smooth objective
+      lands within 1e-4 / 1e-3 m on 92 % of these pairs where PCL's loop run backwards manages 97 %: at least 85 % here, nothing
+      farther than 5e-3 / 5 cm;
+    * the EXACT mode of the same context afterwards still lands on the oracle's bits (the mode is a parameter, not a state)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    seeds = list(range(1000, 1120))
+
+    def ref(seed):
+        src, tgt, gate = _random_pair(seed)
+        return [oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_iterations=10, max_correspondence_distance=gate, gicp_sums=m))
+                for m in (oracle.GICP_SUMS_SMOOTH, oracle.GICP_SUMS_SEQUENTIAL)]
+
+    with ThreadPoolExecutor(8) as ex:
+        refs = list(ex.map(ref, seeds))
+    vs_smooth, vs_pcl, same_iters = [], [], 0
+    for seed, (smooth, seq) in zip(seeds, refs):
+        src, tgt, gate = _random_pair(seed)
+        ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10, max_correspondence_distance=gate, gicp_inner=GICP_INNER_QUADRATIC)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        got = ctx.align()
+        vs_smooth.append(_cmp(got, smooth))
+        vs_pcl.append(_cmp(got, seq))
+        same_iters += got["iterations"] == smooth["iterations"]
+    n = len(seeds)
+    tight = sum(dt <= 1e-6 and dR <= 1e-7 for dR, dt in vs_smooth)
+    ok_smooth = sum(dR <= R_TOL and dt <= T_TOL for dR, dt in vs_smooth)
+    ok_pcl = sum(dR <= R_TOL and dt <= T_TOL for dR, dt in vs_pcl)
+    worst_pcl = (max(dR for dR, _ in vs_pcl), max(dt for _, dt in vs_pcl))
+    print(f"quadratic vs oracle SMOOTH: {tight}/{n} within 1e-7 / 1e-6 m, {ok_smooth}/{n} within 1e-4 / 1e-3 m, same outer iterations {same_iters}/{n}; "
+          f"vs PCL-ordered: {ok_pcl}/{n} within tolerance, worst dR {worst_pcl[0]:.2e} dt {worst_pcl[1]:.2e} m")
+    assert tight >= 0.85 * n and ok_smooth >= 0.97 * n, (tight, ok_smooth)
+    assert ok_pcl >= 0.85 * n and worst_pcl[0] <= 5e-3 and worst_pcl[1] <= 5e-2, (ok_pcl, worst_pcl)
+    p = ctx.profile()
+    assert p.gicp_quadratic_solves > 0
+    # back to EXACT on the same context: the oracle's bits
+    src, tgt, gate = _random_pair(1000)
+    ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10, max_correspondence_distance=gate, gicp_inner=GICP_INNER_EXACT)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    got = ctx.align()
+    exact = oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_iterations=10, max_correspondence_distance=gate))
+    assert np.array_equal(got["T"].view(np.uint32), np.asarray(exact["T"], np.float32).view(np.uint32))
+
+
+def test_quadratic_degenerate_cases(ctx):
+    """fewer than four correspondences -> NotEnoughPoints (not converged, T = guess composition of identity), empty target -> early
+    exit: the same exits as the EXACT mode takes (tests/test_gpu_gicp.py)."""
+    src, tgt, _ = synth.make_pair(4000, 4000, seed=11)
+    far = tgt.copy()
+    far[:, :3] += 500.0                       # nothing within the gate
+    for inner in (GICP_INNER_EXACT, GICP_INNER_QUADRATIC):
+        ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10, gicp_inner=inner)
+        ctx.set_source(src)
+        ctx.set_target(far)
+        r = ctx.align()
+        assert not r["converged"] and r["n_corr"] < 4, (inner, r["converged"], r["n_corr"])
+        assert np.allclose(r["T"], np.eye(4), atol=0)
