@@ -158,7 +158,7 @@ def shim_pipeline(scan_a, scan_b, leaf: float, iters: int, n_scans: int = 24, th
             scan_a.tofile(pa)
             scan_b.tofile(pb)
             for key, env in (("scans_per_sec", {}), ("scans_per_sec_without_recognition", {"ICPGPU_RECOGNISE": "0"}),
-                             ("scans_per_sec_one_thread", {})):
+                             ("scans_per_sec_one_thread", {}), ("scans_per_sec_quadratic_inner", {"ICPGPU_GICP_INNER": "quadratic"})):
                 th = 1 if key.endswith("one_thread") else threads
                 r = subprocess.run([exe, pa, str(scan_a.shape[0]), pb, str(scan_b.shape[0]), str(n_scans), repr(leaf), str(iters),
                                     str(th), "4"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
@@ -358,7 +358,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world == a.gpus
 
-    from icpslam_amd import GICP, NN_AUTO, NN_BRUTE, NN_GRID, Context, sharding, synth
+    from icpslam_amd import GICP, GICP_INNER_EXACT, GICP_INNER_QUADRATIC, NN_AUTO, NN_BRUTE, NN_GRID, Context, sharding, synth
 
     nn_mode = {"auto": NN_AUTO, "brute": NN_BRUTE, "grid": NN_GRID}[a.nn]
     n_s, n_t, kind = WORKLOADS[a.workload]
@@ -503,6 +503,14 @@ def main():
                 for f, _t in a_._fields_:
                     setattr(self, f, getattr(a_, f) - getattr(b_, f))
         pg = _Diff(ctx.profile(), pg0)
+        # (3b) the same pipeline with GICP's inner minimisation on the QUADRATIC FORM of each outer iteration (opt-in:
+        #      icpgpu_params.gicp_inner; one pass over the correspondences per outer iteration instead of ~35, BFGS on the host;
+        #      results within tolerance of, not bit-identical to, the default's -- profiles/r05_gicp_quadratic.txt)
+        pq0 = ctx.profile()
+        pipeline_quadratic = odometry_loop(n_e2e, voxel_leaf=leaf, method=GICP, max_iterations=a.iters, force_iterations=0,
+                                           gicp_inner=GICP_INNER_QUADRATIC)
+        pq = _Diff(ctx.profile(), pq0)
+        ctx.set_params(gicp_inner=GICP_INNER_EXACT)
         gicp_roofline = None
         if pg.gicp_cost_launches and pg.gicp_eval_ms > 0:
             ev_ms = pg.gicp_eval_ms / pg.gicp_cost_launches
@@ -540,6 +548,16 @@ def main():
             gicp_batch = 3 * len(bs) / (time.perf_counter() - tb)
         except Exception as e:  # a secondary figure must not take the headline down
             gicp_batch = repr(e)[:200]
+        gicp_batch_quadratic = None
+        try:
+            ctx.set_params(ctx.default_params(), method=GICP, max_iterations=a.iters, force_iterations=0, gicp_inner=GICP_INNER_QUADRATIC)
+            ctx.align_batch(bs, bt, want_fitness=True)
+            tb = time.perf_counter()
+            for _ in range(3):
+                ctx.align_batch(bs, bt, want_fitness=True)
+            gicp_batch_quadratic = 3 * len(bs) / (time.perf_counter() - tb)
+        except Exception as e:
+            gicp_batch_quadratic = repr(e)[:200]
         shim = shim_pipeline(src, tgt, leaf, a.iters, n_scans=n_e2e + 4)
         gicp_cpu = None if a.no_cpu_baseline else gicp_cpu_baseline(src, tgt, leaf, a.iters, a.cpu_seconds)
         extras["gicp"] = {"scan_pairs_per_sec_e2e": gicp,
@@ -557,6 +575,17 @@ def main():
                           "batch_pairs_per_sec": gicp_batch,
                           "batch_def": f"32 voxel-filtered ({leaf} m) pairs of the bench scans through icpgpu_align_batch in GICP mode, "
                                        "<= 10 outer iterations + fitness each (resumable runs, icpgpu_gicp.cpp: GicpRun)",
+                          "quadratic_inner": {
+                              "reference_pipeline_scans_per_sec": pipeline_quadratic,
+                              "batch_pairs_per_sec": gicp_batch_quadratic,
+                              "outer_iterations_solved": int(pq.gicp_quadratic_solves),
+                              "cost_evaluations_on_the_host": int(pq.gicp_cost_launches),
+                              "def": "OPT-IN mode icpgpu_params.gicp_inner = QUADRATIC (ICPGPU_GICP_INNER=quadratic): the same pipeline / "
+                                     "batch with ONE device pass per outer iteration (gicp_quadratic_kernel: the 73 coefficient sums of "
+                                     "the cost as a quadratic form in T's entries, Mahalanobis matrices on the way) and BFGS on the host "
+                                     "without a device round trip; within the BASELINE tolerance of the default's result on most pairs, "
+                                     "not bit-identical (it leaves out PCL's float32 rounding of the transformed points): "
+                                     "profiles/r05_gicp_quadratic.txt, tests/test_gpu_gicp_quadratic.py"},
                           "reference_pipeline_scans_per_sec": pipeline,
                           "reference_pipeline_def": f"per scan: VoxelGrid({leaf} m) of the raw {n_s}-point scan on the device "
                                                     f"(-> {ctx.n_target} points), then the GICP loop above on the filtered clouds: "

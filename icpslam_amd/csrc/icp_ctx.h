@@ -400,7 +400,8 @@ struct P2PRun {
 // A GICP registration as a resumable run (icpgpu_gicp.cpp: gicp_run_begin / gicp_run_step): the counterpart of P2PRun for the
 // solver the reference instantiates, so that one host thread of icpgpu_align_batch keeps several registrations in flight.
 struct GicpRun {
-  enum Phase { Idle, Blocking, CovGrid, WantSolve, Solve, Fitness, Done } phase = Idle;
+  enum Phase { Idle, Blocking, CovGrid, WantSolve, Solve, Quad, Fitness, Done } phase = Idle;  // Quad: waiting for the quadratic form's sums
+  bool quadratic = false;  // icpgpu_params.gicp_inner = QUADRATIC: every outer iteration is search + one pass + BFGS on the host
   // combine: the run does not launch its outer iteration's solver itself -- it stops in WantSolve with `item` filled in, and the
   // batch scheduler launches the solvers of all the runs that are ready in ONE kernel (gicp_solve_batch_kernel) on solve_stream
   bool combine = false;

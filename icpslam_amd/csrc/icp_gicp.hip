@@ -746,11 +746,30 @@ __global__ __launch_bounds__(256) void gicp_quadratic_kernel(const float4* __res
   if (!s_last) return;
   __threadfence();
   if (threadIdx.x == 0) *done = 0u;  // ready for the next launch (launches of one context are ordered by its stream)
-  if (threadIdx.x < kGicpQuadSums) {
+  // three threads per sum, each over a third of the workgroups, eight loads in flight (one load after the other -- 89 workgroups
+  // for a voxel-filtered scan -- made this tail ~60 us long: every load a trip to L2 and back before the next one left)
+  __shared__ DD s_fin[3][kGicpQuadSums];
+  const int slice = (int)threadIdx.x / kGicpQuadSums, k = (int)threadIdx.x % kGicpQuadSums, nb = (int)gridDim.x;
+  if (slice < 3) {
     DD a{0.0, 0.0};
-    for (unsigned int b = 0; b < gridDim.x; ++b) {
-      a = dd_add(a, partials[(size_t)b * kGicpQuadSums + threadIdx.x]);
+    for (int b0 = slice; b0 < nb; b0 += 3 * 8) {
+      DD v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = b0 + 3 * u;
+        v[u] = bb < nb ? partials[(size_t)bb * kGicpQuadSums + k] : DD{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = dd_add(v[2 * u], v[2 * u + 1]);
+      v[0] = dd_add(v[0], v[1]);
+      v[1] = dd_add(v[2], v[3]);
+      a = dd_add(a, dd_add(v[0], v[1]));
     }
+    s_fin[slice][k] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < kGicpQuadSums) {
+    const DD a = dd_add(dd_add(s_fin[0][k], s_fin[1][k]), s_fin[2][k]);
     store_result_pair(host_out + 2 * (2 * threadIdx.x), (unsigned long long)__double_as_longlong(a.hi), seq);
     store_result_pair(host_out + 2 * (2 * threadIdx.x + 1), (unsigned long long)__double_as_longlong(a.lo), seq);
   }

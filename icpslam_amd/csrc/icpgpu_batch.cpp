@@ -122,7 +122,7 @@ int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, c
     const int grc = ensure_gicp_resources(c);
     if (grc) return grc;
   }
-  const bool gicp_runs = gicp && gicp_device_solver_mode() != 0 && c->gicp_device_ok;
+  const bool gicp_runs = gicp && (gicp_inner_quadratic(c) || (gicp_device_solver_mode() != 0 && c->gicp_device_ok));  // (quadratic runs need no device solver)
   size_t n_threads = batch_threads(c, gicp ? (gicp_runs ? 2 : 8) : 4), depth = 1;
   if (!gicp) {
     if (const char* v = std::getenv("ICPGPU_BATCH_DEPTH")) depth = (size_t)std::max(1, std::atoi(v));

@@ -772,6 +772,17 @@ static int gicp_run_queue_outer(icpgpu_ctx* c, GicpRun& r) {
   } else {
     if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
   }
+  if (r.quadratic) {  // one pass for the quadratic form's sums (Mahalanobis matrices on the way); the run polls them (phase Quad)
+    r.seq0 = ++c->quad_seq;
+    r.t_issue = std::chrono::steady_clock::now();
+    HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, r.thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                     static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
+                                     wire_seq(c, r.seq0), c->stream));
+    r.solve_stream = c->stream;
+    r.phase = GicpRun::Quad;
+    r.polls = 0;
+    return ICPGPU_OK;
+  }
   HIP_TRY(c, launch_gicp_mahalanobis(n_s, keys, r.thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
                                      static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
   Vec6 x = gicp_state_from_matrix(r.transformation);
@@ -867,7 +878,11 @@ int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* r
     const int grc = ensure_gicp_resources(c);
     if (grc) return grc;
   }
-  if (!gicp_run_device_ok(c)) {  // no device solver on this context: the blocking function
+  r.quadratic = gicp_inner_quadratic(c);
+  if (r.quadratic) {
+    const int qrc = ensure_gicp_quadratic_resources(c);
+    if (qrc) return qrc;
+  } else if (!gicp_run_device_ok(c)) {  // no device solver on this context: the blocking function
     r.phase = GicpRun::Blocking;
     return ICPGPU_OK;
   }
@@ -924,9 +939,25 @@ static int gicp_run_conclude(icpgpu_ctx* c, GicpRun& r) {
   return ICPGPU_OK;
 }
 
+// an outer iteration's minimiser is in: the new transformation, PCL's convergence test, then the end or the next outer iteration
+static int gicp_run_after_solve(icpgpu_ctx* c, GicpRun& r, const Vec6& x) {
+  const icpgpu_params& P = c->params;
+  mat4f_identity(r.transformation);
+  gicp_apply_state(r.transformation, x);
+  const double delta = gicp_outer_delta(r.previous, r.transformation, 2e-3, P.transformation_epsilon);
+  ++r.nr;
+  c->prof.iterations += 1;
+  if (r.nr >= P.max_iterations || (delta < 1 && !P.force_iterations)) {
+    r.converged = true;
+    r.state = r.nr >= P.max_iterations ? ICPGPU_CONV_ITERATIONS : ICPGPU_CONV_TRANSFORM;
+    std::memcpy(r.previous, r.transformation, sizeof(r.previous));
+    return gicp_run_conclude(c, r);
+  }
+  return gicp_run_queue_outer(c, r);
+}
+
 // One non-blocking step.  Returns < 0 on error, 0 when nothing has arrived yet, 1 when the run moved on (r.phase == Done: finished).
 int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
-  const icpgpu_params& P = c->params;
   int rc;
   switch (r.phase) {
     case GicpRun::WantSolve:
@@ -1030,19 +1061,45 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
       }
       Vec6 x;
       for (int k = 0; k < 6; ++k) x[k] = out[1 + k];
-      mat4f_identity(r.transformation);
-      gicp_apply_state(r.transformation, x);
-      const double delta = gicp_outer_delta(r.previous, r.transformation, 2e-3, P.transformation_epsilon);
-      ++r.nr;
-      c->prof.iterations += 1;
-      if (r.nr >= P.max_iterations || (delta < 1 && !P.force_iterations)) {
-        r.converged = true;
-        r.state = r.nr >= P.max_iterations ? ICPGPU_CONV_ITERATIONS : ICPGPU_CONV_TRANSFORM;
-        std::memcpy(r.previous, r.transformation, sizeof(r.previous));
+      if ((rc = gicp_run_after_solve(c, r, x))) return rc;
+      return 1;
+    }
+    case GicpRun::Quad: {
+      double sums[2 * kGicpQuadSums];
+      if (!quad_sums_read(c, r.seq0, sums)) {
+        if ((++r.polls & 0x3FFu) != 0) return 0;
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for the GICP quadratic pass: %s", hipGetErrorString(q));
+        if (q == hipErrorNotReady) {
+          if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count() > wait_timeout_ms())
+            return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for the GICP quadratic pass (hung kernel?)", wait_timeout_ms());
+          return 0;
+        }
+        if (!quad_sums_read(c, r.seq0, sums)) return fail(c, ICPGPU_ERR_HIP, "the GICP quadratic pass finished without publishing its sums");
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      const double m = sums[2 * 73], d2 = sums[2 * 74];
+      r.mse = m > 0 ? d2 / m : 0.0;
+      r.n_corr = (unsigned)m;
+      std::memcpy(r.previous, r.transformation, sizeof(r.previous));
+      if (r.n_corr < 4) {  // NotEnoughPointsException -> the loop breaks with converged_ = false
+        r.state = ICPGPU_CONV_NO_CORRESPONDENCES;
         if ((rc = gicp_run_conclude(c, r))) return rc;
         return 1;
       }
-      if ((rc = gicp_run_queue_outer(c, r))) return rc;
+      Vec6 x = gicp_state_from_matrix(r.transformation);
+      int evals = 0;
+      const GicpSolve sr = gicp_minimize_quadratic(sums, r.guess, x, 20, 1e-2, &evals);
+      c->prof.gicp_quadratic_solves += 1;
+      c->prof.gicp_cost_launches += (uint64_t)evals;
+      c->prof.gicp_eval_corr += (uint64_t)(m * evals);
+      c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count();
+      if (sr != GicpSolve::Ok) {  // SolverDidntConvergeException
+        r.state = ICPGPU_NOT_CONVERGED;
+        if ((rc = gicp_run_conclude(c, r))) return rc;
+        return 1;
+      }
+      if ((rc = gicp_run_after_solve(c, r, x))) return rc;
       return 1;
     }
     case GicpRun::Fitness: {

@@ -224,3 +224,42 @@ def test_odometer_pipeline_as_integrated_matches_the_resident_pipeline_bit_for_b
             assert np.array_equal(T, ref["T"]), (row[0], threads, env)
             assert float(row[3]) == ref["fitness"]
     print("shim pipeline scans/s:", rates)
+
+
+@pytest.mark.gpu
+def test_odometer_pipeline_with_the_quadratic_inner_solver(built, tmp_path):
+    """The UNCHANGED pipeline binary with ICPGPU_GICP_INNER=quadratic in its environment (include/icpgpu.h: icpgpu_gicp_inner) against
+    the C-ABI pipeline with icpgpu_params.gicp_inner = QUADRATIC: bit for bit (the mode's sums are exact, the host arithmetic is
+    the same), and close to the default mode's transforms on this pair (1e-4 in R, 1 cm in t: the
+    registration of such pairs is only defined to millimetres, see the comment below)."""
+    from icpslam_amd import GICP, GICP_INNER_EXACT, GICP_INNER_QUADRATIC, Context
+    exe = _build_demo(tmp_path, "odometer_pipeline_demo")
+    a, b, _ = synth.make_pair(60000, 60000, seed=21)
+    n_scans, leaf = 7, 0.2
+    want = {}
+    for inner in (GICP_INNER_QUADRATIC, GICP_INNER_EXACT):
+        want[inner] = []
+        with Context(0) as c:
+            c.set_params(c.default_params(), method=GICP, max_iterations=10, gicp_inner=inner)
+            for k in range(n_scans):
+                c.set_source_voxel_filtered((a, b)[k % 2], leaf)
+                if k == 0:
+                    c.promote_source_to_target()
+                    continue
+                r = c.align(want_fitness=True)
+                want[inner].append(r)
+                if r["converged"] and r["fitness"] < 20:
+                    c.promote_source_to_target()
+    r = _run_pipeline(exe, tmp_path, a, b, n_scans, leaf, 10, 4, {"ICPGPU_GICP_INNER": "quadratic"})
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split() for ln in r.stdout.strip().splitlines()[:-1]]
+    assert len(rows) == n_scans - 1
+    for row, ref, exact in zip(rows, want[GICP_INNER_QUADRATIC], want[GICP_INNER_EXACT]):
+        T = np.array([float(v) for v in row[5:21]], np.float32).reshape(4, 4).T
+        assert int(row[1]) == int(ref["converged"]) and int(row[2]) == ref["iterations"]
+        assert np.array_equal(T, ref["T"]), row[0]
+        assert float(row[3]) == ref["fitness"]
+        assert np.abs(T[:3, :3].astype(np.float64) - exact["T"][:3, :3]).max() <= 1e-4
+        # (offline, scripts/r5/quadratic_costing.py: PCL's own sums run backwards move a pipeline pair by 0.55 mm in the median, 3.1 mm
+        #  at worst; this mode by 0.7-1.1 mm, 3.3-7.8 mm at worst)
+        assert np.linalg.norm(T[:3, 3].astype(np.float64) - exact["T"][:3, 3]) <= 1e-2

@@ -136,3 +136,43 @@ def test_quadratic_degenerate_cases(ctx):
         r = ctx.align()
         assert not r["converged"] and r["n_corr"] < 4, (inner, r["converged"], r["n_corr"])
         assert np.allclose(r["T"], np.eye(4), atol=0)
+
+
+@pytest.mark.parametrize("threads,runs", [(1, 8), (2, 3)])
+def test_quadratic_batch_runs_equal_single_aligns(built, monkeypatch, threads, runs):
+    """icpgpu_align_batch with gicp_inner = QUADRATIC: resumable runs (GicpRun, phase Quad: search + one pass, sums polled, BFGS on
+    the host) -- every pair exactly as a single icpgpu_align in the same mode gives it (the sums are exact, so the bits cannot depend
+    on who computed them), including the degenerate pairs of tests/test_gpu_gicp.py::test_gicp_batch_runs_equal_single_aligns."""
+    from icpslam_amd import Context
+    monkeypatch.setenv("ICPGPU_BATCH_THREADS", str(threads))
+    monkeypatch.setenv("ICPGPU_BATCH_DEPTH", str(runs))
+    pairs = []
+    for k, n in enumerate([3000, 9000, 14000, 22000, 5000, 30000, 7000, 70000, 16000, 4000]):
+        s, t, _ = synth.make_pair(n, n + 500 * (k % 3), seed=700 + k)
+        pairs.append((s, t))
+    far = pairs[1][1].copy()
+    far[:, 2] += 500.0
+    pairs.insert(3, (pairs[1][0], far))                       # nothing within the gate
+    pairs.insert(6, (pairs[0][0][:10].copy(), pairs[0][1]))   # fewer points than neighbours per covariance
+    pairs.append((pairs[2][0], np.zeros((0, 4), np.float32)))  # empty target
+    with Context(0) as one:
+        one.set_params(one.default_params(), method=GICP, max_iterations=8, gicp_inner=GICP_INNER_QUADRATIC)
+        want = []
+        for s, t in pairs:
+            one.set_source(s)
+            one.set_target(t)
+            want.append(one.align(want_fitness=True))
+    with Context(0) as c:
+        c.set_params(c.default_params(), method=GICP, max_iterations=8, gicp_inner=GICP_INNER_QUADRATIC)
+        for _ in range(2):
+            c.profile_reset()
+            got = c.align_batch([p[0] for p in pairs], [p[1] for p in pairs], want_fitness=True)
+            prof = c.profile()
+            assert prof.gicp_quadratic_solves > 0 and prof.gicp_device_solves == 0 and prof.gicp_host_solves == 0
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert np.array_equal(g["T"], w["T"]), k
+                assert (g["converged"], g["iterations"], g["state"], g["n_corr"]) == (w["converged"], w["iterations"], w["state"], w["n_corr"]), k
+                assert g["fitness"] == w["fitness"] or (np.isnan(g["fitness"]) and np.isnan(w["fitness"])), k
+    assert want[3]["n_corr"] < 4 and not want[3]["converged"], want[3]
+    assert not want[6]["converged"] and want[6]["iterations"] == 0, want[6]
+    assert not want[-1]["converged"] and want[-1]["iterations"] == 0, want[-1]
