@@ -678,6 +678,13 @@ __device__ __forceinline__ double quad_term(const QuadPoint& P) {  // term N of 
   }
 }
 template <int G, int K>
+__device__ __forceinline__ void quad_set_group(DD (&acc)[13], const QuadPoint& P) {  // acc = the terms of a lane's FIRST correspondence
+  if constexpr (K < 13 && 13 * G + K < kGicpQuadSums) {
+    acc[K].hi = quad_term<13 * G + K>(P);
+    quad_set_group<G, K + 1>(acc, P);
+  }
+}
+template <int G, int K>
 __device__ __forceinline__ void quad_add_group(DD (&acc)[13], const QuadPoint& P) {
   if constexpr (K < 13 && 13 * G + K < kGicpQuadSums) {
     dd_add_term(acc[K], quad_term<13 * G + K>(P));
@@ -687,14 +694,15 @@ __device__ __forceinline__ void quad_add_group(DD (&acc)[13], const QuadPoint& P
 // partials[block][kGicpQuadSums] (DD); the last workgroup to finish adds the workgroups' partials and publishes the kGicpQuadSums
 // (hi, lo) pairs as 2 x kGicpQuadSums result pairs numbered seq in host_out (gicp_granule_read on the host)
 template <int G>
-__device__ __forceinline__ void quad_group(const QuadPoint& mine, int i_next, int stride, const float4* __restrict__ src, int n_s,
+__device__ __forceinline__ void quad_group(const QuadPoint& mine, const QuadPoint& mine2, int i_next, int stride, const float4* __restrict__ src, int n_s,
                                            const float4* __restrict__ tgt, const unsigned long long* __restrict__ keys, float thr,
                                            const Rot3d& R, const double* __restrict__ cov_s, const double* __restrict__ cov_t,
                                            DD* __restrict__ out, DD (*s_lane)[16][17], DD (*s_chunk)[16]) {
   DD acc[13];
 #pragma unroll
   for (int k = 0; k < 13; ++k) acc[k].hi = acc[k].lo = 0.0;
-  if (mine.use) quad_add_group<G, 0>(acc, mine);
+  if (mine.use) quad_set_group<G, 0>(acc, mine);  // (0 + t by TwoSum is t, seven operations later)
+  if (mine2.use) quad_add_group<G, 0>(acc, mine2);
   for (int i = i_next; i < n_s; i += stride) {  // larger clouds: the further correspondences of this lane, read again per group
     QuadPoint P;
     quad_point_load(P, i, src, tgt, keys, thr, R, cov_s, cov_t);
@@ -723,51 +731,58 @@ __global__ __launch_bounds__(256) void gicp_quadratic_kernel(const float4* __res
                                                              const unsigned long long* __restrict__ keys, float thr, Rot3d R,
                                                              const double* __restrict__ cov_s, const double* __restrict__ cov_t,
                                                              DD* __restrict__ partials, unsigned int* __restrict__ done,
-                                                             unsigned long long* __restrict__ host_out, unsigned long long seq) {
+                                                             unsigned long long* __restrict__ host_out, unsigned long long seq, int stamps) {
+  // stamps (development flavour, ICPGPU_GICP_TIMING): the LAST workgroup's 100 MHz clock at six points, as result pairs behind the sums
+  const long long st0 = stamps ? (long long)wall_clock64() : 0;
   __shared__ DD s_lane[13][16][17];
   __shared__ DD s_chunk[13][16];
   __shared__ bool s_last;
   const int stride = (int)gridDim.x * 256, i0 = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  QuadPoint mine;
-  mine.use = false;
+  QuadPoint mine, mine2;  // the lane's first two correspondences stay in registers (half as many workgroups to add up at the end)
+  mine.use = mine2.use = false;
   if (i0 < n_s) quad_point_load(mine, i0, src, tgt, keys, thr, R, cov_s, cov_t);
+  if (i0 + stride < n_s) quad_point_load(mine2, i0 + stride, src, tgt, keys, thr, R, cov_s, cov_t);
   DD* out = partials + (size_t)blockIdx.x * kGicpQuadSums;
-  quad_group<0>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
-  quad_group<1>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
-  quad_group<2>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
-  quad_group<3>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
-  quad_group<4>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
-  quad_group<5>(mine, i0 + stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  const long long st1 = stamps ? (long long)wall_clock64() : 0;
+  quad_group<0>(mine, mine2, i0 + 2 * stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<1>(mine, mine2, i0 + 2 * stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<2>(mine, mine2, i0 + 2 * stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<3>(mine, mine2, i0 + 2 * stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<4>(mine, mine2, i0 + 2 * stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
+  quad_group<5>(mine, mine2, i0 + 2 * stride, stride, src, n_s, tgt, keys, thr, R, cov_s, cov_t, out, s_lane, s_chunk);
   // the last workgroup to get here adds everybody's partials (device-scope release / acquire around the counter)
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1u;
+  const long long st2 = stamps ? (long long)wall_clock64() : 0;
+  // (every global store of this workgroup came from threads 0..12 -- wave 0, the wave of thread 0 -- so the counter's RELEASE orders
+  //  them by itself: one wave's write-back instead of a fence in all four and a barrier, 3.3 -> ~1.5 us on the last workgroup's path)
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every wave of the last workgroup: its loads below must not be served from stale lines
+  const long long st3 = stamps ? (long long)wall_clock64() : 0;
   if (threadIdx.x == 0) *done = 0u;  // ready for the next launch (launches of one context are ordered by its stream)
-  // three threads per sum, each over a third of the workgroups, eight loads in flight (one load after the other -- 89 workgroups
-  // for a voxel-filtered scan -- made this tail ~60 us long: every load a trip to L2 and back before the next one left)
+  // three threads per sum, each over a third of the workgroups, sixteen loads in flight (one load after the other -- 89 workgroups
+  // for a voxel-filtered scan at first -- made this tail ~60 us long: every load a trip to L2 and back before the next one left)
   __shared__ DD s_fin[3][kGicpQuadSums];
   const int slice = (int)threadIdx.x / kGicpQuadSums, k = (int)threadIdx.x % kGicpQuadSums, nb = (int)gridDim.x;
   if (slice < 3) {
     DD a{0.0, 0.0};
-    for (int b0 = slice; b0 < nb; b0 += 3 * 8) {
-      DD v[8];
+    for (int b0 = slice; b0 < nb; b0 += 3 * 16) {  // sixteen loads in flight: a voxel-filtered scan's 45 workgroups in ONE trip
+      DD v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int bb = b0 + 3 * u;
         v[u] = bb < nb ? partials[(size_t)bb * kGicpQuadSums + k] : DD{0.0, 0.0};
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = dd_add(v[2 * u], v[2 * u + 1]);
-      v[0] = dd_add(v[0], v[1]);
-      v[1] = dd_add(v[2], v[3]);
-      a = dd_add(a, dd_add(v[0], v[1]));
+      a = dd_add(a, dd_sum16(v));
     }
     s_fin[slice][k] = a;
   }
   __syncthreads();
+  const long long st4 = stamps ? (long long)wall_clock64() : 0;
+  if (stamps && threadIdx.x == 255) {
+    const long long t[5] = {st0, st1, st2, st3, st4};
+    for (int u = 0; u < 5; ++u) store_result_pair(host_out + 2 * (2 * kGicpQuadSums + u), (unsigned long long)t[u], seq);
+  }
   if (threadIdx.x < kGicpQuadSums) {
     const DD a = dd_add(dd_add(s_fin[0][k], s_fin[1][k]), s_fin[2][k]);
     store_result_pair(host_out + 2 * (2 * threadIdx.x), (unsigned long long)__double_as_longlong(a.hi), seq);
@@ -1304,14 +1319,15 @@ hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, floa
 }
 
 int gicp_quadratic_blocks(int n_s) {
-  const int b = (n_s + 255) / 256;
+  const int b = (n_s + 511) / 512;  // two correspondences per lane
   return b < 1 ? 1 : b > kGicpQuadBlocks ? kGicpQuadBlocks : b;
 }
 hipError_t launch_gicp_quadratic(const float4* src, int n_s, const float4* tgt, const unsigned long long* keys, float thr,
                                  const Rot3d& R, const double* cov_s, const double* cov_t, double* partials, unsigned int* done,
                                  unsigned long long* host_out, unsigned long long seq, hipStream_t stream) {
+  static const int stamps = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_TIMING"); return e && atoi(e) != 0 ? 1 : 0; }();
   hipLaunchKernelGGL(gicp_quadratic_kernel, dim3(gicp_quadratic_blocks(n_s)), dim3(256), 0, stream, src, n_s, tgt, keys, thr, R, cov_s,
-                     cov_t, reinterpret_cast<DD*>(partials), done, host_out, seq);
+                     cov_t, reinterpret_cast<DD*>(partials), done, host_out, seq, stamps);
   return hipGetLastError();
 }
 

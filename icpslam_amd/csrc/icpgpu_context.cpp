@@ -291,7 +291,7 @@ int ensure_gicp_quadratic_resources(icpgpu_ctx* c) {
   if (c->h_quad) return ICPGPU_OK;
   hipError_t e;
   const size_t part_bytes = (size_t)kGicpQuadBlocks * kGicpQuadSums * 2 * sizeof(double);
-  const size_t out_bytes = (size_t)2 * kGicpQuadSums * 16;
+  const size_t out_bytes = (size_t)(2 * kGicpQuadSums + 8) * 16;  // (+ the development flavour's stamps)
   void* h = nullptr;
   if ((e = hipMalloc(reinterpret_cast<void**>(&c->quad_partials), part_bytes)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&c->quad_done), 64)) != hipSuccess || (e = hipMemset(c->quad_done, 0, 64)) != hipSuccess ||

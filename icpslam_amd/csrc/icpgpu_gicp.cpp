@@ -535,6 +535,21 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       double sums[2 * kGicpQuadSums];
       if ((rc = wait_quad_sums(c, seq, sums))) return rc;
       mark(3);
+      if (stage_timing) {  // the last workgroup's stamps (gicp_quadratic_kernel), 100 MHz ticks
+        double st[5];
+        bool all = true;
+        for (int u = 0; u < 5; ++u) all = gicp_granule_read(c->h_quad + 2 * (2 * kGicpQuadSums + u), seq, &st[u]) && all;
+        if (all) {
+          long long t[5];
+          for (int u = 0; u < 5; ++u) std::memcpy(&t[u], &st[u], sizeof(long long));
+          static double acc[4] = {0, 0, 0, 0};
+          static unsigned long long n = 0;
+          for (int u = 0; u < 4; ++u) acc[u] += (double)(t[u + 1] - t[u]) * 0.01;
+          if ((++n % 100) == 0)
+            fprintf(stderr, "[icpgpu] quadratic pass, last workgroup, mean of %llu (us): loads + Mahalanobis %.2f | six groups %.2f | fence + counter %.2f | partials of all workgroups %.2f\n",
+                    n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n);
+        }
+      }
       const double m = sums[2 * 73], d2 = sums[2 * 74];
       m_count = m;
       mse = m > 0 ? d2 / m : 0.0;

@@ -23,11 +23,11 @@ def _cmp(got, ref):
             float(np.linalg.norm(np.asarray(got["T"], np.float64)[:3, 3] - np.asarray(ref["T"], np.float64)[:3, 3])))
 
 
-@pytest.mark.parametrize("n,seed,gate", [(6000, 3, 1.0), (22000, 5, 1.0), (70000, 7, 0.5)])
+@pytest.mark.parametrize("n,seed,gate", [(6000, 3, 1.0), (22000, 5, 1.0), (70000, 7, 0.5), (200000, 9, 1.0)])
 def test_quadratic_sums_match_numpy(ctx, n, seed, gate):
     """gicp_quadratic_kernel against NumPy on the same correspondences (icpgpu_nn's, exact), the same covariances
     (icpgpu_gicp_covariances) and a float64 Mahalanobis inverse: every one of the 75 sums to 1e-9 of its magnitude; m exactly.
-    (70 000 points: more than one correspondence per lane, the streamed branch of the kernel.)"""
+    (70 000 points: two correspondences per lane; 200 000: the streamed branch of the kernel, up to four per lane.)"""
     src, tgt, _ = synth.make_pair(n, n + 1000, seed=seed)
     ctx.set_params(ctx.default_params(), method=GICP, max_correspondence_distance=gate)
     ctx.set_source(src)
