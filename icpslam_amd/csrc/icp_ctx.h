@@ -250,6 +250,8 @@ struct icpgpu_ctx {
   volatile unsigned long long* h_quad = nullptr;
   unsigned long long* h_quad_dev = nullptr;
   unsigned long long quad_seq = 0;
+  bool quad_pending = false;  // a pass was launched and its sums have not been read: the next launch zeroes the counter first (a pass that
+                              // died half-way would leave it mid-count)
   // measured mode: 0 = still timing both solvers, 1 = host, 2 = device; microseconds and evaluations of the timed inner
   // minimisations, [0] host [1] device (the first run of each is a warm-up and not counted)
   int gicp_choice = 0;

@@ -262,6 +262,15 @@ static int wait_solve_result(icpgpu_ctx* c, unsigned long long seq, double* out)
 
 // The quadratic form of an outer iteration (gicp_quadratic_kernel): 2 x kGicpQuadSums result pairs numbered `seq`.  all_there()
 // is also what a resumable run polls.
+// launch one pass (numbered seq) on the context's stream
+static int quad_pass_launch(icpgpu_ctx* c, int n_s, const unsigned long long* keys, float thr_excl, const Rot3d& R, unsigned long long seq) {
+  if (c->quad_pending) HIP_TRY(c, hipMemsetAsync(c->quad_done, 0, sizeof(unsigned int), c->stream));  // the last pass never reported: its counter may be mid-count
+  c->quad_pending = true;
+  HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
+                                   static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
+                                   wire_seq(c, seq), c->stream));
+  return ICPGPU_OK;
+}
 static bool quad_sums_read(const icpgpu_ctx* c, unsigned long long seq, double* sums) {
   bool all = true;
   for (int k = 0; k < 2 * kGicpQuadSums; ++k) all = gicp_granule_read(c->h_quad + 2 * k, seq, &sums[k]) && all;
@@ -529,11 +538,10 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       // numbers to wait for, then BFGS without a device round trip
       const auto t_q0 = std::chrono::steady_clock::now();
       const unsigned long long seq = ++c->quad_seq;
-      HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
-                                       static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
-                                       wire_seq(c, seq), c->stream));
+      if ((rc = quad_pass_launch(c, n_s, keys, thr_excl, R, seq))) return rc;
       double sums[2 * kGicpQuadSums];
       if ((rc = wait_quad_sums(c, seq, sums))) return rc;
+      c->quad_pending = false;
       mark(3);
       if (stage_timing) {  // the last workgroup's stamps (gicp_quadratic_kernel), 100 MHz ticks
         double st[5];
@@ -790,9 +798,7 @@ static int gicp_run_queue_outer(icpgpu_ctx* c, GicpRun& r) {
   if (r.quadratic) {  // one pass for the quadratic form's sums (Mahalanobis matrices on the way); the run polls them (phase Quad)
     r.seq0 = ++c->quad_seq;
     r.t_issue = std::chrono::steady_clock::now();
-    HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, r.thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
-                                     static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
-                                     wire_seq(c, r.seq0), c->stream));
+    if ((rc = quad_pass_launch(c, n_s, keys, r.thr_excl, R, r.seq0))) return rc;
     r.solve_stream = c->stream;
     r.phase = GicpRun::Quad;
     r.polls = 0;
@@ -1093,6 +1099,7 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
         if (!quad_sums_read(c, r.seq0, sums)) return fail(c, ICPGPU_ERR_HIP, "the GICP quadratic pass finished without publishing its sums");
       }
       std::atomic_thread_fence(std::memory_order_acquire);
+      c->quad_pending = false;
       const double m = sums[2 * 73], d2 = sums[2 * 74];
       r.mse = m > 0 ? d2 / m : 0.0;
       r.n_corr = (unsigned)m;
@@ -1191,10 +1198,9 @@ int icpgpu_gicp_quadratic_sums(icpgpu_ctx* c, const float* T, double* sums150) {
     if ((rc = nn_keys_brute(c, c->tgt.data(), n_t, Tq, keys))) return rc;
   }
   const unsigned long long seq = ++c->quad_seq;
-  HIP_TRY(c, launch_gicp_quadratic(c->src.data(), n_s, c->tgt.data(), keys, thr_excl, R, static_cast<const double*>(c->cov_src.ptr),
-                                   static_cast<const double*>(c->cov_tgt.ptr), c->quad_partials, c->quad_done, c->h_quad_dev,
-                                   wire_seq(c, seq), c->stream));
+  if ((rc = quad_pass_launch(c, n_s, keys, thr_excl, R, seq))) return rc;
   if ((rc = wait_quad_sums(c, seq, sums150))) return rc;
+  c->quad_pending = false;
   return resolve_cov_timing(c);
 }
 
