@@ -176,3 +176,31 @@ def test_quadratic_batch_runs_equal_single_aligns(built, monkeypatch, threads, r
     assert want[3]["n_corr"] < 4 and not want[3]["converged"], want[3]
     assert not want[6]["converged"] and want[6]["iterations"] == 0, want[6]
     assert not want[-1]["converged"] and want[-1]["iterations"] == 0, want[-1]
+
+
+def test_quadratic_mode_with_the_release_form_mailbox():
+    """ICPGPU_MAILBOX=release (value / system-scope release / tag instead of the self-tagged 16-byte pairs): the 150 numbers of a
+    quadratic pass travel through the same result pairs as every other result -- same bits either way.  Subprocesses: the switch
+    is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from icpslam_amd import Context, GICP, GICP_INNER_QUADRATIC, synth\n"
+        "src, tgt, _ = synth.make_pair(9000, 9500, seed=78)\n"
+        "with Context(0) as ctx:\n"
+        "    ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10, gicp_inner=GICP_INNER_QUADRATIC)\n"
+        "    ctx.set_source(src); ctx.set_target(tgt)\n"
+        "    r = ctx.align(want_fitness=True)\n"
+        "    p = ctx.profile()\n"
+        "print(r['T'].tobytes().hex(), r['iterations'], r['n_corr'], float(r['fitness']).hex(), p.gicp_quadratic_solves)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("pairs", "release"):
+        env = dict(os.environ, ICPGPU_MAILBOX=mode, PYTHONPATH=root)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out[mode] = res.stdout.strip().splitlines()[-1]
+    assert out["pairs"] == out["release"], (out["pairs"][:80], out["release"][:80])
+    assert int(out["pairs"].split()[-1]) > 0
