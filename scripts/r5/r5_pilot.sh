@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 5: pilot sweep A/B (ICPGPU_PILOT = shift; 0 = off), dev flavour, per-sweep kernel time + parity of the search
+# round 5: pilot sweep A/B (ICPGPU_PILOT = shift; 0 = off), dev flavour, per-sweep kernel time + parity of the search.
+# (the kernel variant is NOT kept -- EXPERIMENTS.md, round 5 table: it made the cold sweep slower at every shift; this script is the record of how it was measured)
 TAG=${1:-r5pilot}
 mkdir -p gpurun_out/$TAG
 export ICPGPU_FLAVOUR=dev
