@@ -374,31 +374,6 @@ __global__ __launch_bounds__(256) void gicp_maha_kernel(int n_s, const unsigned 
   if (j == 0xFFFFFFFFu || !(d2 < thr)) return;
   gicp_maha_of(cov_s + (size_t)i * 6, cov_t + (size_t)j * 6, R, maha6 + (size_t)i * 6);
 }
-#if 0
-  const double C1[9] = {a[0], a[1], a[2], a[1], a[3], a[4], a[2], a[4], a[5]};
-  double RC[9], S[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) RC[3 * r + c] = R.m[3 * r] * C1[c] + R.m[3 * r + 1] * C1[3 + c] + R.m[3 * r + 2] * C1[6 + c];
-  const double C2[9] = {b[0], b[1], b[2], b[1], b[3], b[4], b[2], b[4], b[5]};
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      S[3 * r + c] = RC[3 * r] * R.m[3 * c] + RC[3 * r + 1] * R.m[3 * c + 1] + RC[3 * r + 2] * R.m[3 * c + 2] + C2[3 * r + c];
-  // inverse by adjugate; the result of inverting a (numerically) symmetric matrix is stored as its upper triangle
-  const double c00 = S[4] * S[8] - S[5] * S[7], c01 = S[5] * S[6] - S[3] * S[8], c02 = S[3] * S[7] - S[4] * S[6];
-  const double id = 1.0 / (S[0] * c00 + S[1] * c01 + S[2] * c02);
-  double* M = maha6 + (size_t)i * 6;
-  M[0] = c00 * id;
-  M[1] = (S[2] * S[7] - S[1] * S[8]) * id;
-  M[2] = (S[1] * S[5] - S[2] * S[4]) * id;
-  M[3] = (S[0] * S[8] - S[2] * S[6]) * id;
-  M[4] = (S[2] * S[3] - S[0] * S[5]) * id;
-  M[5] = (S[0] * S[4] - S[1] * S[3]) * id;
-}
-#endif
 
 // ---- one BFGS evaluation ---------------------------------------------------------------------------------------
 // terms: 0 = m, 1 = sum r^T M r, 2..4 = sum M r, 5..13 = sum (base p)(M r)^T (row-major), 14 = sum d2 of the NN sweep

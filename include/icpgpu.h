@@ -159,7 +159,8 @@ typedef struct {
   uint64_t voxel_bytes;       /* algorithmic bytes: 16*N in + 16*N_out */
   uint64_t gicp_cov_launches; /* GICP: per-cloud 20-NN covariance passes */
   double gicp_cov_ms;
-  uint64_t gicp_cost_launches; /* GICP: BFGS function/gradient evaluations (one device reduction each) */
+  uint64_t gicp_cost_launches; /* GICP: BFGS function/gradient evaluations (one device reduction each; with gicp_inner = QUADRATIC they
+                               * run on the host, and gicp_eval_ms then holds the passes' and the minimisations' wall time) */
   uint64_t map_inserts;       /* f4: addPointsToMap batches */
   double map_insert_ms;
   uint64_t map_points_in;     /* points offered to the map */
