@@ -13,6 +13,8 @@ the work the C restatement does by hand --
     Mahalanobis       numpy.linalg.inv (LU)                               C: adjugate
     sums              "sequential": numpy.add.accumulate (PCL's order)    C: plain loop
                       "exact": math.fsum (correctly rounded exact sum)    C: three-fold TwoSum expansion
+                      "smooth": exact sums of the objective WITHOUT the float32 rounding of the transformed points (T p in
+                      float64 from the float matrix) -- what the GPU's quadratic inner solver minimises; C: ORC_GICP_SUMS_SMOOTH
 so the two agree to rounding in every intermediate quantity but not bit for bit, and -- BFGS being a chaotic consumer of
 its sums -- their final transforms agree within the BASELINE tolerance (1e-4 in R, 1e-3 m in t), not to the last bit.
 That distance is what tests/test_oracle.py::test_gicp_two_restatements_agree and the fixture
@@ -167,13 +169,24 @@ class _Cost:
     def __init__(self, src, tgt, maha, base, sums):
         self.src, self.tgt, self.maha, self.base, self.m = src, tgt, maha, np.asarray(base, f32), src.shape[0]
         self.pb = transform_f32(src, self.base).astype(np.float64)   # base_transformation_ * p_src (rotation gradient)
-        self.sum = (lambda a: math.fsum(a.tolist())) if sums == "exact" else (lambda a: float(np.add.accumulate(a)[-1]))
+        # "smooth": the objective WITHOUT the float32 rounding of the transformed points (the C oracle's ORC_GICP_SUMS_SMOOTH, the
+        # GPU's quadratic inner solver): T p and base p in float64 from the float matrices, exact sums
+        self.smooth = sums == "smooth"
+        if self.smooth:
+            self.src64 = np.asarray(src, np.float64)[:, :3]
+            b64 = self.base.astype(np.float64)
+            self.pb = self.src64 @ b64[:3, :3].T + b64[:3, 3]
+        self.sum = (lambda a: math.fsum(a.tolist())) if sums in ("exact", "smooth") else (lambda a: float(np.add.accumulate(a)[-1]))
         self.evaluations = 0
 
     def fdf(self, x):
         self.evaluations += 1
         T = apply_state(self.base, x)
-        res = (transform_f32(self.src, T) - self.tgt).astype(np.float64)   # float32 difference, then widened
+        if self.smooth:
+            T64 = np.asarray(T, f32).astype(np.float64)
+            res = self.src64 @ T64[:3, :3].T + T64[:3, 3] - np.asarray(self.tgt, np.float64)[:, :3]
+        else:
+            res = (transform_f32(self.src, T) - self.tgt).astype(np.float64)   # float32 difference, then widened
         M = self.maha
         temp = np.empty_like(res)
         for r in range(3):   # temp = M * res, left to right like the C++ expression
