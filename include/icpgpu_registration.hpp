@@ -306,7 +306,11 @@ class IterativeClosestPoint {
   detail::ContextPtr ctx_holder_;
   icpgpu_ctx* ctx_;
   unsigned long long generation_ = 0;
-  icpgpu_params params_;
+
+ protected:
+  icpgpu_params params_;  // (GeneralizedIterativeClosestPoint sets its solver options here)
+
+ private:
   icpgpu_result result_;
   const CloudT* source_ = nullptr;
   const CloudT* target_ = nullptr;

@@ -6,6 +6,7 @@
 // line 1: converged iterations fitness T[16] width height is_dense        (GICP, object A)
 // line 2: fitness of A asked AFTER object B (point-to-point, swapped clouds) used the context; fitness of B
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <memory>
 #include <vector>
@@ -46,6 +47,7 @@ int main(int argc, char** argv) {
     icp.setTransformationEpsilon(ICP_EPSILON);
     icp.setMaxCorrespondenceDistance(ICP_MAX_CORR_DIST);
     icp.setRANSACIterations(0);
+    if (argc > 6 && std::string(argv[6]) == "quadratic") icp.setQuadraticInnerSolver(true);  // (not a PCL method: icpgpu.h, icpgpu_gicp_inner)
     icp.setInputSource(curr_cloud_);
     icp.setInputTarget(prev_cloud_);
     mock_pcl::PointCloud::Ptr out(new mock_pcl::PointCloud());

@@ -20,11 +20,11 @@ def _build_demo(tmp_path, name="shim_demo"):
     return exe
 
 
-def _run(exe, tmp_path, src, tgt, iters):
+def _run(exe, tmp_path, src, tgt, iters, *extra):
     a, b = tmp_path / "src.bin", tmp_path / "tgt.bin"
     src.tofile(a)
     tgt.tofile(b)
-    return subprocess.run([str(exe), str(a), str(src.shape[0]), str(b), str(tgt.shape[0]), str(iters)],
+    return subprocess.run([str(exe), str(a), str(src.shape[0]), str(b), str(tgt.shape[0]), str(iters), *extra],
                           capture_output=True, text=True)
 
 
@@ -263,3 +263,24 @@ def test_odometer_pipeline_with_the_quadratic_inner_solver(built, tmp_path):
         # (offline, scripts/r5/quadratic_costing.py: PCL's own sums run backwards move a pipeline pair by 0.55 mm in the median, 3.1 mm
         #  at worst; this mode by 0.7-1.1 mm, 3.3-7.8 mm at worst)
         assert np.linalg.norm(T[:3, 3].astype(np.float64) - exact["T"][:3, 3]) <= 1e-2
+
+
+@pytest.mark.gpu
+def test_gicp_shim_quadratic_setter_equals_the_parameter(built, tmp_path):
+    """icp.setQuadraticInnerSolver(true) on the shim's GICP object == icpgpu_params.gicp_inner = QUADRATIC through the C-ABI: the same
+    transform, iteration count and fitness, bit for bit."""
+    from icpslam_amd import GICP, GICP_INNER_QUADRATIC, Context
+    exe = _build_demo(tmp_path, "gicp_shim_demo")
+    src, tgt, _ = synth.make_pair(6000, 6500, seed=3)
+    r = _run(exe, tmp_path, src, tgt, 10, "quadratic")
+    assert r.returncode == 0, r.stderr
+    l1 = r.stdout.strip().splitlines()[0].split()
+    with Context(0) as c:
+        c.set_params(c.default_params(), method=GICP, max_iterations=10, gicp_inner=GICP_INNER_QUADRATIC)
+        c.set_source(src)
+        c.set_target(tgt)
+        ref = c.align(want_fitness=True)
+    T = np.array([float(v) for v in l1[3:19]], np.float32).reshape(4, 4).T
+    assert int(l1[0]) == int(ref["converged"]) and int(l1[1]) == ref["iterations"]
+    assert np.array_equal(T, ref["T"])
+    assert float(l1[2]) == ref["fitness"]
