@@ -84,6 +84,18 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4* __restrict__ pt
   }
 }
 
+// counts[0 .. n_counts) and the statistics words zeroed by ONE launch (two hipMemsetAsync calls before: 4 + 9 us of host time and
+// three fill kernels in front of every count pass -- HIP API trace of a pipeline scan, scripts/r5/r5_api_trace.sh)
+__global__ __launch_bounds__(256) void grid_clear_kernel(int* __restrict__ counts, size_t n_counts, int* __restrict__ stats) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  if (t < (size_t)kGridStatInts) stats[t] = 0;
+  // 16-byte stores over the aligned middle (hipMalloc'd: the base is aligned), single words for the tail
+  const size_t n4 = n_counts >> 2;
+  int4* c4 = reinterpret_cast<int4*>(counts);
+  for (size_t i = t; i < n4; i += stride) c4[i] = make_int4(0, 0, 0, 0);
+  for (size_t i = (n4 << 2) + t; i < n_counts; i += stride) counts[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void grid_count_kernel(const float4* __restrict__ pts, int n, GridDesc g,
                                                          int* __restrict__ cell_of_point, int* __restrict__ rank,
                                                          int* __restrict__ counts) {
@@ -622,10 +634,12 @@ void decode_bbox(const int enc[6], float lo[3], float hi[3]) {
 hipError_t launch_grid_count(const float4* pts, int n, const GridDesc& g, int* cell_of_point, int* rank_in_cell,
                              int* counts, int* block_sums, int* d_stats, hipStream_t stream) {
   const int ncells = g.nx * g.ny * g.nz;
-  hipError_t e = hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), stream);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(d_stats, 0, kGridStatInts * sizeof(int), stream);
-  if (e != hipSuccess) return e;
+  {
+    const size_t n_counts = (size_t)ncells + 1;
+    const size_t want = (n_counts / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(grid_clear_kernel, dim3(blocks), dim3(256), 0, stream, counts, n_counts, d_stats);
+  }
   if (n > 0)
     hipLaunchKernelGGL(grid_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, pts, n, g, cell_of_point,
                        rank_in_cell, counts);
