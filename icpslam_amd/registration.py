@@ -376,3 +376,8 @@ class GeneralizedIterativeClosestPoint(IterativeClosestPoint):
     icp_odometer.cpp:188 and octree_mapper.cpp:104 (plane-to-plane cost, BFGS inner solver, PCL's constructor defaults)."""
 
     METHOD = _lib.GICP
+
+    def setQuadraticInnerSolver(self, on: bool):
+        """NOT a PCL method (the C++ shim has the same one): the inner minimisation on the quadratic form of each outer iteration,
+        icpgpu_params.gicp_inner -- faster, within tolerance of the default's result instead of on its bits (include/icpgpu.h)."""
+        self._params.gicp_inner = _lib.GICP_INNER_QUADRATIC if on else _lib.GICP_INNER_EXACT

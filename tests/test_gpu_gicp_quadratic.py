@@ -204,3 +204,22 @@ def test_quadratic_mode_with_the_release_form_mailbox():
         out[mode] = res.stdout.strip().splitlines()[-1]
     assert out["pairs"] == out["release"], (out["pairs"][:80], out["release"][:80])
     assert int(out["pairs"].split()[-1]) > 0
+
+
+def test_python_mirror_setter_equals_the_parameter(built):
+    """icpslam_amd.GeneralizedIterativeClosestPoint.setQuadraticInnerSolver(True) == params.gicp_inner = QUADRATIC on a Context."""
+    from icpslam_amd import Context, GeneralizedIterativeClosestPoint
+    curr, prev, _ = synth.make_pair(6000, 6200, seed=62)
+    a = GeneralizedIterativeClosestPoint()
+    a.setMaximumIterations(10); a.setTransformationEpsilon(1e-6); a.setMaxCorrespondenceDistance(1.0)
+    a.setQuadraticInnerSolver(True)
+    a.setInputSource(curr); a.setInputTarget(prev)
+    a.align()
+    with Context(0) as c:
+        c.set_params(c.default_params(), method=GICP, max_iterations=10, gicp_inner=GICP_INNER_QUADRATIC)
+        c.set_source(curr)
+        c.set_target(prev)
+        ref = c.align(want_fitness=True)
+    assert a.hasConverged() == bool(ref["converged"]) and a.result["iterations"] == ref["iterations"]
+    assert np.array_equal(a.getFinalTransformation(), ref["T"])
+    assert a.getFitnessScore() == ref["fitness"]
