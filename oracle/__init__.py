@@ -92,6 +92,8 @@ def lib():
         L.orc_map_points.restype = fp
         L.orc_map_add_points.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
         L.orc_map_add_points.restype = C.c_long
+        L.orc_map_add_points_sequential.argtypes = [C.c_void_p, fp, C.c_size_t, fp]
+        L.orc_map_add_points_sequential.restype = C.c_long
         L.orc_map_nn_cloud.argtypes = [C.c_void_p, fp, C.c_size_t, fp, fp, fp]
         L.orc_map_nn_cloud.restype = C.c_long
         _lib = L
@@ -248,12 +250,14 @@ class VoxelMap:
     def __len__(self) -> int:
         return int(self._L.orc_map_size(self._h))
 
-    def add_points(self, cloud, pose=None) -> int:
+    def add_points(self, cloud, pose=None, sequential: bool = False) -> int:
+        """sequential=True: the reference's loop as written (O(map) per insertion); default: the batch form of the same rule."""
         cloud, pc = _f32(cloud)
         g = None
         if pose is not None:
             gc, g = _f32(_colmajor(pose))
-        n = self._L.orc_map_add_points(self._h, pc, cloud.shape[0], g)
+        add = self._L.orc_map_add_points_sequential if sequential else self._L.orc_map_add_points
+        n = add(self._h, pc, cloud.shape[0], g)
         if n < 0:
             raise MemoryError("orc_map_add_points")
         return int(n)

@@ -14,7 +14,11 @@
  * octree side lengths afterwards, so the lattice never moves).  Until round 4 this file stopped at p - resolution / 2.  The nearest-neighbour query is EXACT (orc_nn), where PCL's approxNearestSearch is a
  * heuristic descent -- SURVEY.md 8(f4) asks for the exact one.
  *
- * The voxel set is a sorted array + binary search rebuilt per batch: deliberately nothing like the GPU's hash set.
+ * The voxel set is a sorted array + binary search: deliberately nothing like the GPU's hash set.  Two forms of addPointsToMap:
+ * orc_map_add_points_sequential is the reference's loop as written (one point at a time, O(map) per insertion: fine to ~100k
+ * map points); orc_map_add_points states the same rule per batch -- a point is appended iff its voxel is not in the map before
+ * the call AND no earlier point of the call has it -- with one sort of the batch's (voxel, index) pairs, so that a 1M-point map
+ * (BASELINE config 3's scale) takes seconds.  tests/test_map_oracle.py holds the two against each other.
  */
 #include <math.h>
 #include <stdlib.h>
@@ -95,7 +99,7 @@ static long find_key(const int64_t* keys, size_t n, int64_t k) { /* position of 
 }
 
 /* addPointsToMap(transformCloudToPoseFrame(cloud, pose)); returns the number of points appended, -1 on allocation failure */
-long orc_map_add_points(orc_map* m, const float* in_xyzw, size_t n, const float pose[16]) {
+long orc_map_add_points_sequential(orc_map* m, const float* in_xyzw, size_t n, const float pose[16]) {
   float* moved = (float*)malloc((n ? n : 1) * 4 * sizeof(float));
   if (!moved) return -1;
   if (pose) orc_transform_cloud(in_xyzw, n, pose, moved);
@@ -136,6 +140,90 @@ long orc_map_add_points(orc_map* m, const float* in_xyzw, size_t n, const float 
   }
   free(moved);
   return added;
+}
+
+/* the same rule, batch form (see the header comment) */
+typedef struct { int64_t key; size_t i; } orc_key_idx;
+static int cmp_key_idx(const void* a, const void* b) {
+  const orc_key_idx *x = (const orc_key_idx*)a, *y = (const orc_key_idx*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+}
+static int cmp_size_t(const void* a, const void* b) {
+  const size_t x = *(const size_t*)a, y = *(const size_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+long orc_map_add_points(orc_map* m, const float* in_xyzw, size_t n, const float pose[16]) {
+  float* moved = (float*)malloc((n ? n : 1) * 4 * sizeof(float));
+  orc_key_idx* ki = (orc_key_idx*)malloc((n ? n : 1) * sizeof(orc_key_idx));
+  size_t* first = (size_t*)malloc((n ? n : 1) * sizeof(size_t));
+  if (!moved || !ki || !first) {
+    free(moved);
+    free(ki);
+    free(first);
+    return -1;
+  }
+  if (pose) orc_transform_cloud(in_xyzw, n, pose, moved);
+  else {
+    memcpy(moved, in_xyzw, n * 4 * sizeof(float));
+    for (size_t i = 0; i < n; ++i) moved[4 * i + 3] = 1.0f;
+  }
+  size_t nk = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = moved + 4 * i;
+    if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+    if (!m->anchored) {
+      orc_octree_first_box(p, m->res, &m->ox, &m->oy, &m->oz);
+      m->anchored = 1;
+    }
+    int64_t key;
+    if (!point_key(m, p, &key)) continue;
+    ki[nk].key = key;
+    ki[nk].i = i;
+    nk++;
+  }
+  qsort(ki, nk, sizeof(orc_key_idx), cmp_key_idx);
+  /* the first point (lowest index) of every voxel the map does not hold yet */
+  size_t nf = 0;
+  for (size_t a = 0; a < nk; ++a) {
+    if (a && ki[a].key == ki[a - 1].key) continue;
+    if (find_key(m->keys, m->n, ki[a].key) >= 0) continue; /* isVoxelOccupiedAtPoint */
+    first[nf] = ki[a].i;
+    ki[nf].key = ki[a].key; /* (nf <= a: the new voxels' keys, ascending, compacted to the front of ki) */
+    nf++;
+  }
+  qsort(first, nf, sizeof(size_t), cmp_size_t); /* map_cloud_ keeps insertion order */
+  const size_t total = m->n + nf;
+  if (total > m->cap) {
+    size_t cap = m->cap ? m->cap : 4096;
+    while (cap < total) cap *= 2;
+    float* np_ = (float*)realloc(m->pts, cap * 4 * sizeof(float));
+    if (np_) m->pts = np_;
+    int64_t* nkeys = (int64_t*)realloc(m->keys, cap * sizeof(int64_t));
+    if (nkeys) m->keys = nkeys;
+    if (!np_ || !nkeys) {
+      free(moved);
+      free(ki);
+      free(first);
+      return -1;
+    }
+    m->cap = cap;
+  }
+  for (size_t a = 0; a < nf; ++a) memcpy(m->pts + 4 * (m->n + a), moved + 4 * first[a], 4 * sizeof(float));
+  /* merge the new voxels' keys (ki[0 .. nf), ascending) into the sorted key array, from the back */
+  {
+    size_t w = total, o = m->n;
+    for (size_t a = nf; a-- > 0;) {
+      while (o > 0 && m->keys[o - 1] > ki[a].key) m->keys[--w] = m->keys[--o];
+      m->keys[--w] = ki[a].key;
+    }
+  }
+  m->n = total;
+  free(moved);
+  free(ki);
+  free(first);
+  return (long)nf;
 }
 
 /* nn cloud of `cloud` seen from `pose`, moved back by pose_inv: out must hold n points; returns the number written */

@@ -114,3 +114,28 @@ def test_pcl_approx_nearest_search_restatement_and_the_deviation_it_quantifies()
     share = float((ia != ie).mean())
     assert 0.15 <= share <= 0.7, share
     assert da.mean() > de.mean() * 1.05
+
+
+def test_batch_form_equals_the_sequential_loop():
+    """oracle/map_oracle.c holds addPointsToMap twice: the reference's loop as written (orc_map_add_points_sequential) and the
+    same rule per batch with one sort (what the GPU tests at a 1M-point map use).  Same counts, same map, bit for bit -- over
+    several batches, duplicates, non-finite points, sheets and clumps."""
+    for seed in range(8):
+        rng = np.random.default_rng(700 + seed)
+        res = float(rng.choice([0.05, 0.3, 0.5, 2.0]))
+        a, b = oracle.VoxelMap(res), oracle.VoxelMap(res)
+        for k in range(int(rng.integers(2, 5))):
+            n = int(rng.integers(1, 20000))
+            p = rng.uniform(-20, 20, (n, 3))
+            if k % 2:
+                p[:, 2] = rng.normal(0.0, 0.02, n)
+            cloud = np.ones((n, 4), np.float32)
+            cloud[:, :3] = p.astype(np.float32)
+            cloud[rng.integers(0, n, 3), :3] = np.nan
+            cloud[n // 2: n // 2 + 10] = cloud[n // 2]
+            pose = synth.pose_matrix(*rng.uniform(-3, 3, 3), *rng.uniform(-0.3, 0.3, 3)) if k else None
+            assert a.add_points(cloud, pose) == b.add_points(cloud, pose, sequential=True)
+        assert len(a) == len(b) and np.array_equal(a.points().view(np.uint32), b.points().view(np.uint32))
+        q, _, _ = synth.make_pair(500, 10, seed=seed)
+        I = np.eye(4, dtype=np.float32)
+        assert np.array_equal(a.nn_cloud(q, I, I), b.nn_cloud(q, I, I))     # (the sorted key arrays agree as well)
