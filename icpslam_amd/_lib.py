@@ -17,6 +17,8 @@ if os.environ.get("ICPGPU_LIB_PATH"):   # A/B builds of an experiment (scripts/)
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_NO_INPUT, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 P2P_SVD, GICP = 0, 1
 GICP_INNER_EXACT, GICP_INNER_QUADRATIC = 0, 1
+GICP_SOLVER_NONE, GICP_SOLVER_HOST, GICP_SOLVER_DEVICE, GICP_SOLVER_QUADRATIC = 0, 1, 2, 3
+HEADER_VERSION = 1000          # the icpgpu.h these mirrors were written against (ICPGPU_HEADER_VERSION)
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 STATE_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
                5: "NO_CORRESPONDENCES"}
@@ -32,7 +34,8 @@ class Params(C.Structure):
 class Result(C.Structure):
     _fields_ = [("T", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32),
                 ("convergence_state", C.c_int32), ("n_correspondences", C.c_uint32), ("mse_last", C.c_double),
-                ("fitness", C.c_double), ("t_total_ms", C.c_double), ("t_device_ms", C.c_double)]
+                ("fitness", C.c_double), ("t_total_ms", C.c_double), ("t_device_ms", C.c_double),
+                ("gicp_solver", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -60,10 +63,10 @@ class Pose(C.Structure):
 
 # every symbol include/icpgpu.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
-    "icpgpu_create", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params",
-    "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
+    "icpgpu_create_abi", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params_sz", "icpgpu_struct_sizes",
+    "icpgpu_calibrate", "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
     "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
-    "icpgpu_fingerprint", "icpgpu_cloud_sizes", "icpgpu_align_batch_multi", "icpgpu_multi_last_error",
+    "icpgpu_fingerprint", "icpgpu_cloud_sizes", "icpgpu_align_batch_multi_sz", "icpgpu_multi_last_error",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_profile_set_sampling", "icpgpu_get_stream", "icpgpu_synchronize",
     "icpgpu_voxel_grid", "icpgpu_voxel_grid_fetch", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
@@ -100,13 +103,16 @@ def load():
         pass
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, fp, dp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
-    L.icpgpu_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.icpgpu_create_abi.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.icpgpu_struct_sizes.argtypes = [C.POINTER(C.c_size_t)]
+    L.icpgpu_struct_sizes.restype = None
+    L.icpgpu_calibrate.argtypes = [vp, C.POINTER(C.c_int)]
     L.icpgpu_destroy.argtypes = [vp]
     L.icpgpu_last_error.argtypes = [vp]
     L.icpgpu_last_error.restype = C.c_char_p
     L.icpgpu_version.argtypes = []
-    L.icpgpu_default_params.argtypes = [C.POINTER(Params)]
-    L.icpgpu_default_params.restype = None
+    L.icpgpu_default_params_sz.argtypes = [C.POINTER(Params), C.c_size_t]
+    L.icpgpu_default_params_sz.restype = None
     L.icpgpu_set_params.argtypes = [vp, C.POINTER(Params)]
     L.icpgpu_get_params.argtypes = [vp, C.POINTER(Params)]
     L.icpgpu_set_source.argtypes = [vp, fp, C.c_size_t]
@@ -121,9 +127,9 @@ def load():
     L.icpgpu_fitness.argtypes = [vp, C.c_double, dp]
     L.icpgpu_align_batch.argtypes = [vp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp),
                                      C.POINTER(C.c_size_t), C.c_int, C.POINTER(Result)]
-    L.icpgpu_align_batch_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(Params), C.c_size_t, C.POINTER(fp),
-                                           C.POINTER(C.c_size_t), C.POINTER(fp), C.POINTER(C.c_size_t), C.c_int,
-                                           C.POINTER(Result), dp, C.c_int]
+    L.icpgpu_align_batch_multi_sz.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(Params), C.c_size_t, C.POINTER(fp),
+                                              C.POINTER(C.c_size_t), C.POINTER(fp), C.POINTER(C.c_size_t), C.c_int,
+                                              C.POINTER(Result), dp, C.c_int, C.c_size_t, C.c_size_t]
     L.icpgpu_multi_last_error.argtypes = []
     L.icpgpu_multi_last_error.restype = C.c_char_p
     L.icpgpu_nn.argtypes = [vp, fp, ip, fp]
@@ -170,7 +176,13 @@ def load():
         fn = getattr(L, name)
         if name in ("icpgpu_posegraph_num_poses", "icpgpu_posegraph_num_keyframes"):
             fn.restype = C.c_long
-        elif name not in ("icpgpu_last_error", "icpgpu_default_params", "icpgpu_fingerprint", "icpgpu_multi_last_error"):
+        elif name not in ("icpgpu_last_error", "icpgpu_default_params_sz", "icpgpu_struct_sizes", "icpgpu_fingerprint", "icpgpu_multi_last_error"):
             fn.restype = C.c_int
+    # The three names icpgpu.h defines as MACROS over the sized entry points (include/icpgpu.h, "ABI rule"): the same spelling here,
+    # with THESE mirrors' sizes -- a library whose structs have grown copies only what the mirrors hold.
+    sizes = (C.sizeof(Params), C.sizeof(Result), C.sizeof(Profile))
+    L.icpgpu_create = lambda out, device: L.icpgpu_create_abi(out, device, HEADER_VERSION, *sizes)
+    L.icpgpu_default_params = lambda p: L.icpgpu_default_params_sz(p, sizes[0])
+    L.icpgpu_align_batch_multi = lambda *a: L.icpgpu_align_batch_multi_sz(*a, sizes[0], sizes[1])
     _lib = L
     return L

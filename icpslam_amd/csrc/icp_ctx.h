@@ -173,6 +173,10 @@ constexpr size_t kMaxServerWorkers = 8;
 // 1 200 campaign registrations through both).  Which one is faster depends on the box: the host loop's evaluation is 6.8-8.3 us
 // with the box's PCIe and CPU, the kernel's 7.2-7.7 us wherever it runs (EXPERIMENTS.md section 9-f1) -- so a context times a few
 // outer iterations each way (align_gicp) and keeps the faster; runs the one-XCD variant cannot take stay on the host.
+// sizes of the public structs in icpgpu.h 1.0: the shortest a caller of this major version can hand over (icpgpu_create_abi)
+constexpr size_t kAbiParams10 = 56, kAbiResult10 = 120, kAbiProfile10 = 360;
+static_assert(sizeof(icpgpu_params) >= kAbiParams10 && sizeof(icpgpu_result) >= kAbiResult10 && sizeof(icpgpu_profile) >= kAbiProfile10,
+              "public structs only grow (include/icpgpu.h, ABI rule)");
 inline int gicp_device_solver_mode() {  // 0 host, 1 device, 2 measured
   static const int v = [] {
     const char* e = std::getenv("ICPGPU_GICP_DEVICE");
@@ -254,7 +258,9 @@ struct icpgpu_ctx {
                               // died half-way would leave it mid-count)
   // measured mode: 0 = still timing both solvers, 1 = host, 2 = device; microseconds and evaluations of the timed inner
   // minimisations, [0] host [1] device (the first run of each is a warm-up and not counted)
-  int gicp_choice = 0;
+  int gicp_choice = 0;            // (set at creation since 1.0: 1 host / 2 device; 0 only while icpgpu_calibrate is timing both)
+  // what the CALLER's header says the three public structs measure (icpgpu_create_abi; include/icpgpu.h "ABI rule")
+  size_t abi_params = sizeof(icpgpu_params), abi_result = sizeof(icpgpu_result), abi_profile = sizeof(icpgpu_profile);
   double gicp_cal_us[2] = {0.0, 0.0};
   unsigned long long gicp_cal_evals[2] = {0, 0};
   unsigned int gicp_cal_runs[2] = {0, 0};

@@ -37,6 +37,8 @@ namespace {
 
 constexpr int kRecordLen = 23;  // pair_id, iterations, converged, state, n_corr, mse, fitness, T[16] row-major (sharding.py)
 
+constexpr size_t kAbiParams10 = 56, kAbiResult10 = 120;  // sizes of the public structs in icpgpu.h 1.0 (icp_ctx.h holds the same constants)
+
 thread_local std::string g_multi_error;
 int multi_fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -147,9 +149,41 @@ extern "C" {
 
 const char* icpgpu_multi_last_error(void) { return g_multi_error.c_str(); }
 
-int icpgpu_align_batch_multi(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
-                             const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
-                             int want_fitness, icpgpu_result* results, double* records, int communicator) {
+static int align_batch_multi_impl(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
+                                  const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
+                                  int want_fitness, icpgpu_result* results, double* records, int communicator);
+
+// the caller's structs may be shorter or longer than the library's (include/icpgpu.h, ABI rule): parameters are completed with the
+// defaults, results are written with the caller's stride
+int icpgpu_align_batch_multi_sz(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
+                                const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
+                                int want_fitness, icpgpu_result* results, double* records, int communicator, size_t sizeof_params,
+                                size_t sizeof_result) {
+  g_multi_error.clear();
+  if (sizeof_params < kAbiParams10 || sizeof_result < kAbiResult10 || sizeof_params > 4096 || sizeof_result > 4096)
+    return multi_fail(ICPGPU_ERR_INVALID_ARG, "struct sizes %zu / %zu are not those of an icpgpu.h 1.x", sizeof_params, sizeof_result);
+  icpgpu_params full;
+  if (params) {
+    icpgpu_default_params(&full);
+    std::memcpy(&full, params, std::min(sizeof_params, sizeof(full)));
+  }
+  if (sizeof_result == sizeof(icpgpu_result) || !results)
+    return align_batch_multi_impl(devices, n_devices, params ? &full : nullptr, n_pairs, src, n_src, tgt, n_tgt, want_fitness, results, records,
+                                  communicator);
+  std::vector<icpgpu_result> own(n_pairs);
+  const int rc = align_batch_multi_impl(devices, n_devices, params ? &full : nullptr, n_pairs, src, n_src, tgt, n_tgt, want_fitness, own.data(),
+                                        records, communicator);
+  unsigned char* out = reinterpret_cast<unsigned char*>(results);
+  for (size_t k = 0; k < n_pairs; ++k) {
+    std::memset(out + k * sizeof_result, 0, sizeof_result);
+    std::memcpy(out + k * sizeof_result, &own[k], std::min(sizeof_result, sizeof(icpgpu_result)));
+  }
+  return rc;
+}
+
+static int align_batch_multi_impl(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
+                                  const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
+                                  int want_fitness, icpgpu_result* results, double* records, int communicator) {
   g_multi_error.clear();
   if (!devices || n_devices < 1 || n_devices > 64) return multi_fail(ICPGPU_ERR_INVALID_ARG, "bad device list");
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return multi_fail(ICPGPU_ERR_INVALID_ARG, "null argument");

@@ -102,11 +102,28 @@ static size_t batch_threads(const icpgpu_ctx* c, size_t cap) {
 // T x K = 8 alignments in flight (a 50k-point sweep fills less than half of the chip), T from the CPUs this process may
 // use: 4 x 2 on an unshared 16-CPU box, 2 x 4 when eight ranks share it.  GICP: one alignment per thread (its BFGS loop is
 // a blocking host loop), T threads.  Every pair is solved exactly as icpgpu_align would solve it.
+static int align_batch_impl(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src, const float* const* tgt,
+                            const size_t* n_tgt, int want_fitness, icpgpu_result* results);
+
 int icpgpu_align_batch(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src,
                        const float* const* tgt, const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
   ENTER(c);
   if (n_pairs && (!src || !n_src || !tgt || !n_tgt || !results)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
   if (n_pairs == 0) return ICPGPU_OK;
+  if (c->abi_result == sizeof(icpgpu_result)) return align_batch_impl(c, n_pairs, src, n_src, tgt, n_tgt, want_fitness, results);
+  // the caller's icpgpu_result has another length (include/icpgpu.h, ABI rule): its array has ITS stride
+  std::vector<icpgpu_result> own(n_pairs);
+  const int rc = align_batch_impl(c, n_pairs, src, n_src, tgt, n_tgt, want_fitness, own.data());
+  unsigned char* out = reinterpret_cast<unsigned char*>(results);
+  for (size_t k = 0; k < n_pairs; ++k) {
+    std::memset(out + k * c->abi_result, 0, c->abi_result);
+    std::memcpy(out + k * c->abi_result, &own[k], std::min(c->abi_result, sizeof(icpgpu_result)));
+  }
+  return rc;
+}
+
+static int align_batch_impl(icpgpu_ctx* c, size_t n_pairs, const float* const* src, const size_t* n_src, const float* const* tgt,
+                            const size_t* n_tgt, int want_fitness, icpgpu_result* results) {
   const bool gicp = c->params.method == ICPGPU_GICP;
   // Point-to-point batches run in LOCK-STEP (ICPGPU_BATCH_LOCKSTEP=0: the round-robin scheduler of round 2): a host thread
   // leads a group of `depth` pairs on ONE stream -- their index builds go through their host round trips together, and

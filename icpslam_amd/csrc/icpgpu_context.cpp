@@ -321,8 +321,8 @@ extern "C" {
 
 int icpgpu_version(void) { return ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR; }
 
-void icpgpu_default_params(icpgpu_params* p) {
-  if (!p) return;
+// the library's own defaults
+static void default_params_full(icpgpu_params* p) {
   std::memset(p, 0, sizeof(*p));
   p->method = ICPGPU_P2P_SVD;
   p->max_iterations = 10;                    // icp_odometer.h:65
@@ -336,7 +336,40 @@ void icpgpu_default_params(icpgpu_params* p) {
   p->gicp_inner = ICPGPU_GICP_INNER_EXACT;
 }
 
-int icpgpu_create(icpgpu_ctx** out_ctx, int device_id) { return create_context(out_ctx, device_id, /*with_stream=*/true); }
+// ABI rule of include/icpgpu.h: the caller's struct may be shorter (an older header) or longer (a newer one) than the library's
+void icpgpu_default_params_sz(icpgpu_params* p, size_t sizeof_params) {
+  if (!p || sizeof_params == 0) return;
+  icpgpu_params full;
+  default_params_full(&full);
+  std::memset(p, 0, sizeof_params);
+  std::memcpy(p, &full, std::min(sizeof_params, sizeof(full)));
+}
+
+void icpgpu_struct_sizes(size_t out3[3]) {
+  if (!out3) return;
+  out3[0] = sizeof(icpgpu_params);
+  out3[1] = sizeof(icpgpu_result);
+  out3[2] = sizeof(icpgpu_profile);
+}
+
+int icpgpu_create_abi(icpgpu_ctx** out_ctx, int device_id, int header_version, size_t sizeof_params, size_t sizeof_result,
+                      size_t sizeof_profile) {
+  if (out_ctx) *out_ctx = nullptr;
+  if (header_version / 1000 != ICPGPU_VERSION_MAJOR)
+    return fail(nullptr, ICPGPU_ERR_UNSUPPORTED, "the caller was built against icpgpu.h %d.%d, this library is %d.%d: another major version",
+                header_version / 1000, header_version % 1000, ICPGPU_VERSION_MAJOR, ICPGPU_VERSION_MINOR);
+  // 1.0's structs are the shortest a caller of this major version can have
+  if (sizeof_params < kAbiParams10 || sizeof_result < kAbiResult10 || sizeof_profile < kAbiProfile10 || sizeof_params > 4096 ||
+      sizeof_result > 4096 || sizeof_profile > 65536)
+    return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "struct sizes %zu / %zu / %zu are not those of an icpgpu.h 1.x (at least %zu / %zu / %zu)",
+                sizeof_params, sizeof_result, sizeof_profile, kAbiParams10, kAbiResult10, kAbiProfile10);
+  const int rc = create_context(out_ctx, device_id, /*with_stream=*/true);
+  if (rc != ICPGPU_OK) return rc;
+  (*out_ctx)->abi_params = sizeof_params;
+  (*out_ctx)->abi_result = sizeof_result;
+  (*out_ctx)->abi_profile = sizeof_profile;
+  return ICPGPU_OK;
+}
 
 }  // extern "C"
 
@@ -399,7 +432,8 @@ int create_context(icpgpu_ctx** out_ctx, int device_id, bool with_stream) {
   if (!c) return fail(nullptr, ICPGPU_ERR_OOM, "out of host memory");
   c->device = device_id;
   c->num_cus = cus;
-  icpgpu_default_params(&c->params);
+  default_params_full(&c->params);
+  c->gicp_choice = gicp_device_solver_mode() == 1 ? 2 : 1;  // auto: the host loop for single alignments (include/icpgpu.h, ICPGPU_GICP_DEVICE)
   if (const char* v = ICPGPU_DEV_ENV("ICPGPU_NN_VARIANT")) c->nn_variant = std::atoi(v);
 
   auto bail = [&](const char* what, hipError_t err) {
@@ -597,20 +631,25 @@ int icpgpu_destroy(icpgpu_ctx* c) {
 
 const char* icpgpu_last_error(const icpgpu_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
-int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* p) {
-  if (!c || !p) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+int icpgpu_set_params(icpgpu_ctx* c, const icpgpu_params* user) {
+  if (!c || !user) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  icpgpu_params full;  // fields the caller's (older) header does not have keep their defaults; fields of a newer header are ignored
+  default_params_full(&full);
+  std::memcpy(&full, user, std::min(c->abi_params, sizeof(full)));
+  const icpgpu_params* p = &full;
   if (p->method != ICPGPU_P2P_SVD && p->method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad method");
   if (p->nn_mode < ICPGPU_NN_AUTO || p->nn_mode > ICPGPU_NN_GRID) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad nn_mode");
   if (p->brute_variant < 0 || p->brute_variant > 2) return fail(c, ICPGPU_ERR_INVALID_ARG, "bad brute_variant");
   if (p->gicp_inner != ICPGPU_GICP_INNER_EXACT && p->gicp_inner != ICPGPU_GICP_INNER_QUADRATIC)
-    return fail(c, ICPGPU_ERR_INVALID_ARG, "bad gicp_inner (a caller built against icpgpu.h < 0.4 passes a shorter icpgpu_params)");
+    return fail(c, ICPGPU_ERR_INVALID_ARG, "bad gicp_inner");
   c->params = *p;
   return ICPGPU_OK;
 }
 
 int icpgpu_get_params(const icpgpu_ctx* c, icpgpu_params* p) {
   if (!c || !p) return ICPGPU_ERR_INVALID_ARG;
-  *p = c->params;
+  std::memset(p, 0, c->abi_params);
+  std::memcpy(p, &c->params, std::min(c->abi_params, sizeof(c->params)));
   return ICPGPU_OK;
 }
 
@@ -865,11 +904,11 @@ int icpgpu_profile_get(icpgpu_ctx* c, icpgpu_profile* out) {
   int rc = resolve_sweep_timings(c);
   if (rc) return rc;
   if ((rc = resolve_cov_timing(c))) return rc;
-  // which inner solver this context's GICP alignments run on (icpgpu_gicp.cpp): forced modes answer at once, the measured mode
-  // once its timing has settled
-  const int mode = gicp_device_solver_mode();
-  c->prof.gicp_solver_choice = mode == 2 ? (uint64_t)c->gicp_choice : (mode == 1 && c->gicp_device_ok ? 2u : 1u);
-  *out = c->prof;
+  // which inner solver this context's single GICP alignments run on (icpgpu_gicp.cpp): fixed at creation, changed by icpgpu_calibrate
+  // only; a device solver that gave up on this context (a gather timed out) reads as the host loop
+  c->prof.gicp_solver_choice = (c->gicp_choice == 2 && c->gicp_resources_ready && !c->gicp_device_ok) ? 1u : (uint64_t)c->gicp_choice;
+  std::memset(out, 0, c->abi_profile);
+  std::memcpy(out, &c->prof, std::min(c->abi_profile, sizeof(c->prof)));
   return ICPGPU_OK;
 }
 

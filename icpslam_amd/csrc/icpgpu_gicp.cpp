@@ -571,6 +571,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       const GicpSolve sr = gicp_minimize_quadratic(sums, guess, x, 20, 1e-2, &evals);
       mark(4);
       c->prof.gicp_quadratic_solves += 1;
+      res->gicp_solver = ICPGPU_GICP_SOLVER_QUADRATIC;
       c->prof.gicp_cost_launches += (uint64_t)evals;
       c->prof.gicp_eval_corr += (uint64_t)(m * evals);
       c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_q0).count();
@@ -623,6 +624,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       } else {
         solved = true;
         c->prof.gicp_device_solves += 1;
+        res->gicp_solver = ICPGPU_GICP_SOLVER_DEVICE;
         const double m = out[7], evals = out[10];
         m_count = m;
         mse = m > 0 ? out[8] / m : 0.0;
@@ -663,6 +665,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
       }
       const GicpSolve sr = gicp_minimize(eval, x, 20, 1e-2, &probe);
       c->prof.gicp_host_solves += 1;
+      res->gicp_solver = ICPGPU_GICP_SOLVER_HOST;
       mark(4);
       gicp_server_stop(c);
       mark(5);
@@ -1046,6 +1049,7 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
         return gicp_run_restart_blocking(c, r) ? -1 : 1;
       }
       c->prof.gicp_device_solves += 1;
+      r.res->gicp_solver = ICPGPU_GICP_SOLVER_DEVICE;
       const double m = out[7], evals = out[10];
 #if defined(ICPGPU_DEV_SWITCHES)
       {  // development flavour, ICPGPU_BATCH_TRACE=1: where the device solver's microseconds go with several runs in flight
@@ -1113,6 +1117,7 @@ int gicp_run_step(icpgpu_ctx* c, GicpRun& r) {
       int evals = 0;
       const GicpSolve sr = gicp_minimize_quadratic(sums, r.guess, x, 20, 1e-2, &evals);
       c->prof.gicp_quadratic_solves += 1;
+      r.res->gicp_solver = ICPGPU_GICP_SOLVER_QUADRATIC;
       c->prof.gicp_cost_launches += (uint64_t)evals;
       c->prof.gicp_eval_corr += (uint64_t)(m * evals);
       c->prof.gicp_eval_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t_issue).count();

@@ -509,12 +509,41 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
 
 extern "C" {
 
-int icpgpu_align(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res) {
+int icpgpu_align(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* user_res) {
   ENTER(c);
-  if (!res) return fail(c, ICPGPU_ERR_INVALID_ARG, "result is null");
+  if (!user_res) return fail(c, ICPGPU_ERR_INVALID_ARG, "result is null");
   if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "align: source and target must be set first");
-  if (c->params.method == ICPGPU_GICP) return align_gicp(c, guess, out_xyzw, want_fitness, res);
-  return align_p2p(c, guess, out_xyzw, want_fitness, res);
+  // a caller whose icpgpu_result is not this library's (include/icpgpu.h, ABI rule) gets the leading bytes it knows
+  icpgpu_result own;
+  icpgpu_result* res = c->abi_result == sizeof(icpgpu_result) ? user_res : &own;
+  const int rc = c->params.method == ICPGPU_GICP ? align_gicp(c, guess, out_xyzw, want_fitness, res) : align_p2p(c, guess, out_xyzw, want_fitness, res);
+  if (res != user_res) {
+    std::memset(user_res, 0, c->abi_result);
+    std::memcpy(user_res, res, std::min(c->abi_result, sizeof(own)));
+  }
+  return rc;
+}
+
+// ICPGPU_GICP_DEVICE=auto: time both inner solvers of GICP on the clouds the context holds (align_gicp alternates and times while
+// gicp_choice is 0) and keep the faster; see include/icpgpu.h
+int icpgpu_calibrate(icpgpu_ctx* c, int* choice) {
+  ENTER(c);
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "calibrate: source and target must be set first");
+  if (c->params.method != ICPGPU_GICP) return fail(c, ICPGPU_ERR_INVALID_ARG, "calibrate: the context's method is not GICP");
+  if (gicp_device_solver_mode() == 2 && !gicp_inner_quadratic(c)) {
+    const int before = c->gicp_choice;
+    c->gicp_choice = 0;
+    c->gicp_cal_us[0] = c->gicp_cal_us[1] = 0.0;
+    c->gicp_cal_evals[0] = c->gicp_cal_evals[1] = 0;
+    c->gicp_cal_runs[0] = c->gicp_cal_runs[1] = 0;
+    icpgpu_result scratch;
+    int rc = ICPGPU_OK;
+    for (int k = 0; k < 12 && c->gicp_choice == 0 && rc == ICPGPU_OK; ++k) rc = align_gicp(c, nullptr, nullptr, 0, &scratch);
+    if (c->gicp_choice == 0) c->gicp_choice = before;  // too few evaluations to tell (tiny clouds, runs the device solver cannot take)
+    if (rc != ICPGPU_OK) return rc;
+  }
+  if (choice) *choice = c->gicp_choice == 2 && c->gicp_device_ok ? ICPGPU_GICP_SOLVER_DEVICE : ICPGPU_GICP_SOLVER_HOST;
+  return ICPGPU_OK;
 }
 
 int icpgpu_fitness(icpgpu_ctx* c, double max_range, double* out) {

@@ -255,6 +255,12 @@ class Context:
         return self.n_source
 
     # measurement -----------------------------------------------------------------------------------------------
+    def calibrate(self) -> int:
+        """icpgpu_calibrate: time GICP's two inner solvers on the clouds this context holds and keep the faster (GICP_SOLVER_*)."""
+        v = C.c_int()
+        self._check(self._L.icpgpu_calibrate(self._h, C.byref(v)))
+        return int(v.value)
+
     def profile_reset(self):
         self._check(self._L.icpgpu_profile_reset(self._h))
 
@@ -284,7 +290,7 @@ def result_dict(res: Result, cloud):
     return dict(T=np.array(res.T, dtype=np.float32).reshape(4, 4).T.copy(), converged=bool(res.converged),
                 iterations=int(res.iterations), state=int(res.convergence_state), n_corr=int(res.n_correspondences),
                 mse=float(res.mse_last), fitness=float(res.fitness), cloud=cloud, t_total_ms=float(res.t_total_ms),
-                t_device_ms=float(res.t_device_ms))
+                t_device_ms=float(res.t_device_ms), gicp_solver=int(res.gicp_solver))
 
 
 class IterativeClosestPoint:

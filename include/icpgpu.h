@@ -36,10 +36,19 @@
 extern "C" {
 #endif
 
-#define ICPGPU_VERSION_MAJOR 0
-#define ICPGPU_VERSION_MINOR 4 /* 0.4: icpgpu_params.gicp_inner, icpgpu_profile.gicp_quadratic_solves; 0.3: icpgpu_profile grew
-                                * (sources_adopted, gicp_host_solves, gicp_solver_choice); a caller built against an older header
-                                * passes smaller structs -- compare icpgpu_version() first */
+#define ICPGPU_VERSION_MAJOR 1
+#define ICPGPU_VERSION_MINOR 0
+#define ICPGPU_HEADER_VERSION (ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR)
+/* ABI rule (1.0).  icpgpu_params, icpgpu_result and icpgpu_profile only ever GROW AT THE END, and the library never assumes the
+ * caller's structs are as long as its own: the caller's sizeof of the three travels with icpgpu_create (the macro below hands them
+ * to icpgpu_create_abi) and every entry point that reads or writes one of them through that context copies min(caller's, library's)
+ * bytes -- fields the caller does not know are not written, fields the library does not know read as zero.  The two entry points
+ * without a context take the sizes themselves (icpgpu_default_params_sz, icpgpu_align_batch_multi_sz; macros below).
+ * icpgpu_create_abi refuses a header of another MAJOR version (ICPGPU_ERR_UNSUPPORTED).  Until 0.4 the structs grew in place with
+ * nothing but a comment to protect an older caller; the unsized symbols of those versions (icpgpu_create, icpgpu_default_params,
+ * icpgpu_align_batch_multi) are NOT exported any more, so a binary built against a 0.x header fails at load time instead of
+ * overrunning its structs.  History: 1.0 icpgpu_result.gicp_solver, icpgpu_calibrate, sized entry points; 0.4 icpgpu_params.gicp_inner,
+ * icpgpu_profile.gicp_quadratic_solves; 0.3 icpgpu_profile (sources_adopted, gicp_host_solves, gicp_solver_choice). */
 
 /* ---- environment ---------------------------------------------------------------------------------
  * Production switches, read by every build of libicpgpu.so (none of them changes a result, except ICPGPU_GICP_INNER):
@@ -49,9 +58,11 @@ extern "C" {
  *   ICPGPU_BATCH_GROUPS           lock-step groups in flight on the GPU, over all host threads together (default 8)
  *   ICPGPU_RECOGNISE=0            icpgpu_set_target / icpgpu_set_source always upload (no content recognition)
  *   ICPGPU_GICP_SERVER=0          every GICP cost evaluation is its own kernel launch (no resident evaluation server)
- *   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host (0), in the resident device solver (1), or whichever the context
- *                                 measures to be faster over its first alignments (auto, the default); same bits either way, the
- *                                 choice is reported in icpgpu_profile.gicp_solver_choice
+ *   ICPGPU_GICP_DEVICE=0|1|auto   GICP's inner BFGS on the host over the evaluation server (0), or in the resident device solver (1);
+ *                                 auto (the default) = the host loop for single alignments, the device solver for the runs of a
+ *                                 batch -- a fixed rule since 1.0 (until 0.4 a context timed both over its first alignments);
+ *                                 icpgpu_calibrate measures on request.  Same bits either way; the solver an alignment ran on is
+ *                                 in icpgpu_result.gicp_solver, the context's setting in icpgpu_profile.gicp_solver_choice
  *   ICPGPU_GICP_INNER=exact|quadratic  overrides icpgpu_params.gicp_inner (see icpgpu_gicp_inner below: QUADRATIC moves a GICP
  *                                 result within the stated tolerance, not bit for bit)
  *   ICPGPU_MAILBOX=pairs|release  how results reach the host (default: a self-test at context creation picks it)
@@ -131,7 +142,16 @@ typedef struct {
                                * (icpgpu_profile_set_sampling), scaled to all sweeps of the call.  An estimate: timings are
                                * read without blocking, and one that was not ready at the end of the call counts towards
                                * the next one; 0 when none of the call's sweeps was a timed one (icpgpu_profile_get always waits and is exact) */
+  int32_t gicp_solver;        /* GICP: where the inner BFGS of this alignment's LAST outer iteration ran -- icpgpu_gicp_solver;
+                               * 0 for point-to-point alignments and alignments that never reached a minimisation -- 1.0 */
+  int32_t reserved0;
 } icpgpu_result;
+typedef enum {
+  ICPGPU_GICP_SOLVER_NONE = 0,
+  ICPGPU_GICP_SOLVER_HOST = 1,      /* BFGS on the host, every evaluation a round trip to the resident evaluation server */
+  ICPGPU_GICP_SOLVER_DEVICE = 2,    /* the whole BFGS inside gicp_solve_kernel */
+  ICPGPU_GICP_SOLVER_QUADRATIC = 3  /* gicp_inner = QUADRATIC: one device pass, BFGS on the host on the quadratic form */
+} icpgpu_gicp_solver;
 
 /* Kernel-level accounting since the last icpgpu_profile_reset(); times are HIP-event times on the
  * context's own stream (this is what bench.py's roofline object is computed from). */
@@ -183,21 +203,28 @@ typedef struct {
   uint64_t sources_adopted;        /* icpgpu_set_source calls that found the buffer to be the context's last voxel-filter result,
                                     * still in HBM (no upload, no bounding-box pass) -- version 0.3 */
   uint64_t gicp_host_solves;       /* GICP outer iterations whose inner BFGS ran on the host (over the evaluation server) -- 0.3 */
-  uint64_t gicp_solver_choice;     /* ICPGPU_GICP_DEVICE=auto: 0 = the context is still timing both solvers, 1 = it settled on the
-                                    * host loop, 2 = on the device solver (forced modes report 1 / 2 at once) -- 0.3 */
+  uint64_t gicp_solver_choice;     /* the solver single GICP alignments of this context run on: 1 = host loop, 2 = device solver; never 0
+                                    * since 1.0 (set at icpgpu_create from ICPGPU_GICP_DEVICE, changed only by icpgpu_calibrate) -- 0.3 */
   uint64_t gicp_quadratic_solves;  /* GICP outer iterations solved on the quadratic form (icpgpu_params.gicp_inner = QUADRATIC) -- 0.4 */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* replaces: construction of the stack `icp` object, icp_odometer.cpp:188 / octree_mapper.cpp:104.
  * Unlike the reference (fresh object per scan) a context is meant to be created once and reused. */
-int icpgpu_create(icpgpu_ctx** out_ctx, int device_id);
+int icpgpu_create_abi(icpgpu_ctx** out_ctx, int device_id, int header_version, size_t sizeof_params, size_t sizeof_result,
+                      size_t sizeof_profile);
+#define icpgpu_create(out_ctx, device_id) \
+  icpgpu_create_abi((out_ctx), (device_id), ICPGPU_HEADER_VERSION, sizeof(icpgpu_params), sizeof(icpgpu_result), sizeof(icpgpu_profile))
 int icpgpu_destroy(icpgpu_ctx* ctx);
 const char* icpgpu_last_error(const icpgpu_ctx* ctx); /* ctx may be NULL: last create() error */
 int icpgpu_version(void);                             /* major*1000 + minor */
 
 /* ---- parameters (icp_odometer.cpp:189-192, octree_mapper.cpp:105-108) ----------------------- */
-void icpgpu_default_params(icpgpu_params* p); /* PCL defaults + the reference's odometer constants */
+void icpgpu_default_params_sz(icpgpu_params* p, size_t sizeof_params); /* PCL defaults + the reference's odometer constants */
+#define icpgpu_default_params(p) icpgpu_default_params_sz((p), sizeof(icpgpu_params))
+/* what THIS library's structs measure: {sizeof(icpgpu_params), sizeof(icpgpu_result), sizeof(icpgpu_profile)} (bindings that
+ * mirror the structs by hand -- ctypes, JNA -- check themselves against it) */
+void icpgpu_struct_sizes(size_t out3[3]);
 int icpgpu_set_params(icpgpu_ctx* ctx, const icpgpu_params* p);
 int icpgpu_get_params(const icpgpu_ctx* ctx, icpgpu_params* p);
 
@@ -263,9 +290,13 @@ int icpgpu_align_batch(icpgpu_ctx* ctx, size_t n_pairs, const float* const* src,
  *   ICPGPU_COMM_HOST  the same buffers, exchanged through host memory (tests on one GPU: a device may be named twice)
  * params NULL keeps the contexts' parameters.  Errors: status code + icpgpu_multi_last_error() (per calling thread). */
 enum { ICPGPU_COMM_NONE = 0, ICPGPU_COMM_RCCL = 1, ICPGPU_COMM_HOST = 2 };
-int icpgpu_align_batch_multi(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
-                             const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
-                             int want_fitness, icpgpu_result* results, double* records, int communicator);
+int icpgpu_align_batch_multi_sz(const int* devices, int n_devices, const icpgpu_params* params, size_t n_pairs,
+                                const float* const* src, const size_t* n_src, const float* const* tgt, const size_t* n_tgt,
+                                int want_fitness, icpgpu_result* results, double* records, int communicator, size_t sizeof_params,
+                                size_t sizeof_result);
+#define icpgpu_align_batch_multi(devices, n_devices, params, n_pairs, src, n_src, tgt, n_tgt, want_fitness, results, records, comm) \
+  icpgpu_align_batch_multi_sz((devices), (n_devices), (params), (n_pairs), (src), (n_src), (tgt), (n_tgt), (want_fitness), (results), \
+                              (records), (comm), sizeof(icpgpu_params), sizeof(icpgpu_result))
 const char* icpgpu_multi_last_error(void);
 
 /* ---- kernel-level entry points (used by the parity tests; same kernels as align) ------------- */
@@ -283,6 +314,11 @@ int icpgpu_transform(icpgpu_ctx* ctx, const float* T, float* out_xyzw);
 /* a11 (GICP mode): per-point regularised covariances U diag(1,1,1e-3) U^T of the 20 nearest neighbours
  * (pcl::GeneralizedIterativeClosestPoint::computeCovariances); out6 = n x {xx, xy, xz, yy, yz, zz}. */
 int icpgpu_gicp_covariances(icpgpu_ctx* ctx, int of_target, double* out6);
+/* ICPGPU_GICP_DEVICE=auto only: time GICP's two inner solvers on THIS box with the context's current source, target and parameters
+ * (method GICP; a few alignments whose results are discarded) and keep the faster for the context's single alignments from now on.
+ * *choice (nullable) = icpgpu_gicp_solver.  Never called implicitly: without it the fixed rule above holds, so two identical runs
+ * take identical paths from their first alignment on.  Results cannot depend on the choice (same bits, tests/test_gpu_gicp.py). */
+int icpgpu_calibrate(icpgpu_ctx* ctx, int* choice);
 /* One evaluation of the QUADRATIC inner objective on the host (no device): sums = 75 double-double numbers as (hi, lo) pairs
  * (icpslam_amd/csrc/icp_gicp_quadratic.h: 60 A, 12 Bq, cq, m, sum d2), base16 = the guess (column-major float 4x4), x = (tx, ty,
  * tz, roll, pitch, yaw) -> f and its gradient as BFGS sees them.  A diagnostic entry: tests check the algebra with it. */

@@ -18,6 +18,7 @@ HEADER = os.path.join(ROOT, "include", "icpgpu.h")
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"^#define(.*\\\n)*.*$", "", text, flags=re.M)     # the three macros over the sized entry points: not symbols
     return sorted(set(re.findall(r"\b(icpgpu_[a-z_0-9]+)\s*\(", text)))
 
 
@@ -47,6 +48,35 @@ def test_header_compiles_as_c_and_struct_sizes_match(built, tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert sizes == [C.sizeof(_lib.Params), C.sizeof(_lib.Result), C.sizeof(_lib.Profile)]
+
+
+def test_struct_sizes_and_the_abi_rule(built):
+    """include/icpgpu.h, "ABI rule": the library reports its structs' sizes (equal to the ctypes mirrors'), default_params_sz fills a
+    SHORTER struct (an older 1.x header) without touching what follows it and zero-fills the tail of a LONGER one (a newer header);
+    a context cannot be created for a header of another major version, nor with sizes no 1.x header ever had; and the unsized
+    symbols of 0.x are gone, so a binary built against them fails to load instead of overrunning its structs."""
+    lib = _lib.load()
+    sizes = (C.c_size_t * 3)()
+    lib.icpgpu_struct_sizes(sizes)
+    assert list(sizes) == [C.sizeof(_lib.Params), C.sizeof(_lib.Result), C.sizeof(_lib.Profile)]
+    assert lib.icpgpu_version() == _lib.HEADER_VERSION
+    full = _lib.Params()
+    lib.icpgpu_default_params(C.byref(full))
+    n = C.sizeof(_lib.Params)
+    buf = (C.c_ubyte * (n + 64))(*([0xAB] * (n + 64)))
+    lib.icpgpu_default_params_sz(C.cast(buf, C.POINTER(_lib.Params)), n - 8)                 # a caller without the last fields
+    assert bytes(buf[:n - 8]) == bytes(full)[:n - 8] and set(buf[n - 8:]) == {0xAB}
+    lib.icpgpu_default_params_sz(C.cast(buf, C.POINTER(_lib.Params)), n + 32)                # a caller with fields the library lacks
+    assert bytes(buf[:n]) == bytes(full) and set(buf[n:n + 32]) == {0} and set(buf[n + 32:]) == {0xAB}
+    h = C.c_void_p()
+    sz = [C.sizeof(_lib.Params), C.sizeof(_lib.Result), C.sizeof(_lib.Profile)]
+    assert lib.icpgpu_create_abi(C.byref(h), 0, 4, *sz) == _lib.ERR_UNSUPPORTED and not h.value          # a 0.4 header
+    assert b"major version" in lib.icpgpu_last_error(None)
+    assert lib.icpgpu_create_abi(C.byref(h), 0, 2000, *sz) == _lib.ERR_UNSUPPORTED and not h.value
+    assert lib.icpgpu_create_abi(C.byref(h), 0, _lib.HEADER_VERSION, 48, sz[1], sz[2]) == _lib.ERR_INVALID_ARG and not h.value
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    for gone in ("icpgpu_create", "icpgpu_default_params", "icpgpu_align_batch_multi"):
+        assert not re.search(rf"\bT {gone}$", out, flags=re.M), gone
 
 
 def test_version_and_default_params(built):

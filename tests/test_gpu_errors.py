@@ -144,3 +144,59 @@ def test_map_get_points_capacity_is_checked(ctx):
     buf = np.zeros((4, 4), np.float32)
     rc = L.icpgpu_map_get_points(ctx._h, buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(4), C.byref(n))
     assert rc == ERR_INVALID_ARG and n.value == ctx.map_size() > 4
+
+
+def test_callers_with_shorter_and_longer_structs(built):
+    """include/icpgpu.h, "ABI rule", on a device: a context created by a caller whose structs are SHORTER than the library's (an older
+    1.x header: here icpgpu_result without gicp_solver, icpgpu_params without gicp_inner's word, a profile without its last field)
+    gets exactly its bytes written -- the guard bytes behind its structs stay untouched -- and the same numbers; a caller with LONGER
+    structs gets the tail zeroed; batches honour the caller's stride."""
+    L = _lib.load()
+    src, tgt, _ = synth.make_pair(4000, 4000, seed=5)
+    fp = C.POINTER(C.c_float)
+    ptr = lambda a: a.ctypes.data_as(fp)
+    with __import__("icpslam_amd").Context(0) as ref_ctx:
+        ref_ctx.set_params(ref_ctx.default_params(), max_iterations=10)
+        ref_ctx.set_source(src)
+        ref_ctx.set_target(tgt)
+        ref = ref_ctx.align(want_fitness=True)
+    n_p, n_r, n_f = C.sizeof(_lib.Params), C.sizeof(_lib.Result), C.sizeof(_lib.Profile)
+    for d_p, d_r, d_f in ((0, -8, -8), (16, 24, 40)):
+        s_p, s_r, s_f = n_p + d_p, n_r + d_r, n_f + d_f
+        h = C.c_void_p()
+        assert L.icpgpu_create_abi(C.byref(h), 0, _lib.HEADER_VERSION, s_p, s_r, s_f) == 0
+        try:
+            pbuf = (C.c_ubyte * (s_p + 32))(*([0xCD] * (s_p + 32)))
+            L.icpgpu_default_params_sz(C.cast(pbuf, C.POINTER(_lib.Params)), s_p)
+            assert L.icpgpu_set_params(h, C.cast(pbuf, C.POINTER(_lib.Params))) == 0
+            back = (C.c_ubyte * (s_p + 32))(*([0xCD] * (s_p + 32)))
+            assert L.icpgpu_get_params(h, C.cast(back, C.POINTER(_lib.Params))) == 0
+            assert bytes(back) == bytes(pbuf)
+            assert L.icpgpu_set_source(h, ptr(src), src.shape[0]) == 0 and L.icpgpu_set_target(h, ptr(tgt), tgt.shape[0]) == 0
+            rbuf = (C.c_ubyte * (s_r + 32))(*([0xCD] * (s_r + 32)))
+            assert L.icpgpu_align(h, None, None, 1, C.cast(rbuf, C.POINTER(_lib.Result))) == 0
+            assert set(rbuf[s_r:]) == {0xCD}                                       # nothing written behind the caller's struct
+            if d_r > 0:
+                assert set(rbuf[n_r:s_r]) == {0}
+            res = _lib.Result.from_buffer_copy(bytes(rbuf[:n_r]) if d_r >= 0 else bytes(rbuf[:s_r]) + bytes(-d_r))
+            assert np.array_equal(np.array(res.T, np.float32).reshape(4, 4).T, ref["T"])
+            assert (res.iterations, res.n_correspondences, res.fitness) == (ref["iterations"], ref["n_corr"], ref["fitness"])
+            fbuf = (C.c_ubyte * (s_f + 32))(*([0xCD] * (s_f + 32)))
+            assert L.icpgpu_profile_get(h, C.cast(fbuf, C.POINTER(_lib.Profile))) == 0
+            assert set(fbuf[s_f:]) == {0xCD}
+            prof = _lib.Profile.from_buffer_copy(bytes(fbuf[:n_f]) if d_f >= 0 else bytes(fbuf[:s_f]) + bytes(-d_f))
+            assert prof.aligns == 1 and prof.iterations == ref["iterations"]
+            # a batch of three pairs: results at the CALLER's stride
+            srcs = (fp * 3)(ptr(src), ptr(src), ptr(src))
+            tgts = (fp * 3)(ptr(tgt), ptr(tgt), ptr(tgt))
+            ns = (C.c_size_t * 3)(src.shape[0], src.shape[0], src.shape[0])
+            nt = (C.c_size_t * 3)(tgt.shape[0], tgt.shape[0], tgt.shape[0])
+            bbuf = (C.c_ubyte * (3 * s_r + 32))(*([0xCD] * (3 * s_r + 32)))
+            assert L.icpgpu_align_batch(h, 3, srcs, ns, tgts, nt, 1, C.cast(bbuf, C.POINTER(_lib.Result))) == 0
+            assert set(bbuf[3 * s_r:]) == {0xCD}
+            for k in range(3):
+                one = bytes(bbuf[k * s_r:(k + 1) * s_r])
+                r = _lib.Result.from_buffer_copy(one[:n_r] if d_r >= 0 else one + bytes(-d_r))
+                assert np.array_equal(np.array(r.T, np.float32).reshape(4, 4).T, ref["T"]) and r.fitness == ref["fitness"]
+        finally:
+            assert L.icpgpu_destroy(h) == 0

@@ -1,5 +1,7 @@
 """GPU parity of the GICP mode -- the solver the reference literally instantiates
 (icp_odometer.cpp:188, octree_mapper.cpp:104) -- against the oracle's restatement of PCL's GICP."""
+import os
+
 import numpy as np
 import pytest
 
@@ -411,3 +413,44 @@ def test_gicp_batch_runs_equal_single_aligns(built, monkeypatch, threads, runs):
     assert want[3]["n_corr"] < 4 and not want[3]["converged"], want[3]
     assert not want[6]["converged"] and want[6]["iterations"] == 0, want[6]
     assert not want[-1]["converged"] and want[-1]["iterations"] == 0, want[-1]
+
+
+def test_solver_choice_is_fixed_at_creation_recorded_per_result_and_calibrate_is_explicit(built):
+    """icpgpu.h 1.0: which code path a GICP alignment takes no longer depends on a timing race inside
+    production aligns.  A context knows its solver from icpgpu_create on (ICPGPU_GICP_DEVICE=auto: the host loop), every result
+    names the solver it ran on (icpgpu_result.gicp_solver) from the FIRST alignment, two fresh contexts take the same path, and
+    only icpgpu_calibrate -- explicit, results discarded -- may change the choice; the bits are the same whatever it picks."""
+    from icpslam_amd import Context, GICP_INNER_QUADRATIC, _lib
+    if os.environ.get("ICPGPU_GICP_DEVICE", "auto") != "auto":
+        pytest.skip("ICPGPU_GICP_DEVICE is forced in this environment")
+    src, tgt, _ = synth.make_pair(9000, 9400, seed=91)
+    firsts = []
+    for _ in range(2):
+        with Context(0) as c:
+            assert c.profile().gicp_solver_choice == _lib.GICP_SOLVER_HOST          # known at creation, before any alignment
+            c.set_params(c.default_params(), method=GICP, max_iterations=10)
+            c.set_source(src)
+            c.set_target(tgt)
+            runs = [c.align(want_fitness=True) for _ in range(6)]
+            assert [r["gicp_solver"] for r in runs] == [_lib.GICP_SOLVER_HOST] * 6  # the same path from the first alignment on
+            p = c.profile()
+            assert p.gicp_device_solves == 0 and p.gicp_host_solves == sum(r["iterations"] for r in runs)
+            firsts.append(runs[0])
+    assert firsts[0]["T"].tobytes() == firsts[1]["T"].tobytes()
+    with Context(0) as c:
+        c.set_params(c.default_params(), max_iterations=10)                          # point-to-point: no inner solver
+        c.set_source(src)
+        c.set_target(tgt)
+        assert c.align()["gicp_solver"] == _lib.GICP_SOLVER_NONE
+        with pytest.raises(Exception):
+            c.calibrate()                                                             # method is not GICP
+        c.set_params(c.default_params(), method=GICP, max_iterations=10, gicp_inner=GICP_INNER_QUADRATIC)
+        assert c.align()["gicp_solver"] == _lib.GICP_SOLVER_QUADRATIC
+        c.set_params(c.default_params(), method=GICP, max_iterations=10)
+        choice = c.calibrate()
+        assert choice in (_lib.GICP_SOLVER_HOST, _lib.GICP_SOLVER_DEVICE)
+        assert c.profile().gicp_solver_choice == choice
+        again = [c.align(want_fitness=True) for _ in range(3)]
+        assert [r["gicp_solver"] for r in again] == [choice] * 3
+        assert all(r["T"].tobytes() == firsts[0]["T"].tobytes() and r["fitness"] == firsts[0]["fitness"] for r in again)
+        print(f"icpgpu_calibrate on this box: {'device solver' if choice == 2 else 'host loop'}")
