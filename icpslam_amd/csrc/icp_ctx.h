@@ -246,6 +246,7 @@ struct icpgpu_ctx {
   unsigned long long* h_solve_dev = nullptr;
   unsigned long long gicp_solve_seq = 0;
   bool gicp_device_ok = false;
+  int gicp_device_failures = 0;  // batch runs in a row whose device solver gave no answer (three switch it off on this worker)
   bool gicp_resources_ready = false;  // ensure_gicp_resources has run (icpgpu_context.cpp)
   // the quadratic inner solver (icpgpu_params.gicp_inner; icp_gicp_quadratic.h): the workgroups' partial sums, the counter of
   // finished workgroups, the 2 x kGicpQuadSums result pairs (host, mapped) and the number the next pass's pairs carry

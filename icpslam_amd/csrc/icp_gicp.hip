@@ -509,8 +509,8 @@ __device__ __forceinline__ void gicp_accumulate(GicpAcc& acc, const float4* __re
   }
 }
 
-// Workgroup reduction of the lanes' accumulators into partials[block * kGicpPartialStride + ...]: [0] = m, [1..13] = the
-// sums' high parts, [14] = sum d2, [16..28] = their low parts.  The 13 double-double sums go through LDS: thread
+// Workgroup reduction of the lanes' accumulators into partials[block * kGicpPartialStride + ...] as four 64-byte ANSWER LINES of
+// seven values + one tag (word 8 L + 7): value 0 = m, 1..13 = the sums' high parts, 14 = sum d2, 15..27 = their low parts.  The 13 double-double sums go through LDS: thread
 // (sum, chunk) adds the 16 lanes of its chunk in lane order, then thread `sum` adds the 16 chunk results in order.
 // md (nullable): the workgroup's m and sum d2 from an EARLIER evaluation of the same correspondences (they do not depend on the
 // state): md[2] != 0 means md[0], md[1] are valid and the two wave reductions (twelve dependent cross-lane steps) are skipped;
@@ -577,6 +577,11 @@ __device__ __forceinline__ void gicp_block_reduce_store(const GicpAcc& acc, doub
     fold ^= (unsigned int)__shfl_xor((int)fold, 4, 64);  // every lane of the line: the XOR of its seven folds
     const unsigned long long word = pos < 7 ? bits : (((tag & ~kMailboxReleaseBit) << 24) | (unsigned long long)fold);
     unsigned long long* w = reinterpret_cast<unsigned long long*>(out) + lane;
+    // (ASSUMPTION of the classic form, gfx9 hardware rather than the HIP memory model: the values of a line are stored by lanes
+    //  8 L .. 8 L + 6 and its tag by lane 8 L + 7 of the SAME wave; a release fence is executed wave-wide on this hardware
+    //  (s_waitcnt + write-back), so the tag lane's release also orders the other lanes' stores.  The model only promises that for
+    //  the storing lane itself.  The default form below does not depend on it -- a line carries its own checksum -- and
+    //  tests/test_gpu_mailbox.py runs both forms against each other.)
     if (tag & kMailboxReleaseBit) {  // the classic form: values, system-scope release, tags
       if (lane < 8 * kGicpLines && pos < 7) __hip_atomic_store(w, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -729,6 +734,13 @@ __global__ __launch_bounds__(256) void gicp_quadratic_kernel(const float4* __res
   const long long st2 = stamps ? (long long)wall_clock64() : 0;
   // (every global store of this workgroup came from threads 0..12 -- wave 0, the wave of thread 0 -- so the counter's RELEASE orders
   //  them by itself: one wave's write-back instead of a fence in all four and a barrier, 3.3 -> ~1.5 us on the last workgroup's path)
+  //  Since round 6 the storing lanes say so themselves: an agent-scope release fence in wave 0 (all of its lanes: the fence is
+  //  wave-wide on this hardware anyway, and the memory model orders a lane's stores only behind that lane's own release), then
+  //  the counter -- ADVICE r5; one more write-back of an already clean wave.)
+  if (threadIdx.x < 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_wave_barrier();  // (no instruction: the lanes of a wave are in step; it marks the wavefront-scope hand-over to lane 0)
+  }
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
   __syncthreads();
   if (!s_last) return;

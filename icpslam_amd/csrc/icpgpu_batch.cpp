@@ -217,7 +217,10 @@ static int align_batch_impl(icpgpu_ctx* c, size_t n_pairs, const float* const* s
       const size_t n_makers = std::min<size_t>(std::max<size_t>(1, n_threads), n_ctx);
       for (size_t m = 0; m < n_makers; ++m)
         makers.emplace_back([&, m] {
-          if (hipSetDevice(c->device) != hipSuccess) return;
+          if (hipSetDevice(c->device) != hipSuccess) {  // (reported through the workers this maker was responsible for)
+            for (size_t i = m; i < n_ctx; i += n_makers) pre_rc[i] = fail(c->workers[i], ICPGPU_ERR_HIP, "hipSetDevice failed in a batch maker thread");
+            return;
+          }
           for (size_t i = m; i < n_ctx; i += n_makers) pre_rc[i] = presize_batch_worker(c->workers[i], ns_max, nt_max, cells);
         });
       for (auto& th : makers) th.join();
@@ -321,6 +324,7 @@ static int align_batch_impl(icpgpu_ctx* c, size_t n_pairs, const float* const* s
       hipStream_t work_stream[2] = {nullptr, nullptr}, solve_stream[2] = {nullptr, nullptr};
       std::vector<hipStream_t> own(depth, nullptr);
       std::vector<int> solving_on(depth, -1);  // which solve stream a run's solver is on (-1: none)
+      int blocks_on[2] = {0, 0};               // solver workgroups the launch in flight on each solve stream holds
       struct RestoreStreams {
         std::vector<hipStream_t>& own; icpgpu_ctx* const* ws; hipStream_t* w; hipStream_t* s2;
         ~RestoreStreams() {
@@ -366,20 +370,24 @@ static int align_batch_impl(icpgpu_ctx* c, size_t n_pairs, const float* const* s
         }
         if (in_flight == 0 && (exhausted || abort.load())) return;
         for (int ss = 0; gicp_runs && ss < 2; ++ss) {  // the solvers of every run that is ready: one launch, on a solve stream that is idle
-          bool busy = false;
+          bool busy = false, other_busy = false;
           for (size_t s2 = 0; s2 < depth; ++s2) {
-            if (solving_on[s2] == ss && gruns[s2].phase != GicpRun::Solve) solving_on[s2] = -1;  // (answered, or gave up)
+            if (solving_on[s2] >= 0 && gruns[s2].phase != GicpRun::Solve) solving_on[s2] = -1;  // (answered, or gave up)
             busy = busy || solving_on[s2] == ss;
+            other_busy = other_busy || solving_on[s2] == 1 - ss;
           }
           if (busy) continue;
+          blocks_on[ss] = 0;
+          if (!other_busy) blocks_on[1 - ss] = 0;
           GicpSolveItem items[kGicpSolveBatchMax];
           size_t who[kGicpSolveBatchMax];
           int n_ready = 0, blocks_sum = 0;
-          // (a solver workgroup takes a CU's one-wave-per-SIMD slot: the launches of all threads together stay below the chip's 256
-          //  CUs, or a run's workgroups would spin waiting for peers that have no CU yet)
-          const int blocks_cap = std::max(1, 240 / (int)n_threads);
+          // (a solver workgroup takes a CU's one-wave-per-SIMD slot: the workgroups resident over BOTH solve streams of ALL threads
+          //  together stay below the chip's 256 CUs, or a run's workgroups would spin waiting for peers that have no CU yet.  Until
+          //  round 6 the cap was applied per launch, and two launches of a thread could hold ~2 x 240 / n_threads between them.)
+          const int blocks_cap = std::max(1, 240 / (int)n_threads) - blocks_on[1 - ss];
           for (size_t s2 = 0; s2 < depth && n_ready < kGicpSolveBatchMax; ++s2)
-            if (gruns[s2].phase == GicpRun::WantSolve && (n_ready == 0 || blocks_sum + gruns[s2].item.blocks <= blocks_cap)) {
+            if (gruns[s2].phase == GicpRun::WantSolve && ((n_ready == 0 && !other_busy) || blocks_sum + gruns[s2].item.blocks <= blocks_cap)) {
               items[n_ready] = gruns[s2].item;
               blocks_sum += gruns[s2].item.blocks;
               who[n_ready++] = s2;
@@ -400,6 +408,7 @@ static int align_batch_impl(icpgpu_ctx* c, size_t n_pairs, const float* const* s
               gicp_run_solver_launched(ws[who[k]], gruns[who[k]], solve_stream[ss]);
               solving_on[who[k]] = ss;
             }
+            blocks_on[ss] = blocks_sum;
             progressed = true;
           }
         }

@@ -234,74 +234,104 @@ int device_fingerprint(icpgpu_ctx* c, const Cloud& cl, uint64_t version, unsigne
 // and three synchronous memsets that a point-to-point batch worker never uses (icpgpu_align_batch creates up to 64 workers).
 int ensure_gicp_resources(icpgpu_ctx* c) {
   if (c->gicp_resources_ready) return ICPGPU_OK;
+  // Every failure path leaves the context as it found it (nothing half-allocated that a second call would allocate over):
+  // each buffer is guarded by its own pointer and released again when a later step of its group fails.
   hipError_t e;
-  {
+  if (!c->h_gicp) {
     const size_t n_flags_end = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8 + kGicpDirectBlocks;  // partials, gap, flags
     const size_t cmd_off = (n_flags_end + 7) & ~(size_t)7;                                        // 64-byte aligned
     const size_t n_d = cmd_off + 8;                                                              // + the server's command line
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&c->h_gicp), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) !=
-        hipSuccess)
+    double* h = nullptr;
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h), n_d * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
       return fail(c, e == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "hipHostMalloc: %s", hipGetErrorString(e));
-    std::memset(c->h_gicp, 0, n_d * sizeof(double));
-    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_gicp_dev), c->h_gicp, 0)) != hipSuccess)
+    std::memset(h, 0, n_d * sizeof(double));
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_gicp_dev), h, 0)) != hipSuccess) {
+      (void)hipHostFree(h);
       return fail(c, ICPGPU_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+    }
+    c->h_gicp = h;
     const size_t off = (size_t)kGicpDirectBlocks * kGicpPartialStride + 8;
     c->h_gicp_flags = reinterpret_cast<volatile unsigned long long*>(c->h_gicp + off);
     c->h_gicp_flags_dev = reinterpret_cast<unsigned long long*>(c->h_gicp_dev + off);
-    (void)cmd_off;
   }
-  if (gicp_device_solver_enabled()) {  // the device solver's slots and result granules; without them GICP solves on the host
+  if (gicp_device_solver_enabled() && !c->gicp_device_ok) {  // the device solver's slots and result granules; without them GICP solves on the host
     const size_t slot_bytes = gicp_solve_slot_bytes(kGicpDirectBlocks);
     void* h = nullptr;
-    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_slots), slot_bytes, hipDeviceMallocFinegrained) == hipSuccess &&
-        hipMemset(c->gicp_slots, 0, slot_bytes) == hipSuccess &&
+    unsigned long long* slots = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&slots), slot_bytes, hipDeviceMallocFinegrained) == hipSuccess &&
+        hipMemset(slots, 0, slot_bytes) == hipSuccess &&
         hipHostMalloc(&h, 512, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
       std::memset(h, 0, 512);
-      c->h_solve = static_cast<volatile unsigned long long*>(h);
-      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_solve_dev), h, 0) == hipSuccess) c->gicp_device_ok = true;
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_solve_dev), h, 0) == hipSuccess) {
+        c->gicp_slots = slots;
+        c->h_solve = static_cast<volatile unsigned long long*>(h);
+        c->gicp_device_ok = true;
+      }
     }
-    if (!c->gicp_device_ok) (void)hipGetLastError();
+    if (!c->gicp_device_ok) {  // no device solver on this context: nothing of it stays behind
+      (void)hipGetLastError();
+      if (slots) (void)hipFree(slots);
+      if (h) (void)hipHostFree(h);
+      c->h_solve_dev = nullptr;
+    }
     if (c->gicp_device_ok) {
       static std::atomic<int> serial{0};
       c->gicp_xcc = serial.fetch_add(1) & 7;  // concurrent contexts spread their one-XCD runs over the eight XCDs
       const size_t owner_bytes = (size_t)kGicpDirectBlocks * sizeof(unsigned long long);
-      if (hipMalloc(reinterpret_cast<void**>(&c->gicp_slots_local), slot_bytes) == hipSuccess &&
-          hipMemset(c->gicp_slots_local, 0, slot_bytes) == hipSuccess &&
-          hipMalloc(reinterpret_cast<void**>(&c->gicp_owner), owner_bytes) == hipSuccess &&
-          hipMemset(c->gicp_owner, 0, owner_bytes) == hipSuccess)
+      unsigned long long *local = nullptr, *owner = nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&local), slot_bytes) == hipSuccess && hipMemset(local, 0, slot_bytes) == hipSuccess &&
+          hipMalloc(reinterpret_cast<void**>(&owner), owner_bytes) == hipSuccess && hipMemset(owner, 0, owner_bytes) == hipSuccess) {
+        c->gicp_slots_local = local;
+        c->gicp_owner = owner;
         c->gicp_local_ok = true;
-      else
+      } else {
         (void)hipGetLastError();
+        if (local) (void)hipFree(local);
+        if (owner) (void)hipFree(owner);
+      }
     }
   }
-  if (gicp_server_enabled()) {  // no such memory (no large BAR): the evaluations stay single launches
-    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&c->gicp_cmd), 4096, hipDeviceMallocFinegrained) != hipSuccess) {
+  if (gicp_server_enabled() && !c->gicp_cmd) {  // no such memory (no large BAR): the evaluations stay single launches
+    unsigned int* cmd = nullptr;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&cmd), 4096, hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
-      c->gicp_cmd = nullptr;
-    } else if ((e = hipMemset(c->gicp_cmd, 0, 4096)) != hipSuccess) {
+    } else if ((e = hipMemset(cmd, 0, 4096)) != hipSuccess) {
+      (void)hipFree(cmd);
       return fail(c, ICPGPU_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+    } else {
+      c->gicp_cmd = cmd;
     }
   }
   c->gicp_resources_ready = true;
   return ICPGPU_OK;
 }
 
-// the quadratic inner solver's buffers, when a context first uses it
+// the quadratic inner solver's buffers, when a context first uses it (all or nothing: a failure releases what it had got)
 int ensure_gicp_quadratic_resources(icpgpu_ctx* c) {
   if (c->h_quad) return ICPGPU_OK;
   hipError_t e;
   const size_t part_bytes = (size_t)kGicpQuadBlocks * kGicpQuadSums * 2 * sizeof(double);
   const size_t out_bytes = (size_t)(2 * kGicpQuadSums + 8) * 16;  // (+ the development flavour's stamps)
   void* h = nullptr;
-  if ((e = hipMalloc(reinterpret_cast<void**>(&c->quad_partials), part_bytes)) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&c->quad_done), 64)) != hipSuccess || (e = hipMemset(c->quad_done, 0, 64)) != hipSuccess ||
-      (e = hipHostMalloc(&h, out_bytes, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
-    return fail(c, e == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "quadratic GICP solver buffers: %s", hipGetErrorString(e));
-  std::memset(h, 0, out_bytes);
-  if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_quad_dev), h, 0)) != hipSuccess) {
-    (void)hipHostFree(h);
-    return fail(c, ICPGPU_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+  double* partials = nullptr;
+  unsigned int* done = nullptr;
+  const char* what = "allocation";
+  if ((e = hipMalloc(reinterpret_cast<void**>(&partials), part_bytes)) == hipSuccess &&
+      (e = hipMalloc(reinterpret_cast<void**>(&done), 64)) == hipSuccess && (e = hipMemset(done, 0, 64)) == hipSuccess &&
+      (e = hipHostMalloc(&h, out_bytes, hipHostMallocMapped | hipHostMallocCoherent)) == hipSuccess) {
+    std::memset(h, 0, out_bytes);
+    what = "hipHostGetDevicePointer";
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_quad_dev), h, 0);
   }
+  if (e != hipSuccess) {
+    if (partials) (void)hipFree(partials);
+    if (done) (void)hipFree(done);
+    if (h) (void)hipHostFree(h);
+    c->h_quad_dev = nullptr;
+    return fail(c, e == hipErrorOutOfMemory ? ICPGPU_ERR_OOM : ICPGPU_ERR_HIP, "quadratic GICP solver buffers (%s): %s", what, hipGetErrorString(e));
+  }
+  c->quad_partials = partials;
+  c->quad_done = done;
   c->h_quad = static_cast<volatile unsigned long long*>(h);
   return ICPGPU_OK;
 }
