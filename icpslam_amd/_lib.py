@@ -54,7 +54,8 @@ class Profile(C.Structure):
                 ("targets_recognised", C.c_uint64), ("brute_bound_violations", C.c_uint64),
                 ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64),
                 ("grid_adopted", C.c_uint64), ("sources_adopted", C.c_uint64), ("gicp_host_solves", C.c_uint64),
-                ("gicp_solver_choice", C.c_uint64), ("gicp_quadratic_solves", C.c_uint64)]
+                ("gicp_solver_choice", C.c_uint64), ("gicp_quadratic_solves", C.c_uint64),
+                ("cov_grids_unchecked", C.c_uint64), ("cov_grids_rebuilt", C.c_uint64)]
 
 
 class Pose(C.Structure):

@@ -173,8 +173,10 @@ constexpr size_t kMaxServerWorkers = 8;
 // 1 200 campaign registrations through both).  Which one is faster depends on the box: the host loop's evaluation is 6.8-8.3 us
 // with the box's PCIe and CPU, the kernel's 7.2-7.7 us wherever it runs (EXPERIMENTS.md section 9-f1) -- so a context times a few
 // outer iterations each way (align_gicp) and keeps the faster; runs the one-XCD variant cannot take stay on the host.
-// sizes of the public structs in icpgpu.h 1.0: the shortest a caller of this major version can hand over (icpgpu_create_abi)
-constexpr size_t kAbiParams10 = 56, kAbiResult10 = 120, kAbiProfile10 = 360;
+// the shortest structs a caller may hand over (icpgpu_create_abi): the layouts of icpgpu.h 0.4, of which 1.0's are extensions (1.0
+// added icpgpu_result.gicp_solver; the floor sits one step below the first sized release so that the min-copy rule has a shorter
+// caller to be tested with: tests/test_gpu_errors.py)
+constexpr size_t kAbiParams10 = 56, kAbiResult10 = 112, kAbiProfile10 = 352;
 static_assert(sizeof(icpgpu_params) >= kAbiParams10 && sizeof(icpgpu_result) >= kAbiResult10 && sizeof(icpgpu_profile) >= kAbiProfile10,
               "public structs only grow (include/icpgpu.h, ABI rule)");
 inline int gicp_device_solver_mode() {  // 0 host, 1 device, 2 measured
@@ -221,6 +223,17 @@ struct icpgpu_ctx {
   GridIndex cov_grid_src, cov_grid_tgt;
   bool cov_timing_pending = false;  // ev[2] .. ev[3] bracket a covariance pass whose duration has not been read yet (resolve_cov_timing)
   double cov_h_hint = 0.0, cov_h_hint_cut = 0.0;  // the cell size the last covariance grid settled on (ensure_covariances)
+  // A covariance grid built WITHOUT waiting for its occupancy statistics (icpgpu_gicp.cpp: ensure_covariances, speculative form):
+  // the statistics were posted into the mailbox (pairs 32..) behind the count pass and are looked at when the alignment first
+  // waits for the device anyway; `cooldown` alignments after one that failed the check go the waiting way.
+  struct SpecGrid {
+    bool pending = false;
+    unsigned long long number = 0;  // the post's sequence number
+    uint64_t serial = 0;            // GridIndex::serial of the build
+    int n = 0;                      // points the cloud holds: all of them must have been binned
+    double h = 0.0, knn_population = 0.0, cut = 0.0;
+  } spec_grid;
+  int spec_cooldown = 0;
   DeviceBuf cov_src, cov_tgt, maha;
   uint64_t cov_src_version = 0, cov_tgt_version = 0;
   // Per-iteration result mailbox in pinned, mapped host memory: 17 sums + 17 sequence flags.  The final reduction
@@ -456,6 +469,7 @@ int promote_internal(icpgpu_ctx* c);
 int gb_begin(icpgpu_ctx* c, GridBuild& b, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
              const int* orig_index = nullptr, double knn_population = 0.0, double h_start = 0.0);
 int gb_advance(icpgpu_ctx* c, GridBuild& b);
+int gb_finish_unchecked(icpgpu_ctx* c, GridBuild& b);  // WaitCount -> Done without the statistics (the caller checks them later)
 int build_grid(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, double cut, bool adapt, GridIndex& G,
                const int* orig_index = nullptr, double knn_population = 0.0, double h_start = 0.0);
 int ensure_grid(icpgpu_ctx* c, float accept_thr);
@@ -495,7 +509,8 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
 int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough,
                         int* bbox_enc_out = nullptr);
 // icpgpu_gicp.cpp
-int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version);
+int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version, bool allow_unchecked = false);
+int covariance_grid_check(icpgpu_ctx* c);
 int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_fitness, icpgpu_result* res);
 int gicp_run_begin(icpgpu_ctx* c, GicpRun& r, int want_fitness, icpgpu_result* res, bool combine = false);
 int gicp_run_step(icpgpu_ctx* c, GicpRun& r);  // < 0 error, 0 nothing yet, 1 moved on (r.phase == GicpRun::Done: finished)

@@ -37,7 +37,7 @@ namespace {
 
 constexpr int kRecordLen = 23;  // pair_id, iterations, converged, state, n_corr, mse, fitness, T[16] row-major (sharding.py)
 
-constexpr size_t kAbiParams10 = 56, kAbiResult10 = 120;  // sizes of the public structs in icpgpu.h 1.0 (icp_ctx.h holds the same constants)
+constexpr size_t kAbiParams10 = 56, kAbiResult10 = 112;  // the shortest structs a caller may hand over (icp_ctx.h holds the same constants)
 
 thread_local std::string g_multi_error;
 int multi_fail(int code, const char* fmt, ...) {

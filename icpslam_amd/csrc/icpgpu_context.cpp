@@ -388,7 +388,7 @@ int icpgpu_create_abi(icpgpu_ctx** out_ctx, int device_id, int header_version, s
   if (header_version / 1000 != ICPGPU_VERSION_MAJOR)
     return fail(nullptr, ICPGPU_ERR_UNSUPPORTED, "the caller was built against icpgpu.h %d.%d, this library is %d.%d: another major version",
                 header_version / 1000, header_version % 1000, ICPGPU_VERSION_MAJOR, ICPGPU_VERSION_MINOR);
-  // 1.0's structs are the shortest a caller of this major version can have
+  // (the floor: icp_ctx.h)
   if (sizeof_params < kAbiParams10 || sizeof_result < kAbiResult10 || sizeof_profile < kAbiProfile10 || sizeof_params > 4096 ||
       sizeof_result > 4096 || sizeof_profile > 65536)
     return fail(nullptr, ICPGPU_ERR_INVALID_ARG, "struct sizes %zu / %zu / %zu are not those of an icpgpu.h 1.x (at least %zu / %zu / %zu)",
@@ -532,8 +532,9 @@ int create_context(icpgpu_ctx** out_ctx, int device_id, bool with_stream) {
   c->pending.reserve(kEventRing);
   {
     void* hp = nullptr;
-    if ((e = hipHostMalloc(&hp, 32 * 16, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
-    std::memset(hp, 0, 32 * 16);
+    // 32 result pairs for fetch_ints and the markers, 8 more for the statistics of a covariance grid built ahead of them (spec_grid)
+    if ((e = hipHostMalloc(&hp, 40 * 16, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+    std::memset(hp, 0, 40 * 16);
     c->h_post = static_cast<volatile unsigned long long*>(hp);
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_post_dev), hp, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
   }

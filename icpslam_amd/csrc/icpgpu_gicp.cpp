@@ -78,12 +78,37 @@ static int cov_launch(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridI
   return ICPGPU_OK;
 }
 
-int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version) {
+// allow_unchecked (align_gicp, the source cloud): when the cloud brings a containing box (the voxel filter's) and the context a proven
+// cell size (the last covariance grid's), the build does not wait for the count pass's statistics -- count, scan, scatter and the
+// covariance pass are queued in one go, the statistics are posted behind the count pass and checked by covariance_grid_check() when
+// the alignment first waits for the device anyway.  (Per scan of the reference's pipeline this was the one remaining host round trip
+// of the index build: ~110 us of host wall in front of a 96 us kernel)
+int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version, bool allow_unchecked) {
   GridBuild b;
   b.post = true;  // (the read-backs go through fetch_ints, as in build_grid)
   bool needed = false;
   int rc = cov_grid_begin(c, cloud, version, G, cov, cov_version, b, needed);
   if (rc || !needed) return rc;
+  static const bool unchecked_enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_COV_GRID_UNCHECKED"); return !e || std::atoi(e) != 0; }();
+  if (allow_unchecked && unchecked_enabled && b.state == GridBuild::WaitCount && b.h_start > 0.0 && !c->spec_grid.pending) {
+    if (c->spec_cooldown > 0) {
+      c->spec_cooldown -= 1;
+    } else {
+      const int* d_ints = static_cast<const int*>(G.ints.ptr);
+      const unsigned long long number = ++c->post_seq;
+      HIP_TRY(c, launch_post_ints(d_ints + 6, kGridStatInts, c->h_post_dev + 2 * 32, wire_seq(c, number), c->stream));
+      if ((rc = gb_finish_unchecked(c, b))) return rc;
+      c->spec_grid.pending = true;
+      c->spec_grid.number = number;
+      c->spec_grid.serial = G.serial;
+      c->spec_grid.n = (int)cloud.n;
+      c->spec_grid.h = b.h;
+      c->spec_grid.knn_population = b.knn_population;
+      c->spec_grid.cut = b.cut;
+      c->prof.cov_grids_unchecked += 1;
+      return cov_launch(c, cloud, version, G, cov, cov_version, /*timed=*/true);
+    }
+  }
   while (!rc && b.state != GridBuild::Done) {
     const int* d_ints = static_cast<const int*>(G.ints.ptr);
     if (b.state == GridBuild::WaitBbox) rc = fetch_ints(c, d_ints, 6, c->h_ints);
@@ -92,6 +117,77 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
   }
   if (rc) return rc;
   return cov_launch(c, cloud, version, G, cov, cov_version, /*timed=*/true);
+}
+
+// The statistics of a covariance grid that was built ahead of them (above): 0 = none pending or all is well (the grid's
+// population figures and the context's cell-size hint are brought up to date), 1 = the build has to be repeated the waiting way
+// (a point outside the box it was given, a non-finite point, a cell beyond kMaxCellPopulation: the source's covariances and its
+// grid are invalidated, the caller starts over), < 0 = error.  The post was queued right behind the count pass: by the time an
+// alignment has queued its covariance pass, its first search and its first evaluation the pairs have long arrived.
+int covariance_grid_check(icpgpu_ctx* c) {
+  if (!c->spec_grid.pending) return 0;
+  c->spec_grid.pending = false;
+  const unsigned long long number = c->spec_grid.number;
+  const volatile unsigned long long* box = c->h_post + 2 * 32;
+  int v[kGridStatInts];
+  std::chrono::steady_clock::time_point t0;
+  for (unsigned spins = 1;; ++spins) {
+    bool all = true;
+    for (int k = 0; k < kGridStatInts && all; ++k) all = (box[2 * k + 1] >> 24) == number;
+    if (all) {
+      unsigned long long bits;
+      for (int k = 0; k < kGridStatInts && all; ++k) {
+        all = mailbox_read(box + 2 * k, number, &bits);
+        if (all) v[k] = (int)(unsigned int)bits;
+      }
+      if (all) break;
+    }
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a grid's statistics: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a grid's statistics (hung kernel?)", wait_timeout_ms());
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  unsigned long long sumsq = 0;
+  std::memcpy(&sumsq, v + 2, sizeof sumsq);
+  const int max_pop = v[1], binned = v[4];
+  GridIndex* G = c->cov_grid_src.serial == c->spec_grid.serial ? &c->cov_grid_src : (c->cov_grid_tgt.serial == c->spec_grid.serial ? &c->cov_grid_tgt : nullptr);
+  // development flavour, ICPGPU_COV_GRID_UNCHECKED=2: every check fails (the tests of the start-over path)
+  static const bool fail_all = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_COV_GRID_UNCHECKED"); return e && std::atoi(e) == 2; }();
+  if (binned != c->spec_grid.n || max_pop > kMaxCellPopulation || fail_all) {
+    c->prof.cov_grids_rebuilt += 1;
+    c->spec_cooldown = fail_all ? 1 : 64;
+    if (std::getenv("ICPGPU_DEBUG"))
+      fprintf(stderr, "[icpgpu] covariance grid built ahead of its statistics: %d of %d points binned, largest cell %d -> rebuilt the waiting way\n", binned,
+              c->spec_grid.n, max_pop);
+    // whichever role the cloud has by now: its grid, its covariances and its cached box are not to be trusted
+    for (int role = 0; role < 2; ++role) {
+      GridIndex& V = role ? c->cov_grid_tgt : c->cov_grid_src;
+      if (V.serial != c->spec_grid.serial) continue;
+      V.built = V.usable = false;
+      (role ? c->cov_tgt_version : c->cov_src_version) = 0;
+      (role ? c->tgt : c->src).bbox_version = 0;
+    }
+    return 1;
+  }
+  const double pop = binned > 0 ? (double)sumsq / (double)binned : 0.0;
+  if (G) {
+    G->max_pop = max_pop;
+    G->point_population = pop;
+  }
+  // the hint follows the rule gb_on_count applies to a first count pass: a population within a factor of two of the aim keeps the
+  // cells, another one gets the cells it would have been re-counted with -- for the NEXT cloud
+  const double aim = c->spec_grid.knn_population, h = c->spec_grid.h;
+  if (aim > 0.0 && pop > 0.0 && (pop > 2.0 * aim || pop < 0.5 * aim))
+    c->cov_h_hint = std::min(std::max(h * std::sqrt(aim / pop), c->spec_grid.cut / 64.0), 8.0 * h);
+  return 0;
 }
 
 // the duration of the last covariance pass into the profile (waits for its end if need be: callers sit behind a result anyway)
@@ -343,6 +439,12 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
     icpgpu_ctx* c;
     ~ServerGuard() { gicp_server_stop(c); }
   } server_guard{c};
+  struct SpecGuard {  // ... and no covariance grid whose statistics nobody has looked at
+    icpgpu_ctx* c;
+    ~SpecGuard() {
+      if (c->spec_grid.pending) (void)covariance_grid_check(c);
+    }
+  } spec_guard{c};
   const auto t_start = std::chrono::steady_clock::now();
   // development flavour, ICPGPU_GICP_TIMING=1: host wall per stage (printed by icpgpu_destroy)
   static const bool stage_timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_TIMING"); return e && std::atoi(e) != 0; }();
@@ -382,7 +484,7 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
 
   int rc;
   if ((rc = ensure_covariances(c, c->tgt, c->tgt_version, c->cov_grid_tgt, c->cov_tgt, c->cov_tgt_version))) return rc;
-  if ((rc = ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version))) return rc;
+  if ((rc = ensure_covariances(c, c->src, c->src_version, c->cov_grid_src, c->cov_src, c->cov_src_version, /*allow_unchecked=*/true))) return rc;
   mark(0);
   // GICP keeps d2 < r^2 (strict): the largest float below r^2
   const double r2 = P.max_correspondence_distance * P.max_correspondence_distance;
@@ -439,6 +541,17 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
                                          static_cast<const double*>(c->cov_tgt.ptr), maha, c->stream));
     if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
     mark(2);
+    // the source's covariance grid was built ahead of its statistics (ensure_covariances): they have arrived by now -- the covariance
+    // pass, this search and the Mahalanobis kernel were queued behind them.  A grid that failed (a point outside the box it was
+    // given) is rebuilt the waiting way and the alignment starts over; nothing of it has reached the host yet.
+    if (c->spec_grid.pending) {
+      const int chk = covariance_grid_check(c);
+      if (chk < 0) return chk;
+      if (chk == 1) {
+        c->prof.aligns -= 1;
+        return align_gicp(c, guess_in, out_xyzw, want_fitness, res);
+      }
+    }
 
     // rigid_transformation_estimation_: BFGS over x = (t, roll, pitch, yaw), every evaluation one reduction on the device
     double m_count = 0.0;

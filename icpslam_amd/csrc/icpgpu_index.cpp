@@ -241,6 +241,34 @@ int gb_on_count(icpgpu_ctx* c, GridBuild& b) {
   return ICPGPU_OK;
 }
 
+// A build whose count pass is queued (state WaitCount), finished WITHOUT its statistics: the cells stay as they were chosen, every
+// point is ASSUMED binned.  For callers that know a containing box and a proven cell size (ensure_covariances with the box the voxel
+// filter handed over and the last cloud's cell size) and check the statistics -- still in G.ints behind the count pass -- when
+// they next wait for the device: one host round trip less per cloud.  The neighbours a search over this grid returns are exact
+// whatever the cells are; only `every point binned` is a matter of correctness, and that is what the later check is for.
+int gb_finish_unchecked(icpgpu_ctx* c, GridBuild& b) {
+  if (b.state != GridBuild::WaitCount) return fail(c, ICPGPU_ERR_INVALID_ARG, "gb_finish_unchecked: no count pass in flight");
+  GridIndex& G = *b.G;
+  const int n_t = (int)b.cloud->n;
+  int* d_ints = static_cast<int*>(G.ints.ptr);
+  G.n_binned = n_t;
+  G.max_pop = 0;
+  G.point_population = b.knn_population > 0.0 ? b.knn_population : kTargetCellPopulation;
+  int rc;
+  if ((rc = ensure(c, G.sorted, (size_t)n_t * sizeof(float4)))) return rc;
+  HIP_TRY(c, launch_grid_finish(b.cloud->data(), n_t, b.g, static_cast<const int*>(G.cell_of_point.ptr),
+                                static_cast<const int*>(G.rank.ptr), static_cast<int*>(G.cell_start.ptr),
+                                static_cast<int*>(G.block_sums.ptr), d_ints + 6, b.orig_index, static_cast<float4*>(G.sorted.ptr), c->stream));
+  c->prof.grid_builds += 1;
+  c->prof.grid_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b.t0).count();
+  G.g = b.g;
+  G.usable = n_t > 0;
+  static std::atomic<uint64_t> g_spec_serial{1ull << 62};  // (its own range: never equal to a checked build's serial)
+  G.serial = ++g_spec_serial;
+  b.state = GridBuild::Done;
+  return ICPGPU_OK;
+}
+
 // after the caller has synchronised the build's stream
 int gb_advance(icpgpu_ctx* c, GridBuild& b) {
   if (b.state == GridBuild::WaitBbox) return gb_on_bbox(c, b);

@@ -206,6 +206,10 @@ typedef struct {
   uint64_t gicp_solver_choice;     /* the solver single GICP alignments of this context run on: 1 = host loop, 2 = device solver; never 0
                                     * since 1.0 (set at icpgpu_create from ICPGPU_GICP_DEVICE, changed only by icpgpu_calibrate) -- 0.3 */
   uint64_t gicp_quadratic_solves;  /* GICP outer iterations solved on the quadratic form (icpgpu_params.gicp_inner = QUADRATIC) -- 0.4 */
+  uint64_t cov_grids_unchecked;    /* GICP: covariance grids built without waiting for their occupancy statistics (a containing box from
+                                    * the voxel filter + the last cloud's cell size; the statistics are checked at the alignment's first
+                                    * wait) -- 1.0 */
+  uint64_t cov_grids_rebuilt;      /* ... of which the check failed: rebuilt the waiting way, the alignment started over -- 1.0 */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -148,7 +148,7 @@ def test_map_get_points_capacity_is_checked(ctx):
 
 def test_callers_with_shorter_and_longer_structs(built):
     """include/icpgpu.h, "ABI rule", on a device: a context created by a caller whose structs are SHORTER than the library's (an older
-    1.x header: here icpgpu_result without gicp_solver, icpgpu_params without gicp_inner's word, a profile without its last field)
+    header: here icpgpu_result without gicp_solver and a profile without its last field -- the floor icpgpu_create_abi accepts)
     gets exactly its bytes written -- the guard bytes behind its structs stay untouched -- and the same numbers; a caller with LONGER
     structs gets the tail zeroed; batches honour the caller's stride."""
     L = _lib.load()

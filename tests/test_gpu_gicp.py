@@ -454,3 +454,67 @@ def test_solver_choice_is_fixed_at_creation_recorded_per_result_and_calibrate_is
         assert [r["gicp_solver"] for r in again] == [choice] * 3
         assert all(r["T"].tobytes() == firsts[0]["T"].tobytes() and r["fitness"] == firsts[0]["fitness"] for r in again)
         print(f"icpgpu_calibrate on this box: {'device solver' if choice == 2 else 'host loop'}")
+
+
+def test_covariance_grid_built_ahead_of_its_statistics(built, tmp_path):
+    """Round 6: per scan of the reference's pipeline (VoxelGrid + GICP, icp_odometer.cpp:177,188-198) the source's
+    covariance grid is built WITHOUT the host waiting for the count pass's statistics -- the box comes from the filter, the cell size
+    from the last cloud, the statistics are checked when the alignment first waits anyway.  Over a filtered drive: the profile says
+    the builds were unchecked and none had to be repeated, and every registration is bit-identical to the oracle (the neighbours
+    are exact whatever the cells).  Development flavour: the same drive with the mechanism off (=0) and with every check made to
+    FAIL (=2: grid and covariances invalidated, rebuilt the waiting way, the alignment started over) gives the same bits."""
+    import subprocess
+    import sys
+    from icpslam_amd import Context
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scene = synth.make_scene(5, extent=120.0)
+    rng = np.random.default_rng(5)
+    poses = [np.eye(4)]
+    for _ in range(6):
+        poses.append(poses[-1] @ synth.pose_matrix(0.25, 0.0, 0.0, 0.0, 0.0, np.deg2rad(rng.uniform(-3, 3))))
+    scans = [synth.scan(scene, P, 60000, seed=7100 + k) for k, P in enumerate(poses)]
+    np.savez(tmp_path / "scans.npz", *scans)
+    with Context(0) as c:
+        c.set_params(c.default_params(), method=GICP, max_iterations=10)
+        c.set_source_voxel_filtered(scans[0], 0.2)
+        c.promote_source_to_target()
+        got = []
+        for k in range(1, len(scans)):
+            c.set_source_voxel_filtered(scans[k], 0.2)
+            got.append(c.align(want_fitness=True))
+            c.promote_source_to_target()
+        p = c.profile()
+    assert p.cov_grids_unchecked >= len(scans) - 3 and p.cov_grids_rebuilt == 0, (p.cov_grids_unchecked, p.cov_grids_rebuilt)
+    for k in range(1, len(scans)):
+        s, t = oracle.voxel_grid(scans[k], 0.2), oracle.voxel_grid(scans[k - 1], 0.2)
+        ref = oracle.icp_align(s, t, oracle.default_params(method=oracle.GICP, max_iterations=10), want_fitness=True)
+        g = got[k - 1]
+        assert (g["iterations"], g["n_corr"], g["converged"]) == (ref["iterations"], ref["n_corr"], ref["converged"]), k
+        assert np.array_equal(g["T"].view(np.uint32), np.asarray(ref["T"], np.float32).view(np.uint32)), k
+        assert abs(g["fitness"] - ref["fitness"]) <= 1e-9 * max(1.0, ref["fitness"])
+    code = (
+        "import sys, numpy as np\n"
+        "from icpslam_amd import Context, GICP\n"
+        "z = np.load(sys.argv[1]); scans = [z[k] for k in z.files]\n"
+        "with Context(0) as c:\n"
+        "    c.set_params(c.default_params(), method=GICP, max_iterations=10)\n"
+        "    c.set_source_voxel_filtered(scans[0], 0.2); c.promote_source_to_target()\n"
+        "    for k in range(1, len(scans)):\n"
+        "        c.set_source_voxel_filtered(scans[k], 0.2)\n"
+        "        r = c.align(want_fitness=True)\n"
+        "        c.promote_source_to_target()\n"
+        "        print(r['T'].tobytes().hex(), r['iterations'], r['n_corr'], float(r['fitness']).hex())\n"
+        "    p = c.profile()\n"
+        "print('profile', p.cov_grids_unchecked, p.cov_grids_rebuilt)\n")
+    want = [f"{g['T'].tobytes().hex()} {g['iterations']} {g['n_corr']} {float(g['fitness']).hex()}" for g in got]
+    for flag in ("0", "2"):
+        env = dict(os.environ, ICPGPU_FLAVOUR="dev", ICPGPU_COV_GRID_UNCHECKED=flag, PYTHONPATH=root)
+        res = subprocess.run([sys.executable, "-c", code, str(tmp_path / "scans.npz")], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = res.stdout.strip().splitlines()
+        assert lines[:-1] == want, flag
+        unchecked, rebuilt = (int(x) for x in lines[-1].split()[1:])
+        if flag == "0":
+            assert unchecked == 0 and rebuilt == 0
+        else:
+            assert unchecked >= 2 and rebuilt == unchecked      # every build that went ahead was caught and repeated
