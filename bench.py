@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--multi-entry", action="store_true",
                     help="batch50k through the C multi-GPU entry (icpgpu_align_batch_multi): ONE process, one host thread per GPU, "
                          "ncclAllGather of the records -- what INTEGRATION.md section 3 recommends to a C++ host; --gpus N = N device entries")
+    ap.add_argument("--steady-seconds", type=float, default=1.5, help="length of the steady-state loop behind the timed region")
     ap.add_argument("--secondary-scans", type=int, default=50, help="scans in each secondary (e2e / GICP / pipeline) loop")
     a = ap.parse_args()
     batch = WORKLOADS[a.workload][2] == "batch"
@@ -430,7 +431,7 @@ def main():
     # Right behind the timed region, on rank 0: a DENSE pass for the roofline -- the same alignments with EVERY sweep's kernel
     # bracketed by HIP events (the timed region samples one sweep in 13, because the event records are barrier packets that cost
     # 6-7 us apiece and would slow `value` down: 15 timed launches at the driver's --steps 20).  Reported beside the sampled figure.
-    dense = None
+    dense = steady = None
     if rank == 0 and not batch and not a.no_extras:
         ctx.profile_sampling(1)
         ctx.profile_reset()
@@ -440,6 +441,25 @@ def main():
         if pd.grid_timed:
             dense = {"avg_launch_ms": pd.grid_ms / pd.grid_timed, "timed_launches": int(pd.grid_timed), "alignments": 20}
         ctx.profile_sampling(13)
+        # ... and a STEADY-STATE loop of the same step for >= 1 s (the driver's --steps 20 is 15 ms of timed region: a busy
+        # figure of a few per cent says nothing about the rate a sequence runs at) -- a secondary figure, `value` stays the K steps
+        ctx.profile_reset()
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        n_steady = 0
+        while time.perf_counter() - t_s < a.steady_seconds:
+            for _ in range(50):
+                step()
+            n_steady += 50
+        torch.cuda.synchronize()
+        steady_s = time.perf_counter() - t_s
+        ps = ctx.profile()
+        steady = {"seconds": steady_s, "steps": n_steady, "iterations_per_sec": int(ps.iterations) / steady_s,
+                  "ms_per_step": 1e3 * steady_s / max(1, n_steady),
+                  "sampled_avg_launch_ms": ps.grid_ms / max(1, ps.grid_timed), "sampled_launches": int(ps.grid_timed),
+                  "kernel_busy_frac": (ps.grid_ms / max(1, ps.grid_timed)) * int(ps.grid_launches) / (1e3 * steady_s),
+                  "how": "the timed region's step repeated for --steady-seconds behind it, same context, one sweep in 13 timed; "
+                         "kernel_busy_frac = the search kernel's sampled mean x its launches / wall"} if n_steady else None
     iters_done = int(prof.iterations)
     pairs_done = int(prof.aligns)
     if world > 1:
@@ -674,7 +694,10 @@ def main():
                 "source": f"{BRUTE_VALU_INSTS_PER_PAIR:g} VALU instructions per pair and lane (ISA of the inner loop) x Ns x Nt / 64 "
                           "lanes / the live launch time; same peak as the grid kernel's `issue`"}
         if used_grid and prof.grid_timed and not batch:
-            g_ms = prof.grid_ms / max(1, prof.grid_timed)
+            s_ms = prof.grid_ms / max(1, prof.grid_timed)   # the timed region's sampled launches
+            # `avg_launch_ms` / `achieved` / `frac` come from the DENSE pass (every launch of 20 alignments between HIP events: 200
+            # launches) when it ran; the timed region's own sample (15 launches at the driver's --steps 20) stays beside it
+            g_ms = dense["avg_launch_ms"] if dense else s_ms
             gbs = alg_bytes_fused / (g_ms * 1e-3) / 1e9
             roofline = {
                 "kernel": "nn_quad_kernel<fused> (uniform-grid exact NN, four points per wave pass, + rejection + 17-term reduction)",
@@ -685,15 +708,20 @@ def main():
                                   "(sha256 over icp_grid.hip + icp_grid_device.h, embedded by the collection scripts)",
                 "pmc_stale": bool(traffic_stale),
                 "kernel_source_sha256": src_hash,
-                "avg_launch_ms": g_ms, "launches": int(prof.grid_launches), "timed_launches": int(prof.grid_timed),
-                "timed_launches_how": "HIP-event triples on the context's stream around one sweep in 13 (13 is coprime with the 10 sweeps of an "
-                                      "alignment, so over the timed steps every sweep position -- the cold first one to the converged tenth -- "
-                                      "is sampled equally often); avg_launch_ms = their mean",
+                "avg_launch_ms": g_ms, "launches": int(prof.grid_launches),
+                "timed_launches": int(dense["timed_launches"]) if dense else int(prof.grid_timed),
+                "timed_launches_how": ("DENSE pass: 20 more alignments right behind the timed region with EVERY sweep's launch between HIP "
+                                       "events on the context's stream; avg_launch_ms = their mean" if dense else
+                                       "HIP-event triples on the context's stream around one sweep in 13 of the timed region"),
                 "algorithmic_bytes_per_launch": alg_bytes_fused,
-                "dense_pass": (dict(dense, achieved=alg_bytes_fused / (dense["avg_launch_ms"] * 1e-3) / 1e9,
-                                    frac=alg_bytes_fused / (dense["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    how="20 more alignments right behind the timed region with every sweep's launch between HIP events")
-                               if dense else None),
+                "sampled_in_timed_region": {
+                    "avg_launch_ms": s_ms, "timed_launches": int(prof.grid_timed),
+                    "achieved": alg_bytes_fused / (s_ms * 1e-3) / 1e9, "frac": alg_bytes_fused / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "how": "one sweep in 13 of the K timed steps (13 is coprime with the 10 sweeps of an alignment, so every sweep position "
+                           "-- the cold first one to the converged tenth -- is sampled equally often; event records are barrier packets "
+                           "of 6-7 us, so the timed region cannot time every launch)"},
+                "dense_pass": dense,
+                "steady_state": steady,
                 "note": "dominant kernel of the default (AUTO) path; algorithmic bytes = both clouds once + 64 B of sums "
                         "(SURVEY.md 8(d) fused lower bound).  An exact NN search does not stream; `issue` gives its VALU "
                         "issue rate against the SIMD-32 peak (it sits well below it: the kernel is latency / dependency "
@@ -730,6 +758,11 @@ def main():
                     "useful_tflops": (8.0 * cand / (g_ms * 1e-3) / 1e12) if cand else None,
                     "useful_flop_frac_of_fp32_peak": (8.0 * cand / (g_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if cand else None,
                     "source": issue_pmc.get("_how", "profiles/pmc_issue.json")}
+                # the roofline that BINDS this kernel, beside `bound: hbm` (the one the metric names)
+                roofline["binding"] = {"bound": "valu_issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instr/s",
+                                       "frac": ginst / VALU_ISSUE_PEAK_GINST, "frac_of_mix_peak": ginst / mix_peak,
+                                       "why": "an exact NN search walks an index: 152 vector instructions per source point against 32 "
+                                              "algorithmic bytes; details under `issue`"}
             if brute_roofline:
                 roofline["brute_force_kernel"] = brute_roofline
         elif batch:
