@@ -18,7 +18,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_NO_INPUT, ERR_UNSUPPOR
 P2P_SVD, GICP = 0, 1
 GICP_INNER_EXACT, GICP_INNER_QUADRATIC = 0, 1
 GICP_SOLVER_NONE, GICP_SOLVER_HOST, GICP_SOLVER_DEVICE, GICP_SOLVER_QUADRATIC = 0, 1, 2, 3
-HEADER_VERSION = 1000          # the icpgpu.h these mirrors were written against (ICPGPU_HEADER_VERSION)
+HEADER_VERSION = 1001          # the icpgpu.h these mirrors were written against (ICPGPU_HEADER_VERSION)
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 STATE_NAMES = {0: "NOT_CONVERGED", 1: "ITERATIONS", 2: "TRANSFORM", 3: "ABS_MSE", 4: "REL_MSE",
                5: "NO_CORRESPONDENCES"}
@@ -55,7 +55,7 @@ class Profile(C.Structure):
                 ("brute_bound_worst", C.c_double), ("gicp_device_solves", C.c_uint64),
                 ("grid_adopted", C.c_uint64), ("sources_adopted", C.c_uint64), ("gicp_host_solves", C.c_uint64),
                 ("gicp_solver_choice", C.c_uint64), ("gicp_quadratic_solves", C.c_uint64),
-                ("cov_grids_unchecked", C.c_uint64), ("cov_grids_rebuilt", C.c_uint64)]
+                ("cov_grids_unchecked", C.c_uint64), ("cov_grids_rebuilt", C.c_uint64), ("voxel_views_direct", C.c_uint64)]
 
 
 class Pose(C.Structure):
@@ -66,11 +66,11 @@ class Pose(C.Structure):
 EXPORTS = [
     "icpgpu_create_abi", "icpgpu_destroy", "icpgpu_last_error", "icpgpu_version", "icpgpu_default_params_sz", "icpgpu_struct_sizes",
     "icpgpu_calibrate", "icpgpu_set_params", "icpgpu_get_params", "icpgpu_set_source", "icpgpu_set_target",
-    "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align",
+    "icpgpu_set_source_device", "icpgpu_set_target_device", "icpgpu_promote_source_to_target", "icpgpu_align", "icpgpu_align_view",
     "icpgpu_fingerprint", "icpgpu_cloud_sizes", "icpgpu_align_batch_multi_sz", "icpgpu_multi_last_error",
     "icpgpu_fitness", "icpgpu_align_batch", "icpgpu_nn", "icpgpu_reduce", "icpgpu_solve", "icpgpu_transform",
     "icpgpu_profile_reset", "icpgpu_profile_get", "icpgpu_profile_set_sampling", "icpgpu_get_stream", "icpgpu_synchronize",
-    "icpgpu_voxel_grid", "icpgpu_voxel_grid_fetch", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
+    "icpgpu_voxel_grid", "icpgpu_voxel_grid_fetch", "icpgpu_voxel_grid_view", "icpgpu_set_source_voxel_filtered", "icpgpu_gicp_covariances",
     "icpgpu_gicp_quadratic_eval", "icpgpu_gicp_quadratic_sums",
     "icpgpu_pose_from_matrix", "icpgpu_pose_to_matrix", "icpgpu_pose_compose", "icpgpu_pose_inverse", "icpgpu_posegraph_create",
     "icpgpu_posegraph_destroy", "icpgpu_posegraph_set_initial_pose", "icpgpu_posegraph_push",
@@ -125,6 +125,7 @@ def load():
     L.icpgpu_fingerprint.restype = C.c_uint64
     L.icpgpu_cloud_sizes.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.icpgpu_align.argtypes = [vp, fp, fp, C.c_int, C.POINTER(Result)]
+    L.icpgpu_align_view.argtypes = [vp, fp, C.c_int, C.POINTER(Result), C.POINTER(fp), C.POINTER(C.c_size_t)]
     L.icpgpu_fitness.argtypes = [vp, C.c_double, dp]
     L.icpgpu_align_batch.argtypes = [vp, C.c_size_t, C.POINTER(fp), C.POINTER(C.c_size_t), C.POINTER(fp),
                                      C.POINTER(C.c_size_t), C.c_int, C.POINTER(Result)]
@@ -142,6 +143,7 @@ def load():
     L.icpgpu_gicp_quadratic_sums.argtypes = [vp, fp, dp]
     L.icpgpu_voxel_grid.argtypes = [vp, fp, C.c_size_t, C.c_float, fp, C.POINTER(C.c_size_t)]
     L.icpgpu_voxel_grid_fetch.argtypes = [vp, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.icpgpu_voxel_grid_view.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(fp), C.POINTER(C.c_size_t)]
     L.icpgpu_set_source_voxel_filtered.argtypes = [vp, fp, C.c_size_t, C.c_float, C.POINTER(C.c_size_t)]
     pp, lp = C.POINTER(Pose), C.POINTER(C.c_long)
     L.icpgpu_pose_from_matrix.argtypes = [fp, pp]

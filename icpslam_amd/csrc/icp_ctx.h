@@ -308,15 +308,19 @@ struct icpgpu_ctx {
   int timing_every = 13;      // time one sweep in 13 (coprime with the 10 / 30 iterations of the reference's aligns; 7 until round 2: an event triple costs 6-7 us)
   unsigned sweep_counter = 0;
   int* h_ints = nullptr;     // pinned (16 ints: bbox / stats / counters)
-  void* h_stage = nullptr;   // pinned staging for results that go to the caller's pageable buffers (copy_to_host)
+  void* h_stage = nullptr;   // pinned, mapped staging for results that go to the caller's pageable buffers (copy_to_host; round 6:
+  void* h_stage_dev = nullptr;  // kernels write result clouds straight into it -- output_cloud_issue, icpgpu_voxel_grid_view)
   size_t h_stage_cap = 0;
-  volatile unsigned long long* h_post = nullptr;  // mapped, coherent: 32 result pairs for fetch_ints (icpgpu_context.cpp)
+  bool want_view = false;       // the entry point in progress hands the staged cloud out as a view (no copy to a caller's buffer)
+  volatile unsigned long long* h_post = nullptr;  // mapped, coherent: 32 result pairs for fetch_ints, 8 for a grid's statistics
+                                                  // (spec_grid), 8 for a staged cloud's marker (stage_post) -- icpgpu_context.cpp
   unsigned long long* h_post_dev = nullptr;
   unsigned long long post_seq = 0;
   bool have_final = false;
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
   int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
+  DeviceBuf cov_list;  // GICP covariances: the points the selecting kernel leaves to the streaming one (count + indices)
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
   DeviceBuf vox_bins, vox_pub;   // ... of the direct (no library sort) path: self-cleaning histogram + group ranges; published counts
   size_t vox_last_n = 0;         // points of the last icpgpu_voxel_grid result (still in vox_out)
@@ -404,6 +408,12 @@ struct SweepTicket {
 // have arrived -- does the host's share of an iteration (Umeyama / SVD, convergence test: icp_solver.cpp) and queues the
 // next sweep, the fitness sweep, or finishes.  icpgpu_align drives one run to the end; icpgpu_align_batch keeps several
 // contexts' runs in flight from one host thread.
+struct StageTicket {  // a cloud on its way into the pinned staging buffer (stage_post / stage_wait below)
+  unsigned long long number = 0;
+  int n_ints = 0;
+  bool issued = false;
+};
+
 struct P2PRun {
   enum Phase { Idle, Iterating, Fitness, Done } phase = Idle;
   Mat4d final_T = mat4_identity();
@@ -416,6 +426,8 @@ struct P2PRun {
   SweepTicket ticket;
   icpgpu_result* res = nullptr;
   float* out_xyzw = nullptr;
+  StageTicket out_ticket;  // the aligned cloud, queued in front of the fitness sweep (p2p_advance), taken out while the sweep runs
+  bool out_done = false;   // ... it has been (align_p2p) -- p2p_finish has nothing left to write
   std::chrono::steady_clock::time_point t_start, t_issue;
 };
 
@@ -457,6 +469,14 @@ float threshold_from(double r2);
 int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst);
 unsigned long long sample_fingerprint(const float* xyzw, size_t n);
 int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, const int* d_extra = nullptr, int n_extra = 0, int* extra_out = nullptr);
+// The staging buffer as a target of kernels: at least `bytes` of pinned, mapped, coherent host memory (c->h_stage / h_stage_dev);
+// ICPGPU_ERR_UNSUPPORTED above kStageMaxBytes unless `any_size` (views have nowhere else to go).
+constexpr size_t kStageMaxBytes = 8u << 20;
+int ensure_stage(icpgpu_ctx* c, size_t bytes, bool any_size = false);
+// A marker behind whatever was queued to fill the staging buffer (<= 8 ints of device memory ride on it), and the wait for it:
+// when stage_wait returns, everything the stream wrote to host memory before the marker is visible.  (StageTicket: above P2PRun)
+int stage_post(icpgpu_ctx* c, const int* d_ints, int n_ints, StageTicket& tk);
+int stage_wait(icpgpu_ctx* c, StageTicket& tk, int* ints_out);
 int set_cloud_host(icpgpu_ctx* c, Cloud& cl, const float* xyzw, size_t n, bool sync = true);
 int set_cloud_device(icpgpu_ctx* c, Cloud& cl, const void* d_xyzw, size_t n);
 int ensure_gicp_resources(icpgpu_ctx* c);
@@ -499,6 +519,12 @@ bool sweep_ready(const icpgpu_ctx* c, const SweepTicket& tk);
 int sweep_complete(icpgpu_ctx* c, SweepTicket& tk);
 int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range);
 int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw);
+// ... in two halves (round 6): the transform kernel writes the aligned cloud into the pinned staging buffer and a marker follows;
+// the host takes it out (one memcpy, or nothing for a view) when the marker is there -- callers queue the fitness sweep in between,
+// so the copy runs while the sweep does.  output_cloud_issue leaves tk.issued false when the cloud does not fit the staging buffer
+// (write_output_cloud's copy-engine path is the caller's way then).
+int output_cloud_issue(icpgpu_ctx* c, const Xform& T, float* out_xyzw, StageTicket& tk);
+int output_cloud_complete(icpgpu_ctx* c, StageTicket& tk, float* out_xyzw);
 void init_result(icpgpu_result* r);
 int p2p_finish(icpgpu_ctx* c, P2PRun& r);
 int p2p_prepare(icpgpu_ctx* c, P2PRun& r, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res);
@@ -507,7 +533,7 @@ int p2p_advance(icpgpu_ctx* c, P2PRun& r, int* deferred = nullptr);
 int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* res);
 // icpgpu_voxel.cpp
 int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough,
-                        int* bbox_enc_out = nullptr);
+                        int* bbox_enc_out = nullptr, bool publish = false, bool* published = nullptr, unsigned long long* fp_sum = nullptr);
 // icpgpu_gicp.cpp
 int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridIndex& G, DeviceBuf& cov, uint64_t& cov_version, bool allow_unchecked = false);
 int covariance_grid_check(icpgpu_ctx* c);

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "icp_env.h"
@@ -169,14 +170,22 @@ __device__ void svd3_left_vectors(const double A[9], double U[9]) {
 }
 
 // ---- computeCovariances -----------------------------------------------------------------------------------------
+// (list, optional: the points gicp_cov_select_kernel left over -- list[0 .. *list_n); without it every point of the cloud)
 __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict__ cloud, int n,
                                                        const float4* __restrict__ sorted,
                                                        const int* __restrict__ cell_start, GridDesc g,
-                                                       double* __restrict__ cov6) {
+                                                       double* __restrict__ cov6, const int* __restrict__ list,
+                                                       const int* __restrict__ list_n) {
   __shared__ unsigned long long s_key[4][GK];  // per-wave staging of the top-20 while it is re-ranked
   __shared__ int s_pos[4][GK];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + wv;  // one wave per point
+  // one wave per point; with a list: a few hundred waves walk it (it is short or empty: an empty launch sized for the cloud cost 4.6 us)
+  for (int slot = blockIdx.x * 4 + wv;; slot += gridDim.x * 4) {
+  int i = slot;
+  if (list) {
+    if (slot >= *list_n) return;
+    i = list[slot];
+  }
   if (i >= n) return;
   const float4 s = cloud[i];
   double C[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 1.0};
@@ -306,6 +315,401 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
   }
   if (!have_patch) C[0] = __longlong_as_double(0x7FF8000000000000ll);  // marker: identity covariance
   if (lane < 6) cov6[(size_t)i * 6 + lane] = C[lane];
+  if (!list) return;
+  }
+}
+
+// ---- shared by the selecting kernels: from a list of >= 20 keys to the covariance ---------------------------------------------
+constexpr int CS = 4;            // 256 keys per level in registers (a scan filtered at 0.2 m has ~60 inside a level's radius)
+constexpr int CS_LIST = 64 * CS;
+
+// buf[0 .. fill): distinct keys (d2 bits << 32 | index), all with d2 <= cap, 20 <= fill <= CS_LIST; one wave.  On return lanes 0..19
+// of `top` (LDS, 20 words) hold the 20 smallest in ascending order.  false: the threshold did not settle (dozens of equal distances).
+__device__ __forceinline__ bool cov_pick20(unsigned long long* buf, unsigned long long* top, int fill, float cap, int lane,
+                                           unsigned long long lane_lt, int& probes, int& ranked) {
+  unsigned long long K[CS];
+  const int nreg = (fill + 63) >> 6;  // wave-uniform: registers in use
+#pragma unroll
+  for (int m = 0; m < CS; ++m) K[m] = (m < nreg && m * 64 + lane < fill) ? buf[m * 64 + lane] : kEmptyKey;
+  auto count_le = [&](unsigned long long T) {
+    int c = 0;
+#pragma unroll
+    for (int m = 0; m < CS; ++m)
+      if (m < nreg) c += __popcll(__ballot(K[m] <= T));
+    return c;
+  };
+  // lower the threshold until 20 .. 64 keys pass: [lo_f: fewer than 20, hi_f: at least 20]
+  float lo_f = 0.0f, hi_f = cap;
+  unsigned long long T = ((unsigned long long)__float_as_uint(hi_f) << 32) | 0xFFFFFFFFull;
+  int c_lo = 0, c_hi = fill;
+  for (int probe = 0; c_hi > 64; ++probe) {
+    // interpolate for ~40 on d2 (the first probes), bisect afterwards
+    float mid = probe < 6 ? lo_f + (hi_f - lo_f) * ((40.0f - (float)c_lo) / (float)(c_hi - c_lo)) : 0.5f * (lo_f + hi_f);
+    if (!(mid > lo_f && mid < hi_f)) mid = 0.5f * (lo_f + hi_f);
+    if (probe >= 24 || !(mid > lo_f && mid < hi_f)) return false;  // (adjacent floats: more than 44 keys at one distance)
+    probes += 1;
+    const unsigned long long Tm = ((unsigned long long)__float_as_uint(mid) << 32) | 0xFFFFFFFFull;
+    const int cm = count_le(Tm);
+    if (cm < GK) {
+      lo_f = mid;
+      c_lo = cm;
+    } else {
+      hi_f = mid;
+      c_hi = cm;
+      T = Tm;
+    }
+  }
+  // compact the passing keys, one per lane (the list is in registers: its first 64 entries are free again; one wave reads what
+  // it wrote itself -- no barrier, the LDS operations of a wave complete in order)
+  unsigned long long k = K[0];  // (a list of one register's length that passes whole is in place already)
+  if (!(nreg == 1 && c_hi == fill)) {
+    int base = 0;
+#pragma unroll
+    for (int m = 0; m < CS; ++m)
+      if (m < nreg) {
+        const unsigned long long b = __ballot(K[m] <= T);
+        if (K[m] <= T) buf[base + __popcll(b & lane_lt)] = K[m];
+        base += __popcll(b);
+      }
+    k = lane < c_hi ? buf[lane] : kEmptyKey;
+  }
+  int rank = 0;
+  const int c8 = c_hi & ~7;
+  for (int j = 0; j < c8; j += 8) {  // wave-uniform addresses: broadcast reads, eight in flight
+    unsigned long long v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = buf[j + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rank += v[u] < k ? 1 : 0;
+  }
+  for (int j = c8; j < c_hi; ++j) rank += buf[j] < k ? 1 : 0;
+  if (lane < c_hi && rank < GK) top[rank] = k;
+  ranked = c_hi;
+  return true;
+}
+
+// Lanes 0..19 of `top` hold the neighbours in key order: mean and second moments exactly as gicp_cov_kernel forms them -- there nine
+// butterfly sums over the wave (xor 32, 16, 8, 4, 2, 1 with zeros in the lanes above 19) and nine divisions in every lane; here
+// the SAME tree of additions (fp addition commutes, so the butterfly's value in lane 0 is a fixed tree over the 20 terms: the xor-32
+// step adds a zero, the xor-16 step pairs terms l and l + 16 for l < 4 and adds zeros elsewhere, then 8 + 4 + 2 + 1 pairings) is
+// walked by ONE lane per sum over the terms in LDS, and one lane per covariance entry does its three divisions.  One wave;
+// `scratch`: 189 doubles of LDS (the key list's buffer: the list is dead).
+__device__ __forceinline__ void cov_emit(const unsigned long long* top, double* scratch, const float4* __restrict__ cloud, int i,
+                                         double* __restrict__ cov6, int lane) {
+  double* term = scratch;  // [9][20]
+  if (lane < GK) {
+    const float4 q = cloud[(unsigned int)top[lane]];  // (the grid's sorted copy holds the same coordinates under the same index)
+    term[0 * GK + lane] = (double)q.x;
+    term[1 * GK + lane] = (double)q.y;
+    term[2 * GK + lane] = (double)q.z;
+    term[3 * GK + lane] = (double)(q.x * q.x);  // (the second moments in the order of the triangle's entries)
+    term[4 * GK + lane] = (double)(q.y * q.x);
+    term[5 * GK + lane] = (double)(q.z * q.x);
+    term[6 * GK + lane] = (double)(q.y * q.y);
+    term[7 * GK + lane] = (double)(q.z * q.y);
+    term[8 * GK + lane] = (double)(q.z * q.z);
+  }
+  double* sums = term + 9 * GK;  // [9]
+  if (lane < 9) {
+    const volatile double* v = term + lane * GK;  // (volatile: read in the order of use -- all twenty at once cost 40 registers)
+    // a(l) = lane l's value after the xor-32 and xor-16 steps; then c(l) = a(l) + a(l + 8), d(l) = c(l) + c(l + 4),
+    // e(0) = d(0) + d(2), e(1) = d(1) + d(3), sum = e(0) + e(1)
+    auto a = [&](int l) -> double { return (v[l] + 0.0) + (l < 4 ? v[l + 16] + 0.0 : 0.0); };
+    auto d = [&](int l) -> double { return (a(l) + a(l + 8)) + (a(l + 4) + a(l + 12)); };
+    const double e0 = d(0) + d(2);
+    const double e1 = d(1) + d(3);
+    sums[lane] = e0 + e1;
+  }
+  if (lane < 6) {
+    // entry e = (row r, column c) of the upper triangle: (0,0) (1,0) (2,0) (1,1) (2,1) (2,2), second moments at sums[3 + e]
+    const int r = lane == 0 ? 0 : (lane == 1 || lane == 3 ? 1 : 2), cidx = lane < 3 ? 0 : (lane < 5 ? 1 : 2);
+    const double kk = (double)GK;
+    const double mr = sums[r] / kk, mc = sums[cidx] / kk;
+    cov6[(size_t)i * 6 + lane] = sums[3 + lane] / kk - mr * mc;
+  }
+}
+
+// The points the selecting kernel's cubes do not reach cheaply -- isolated far-field points whose 20th neighbour is metres away: cube
+// radii 8, 16, ... cells are hundreds to thousands of rows walked in one dependent chain (27 row batches, ~65 us, for a point
+// certified at radius 16; a handful of them per scan set the kernel's duration).  Here a WORKGROUP takes such a point and looks at
+// the whole cloud (a filtered scan: ~23k points, 23 per thread): a pass collects the keys under a cap into the list; the first cap
+// extrapolates the count the last cube found inside its radius (neighbours on a surface grow with d2) to ~60, later ones
+// interpolate between the caps tried -- usually one pass, then the same selection and sums as above.  Exact whatever the caps were:
+// every point of the cloud is looked at.  Clouds above kCovFarMost points keep the streaming kernel for these points.
+constexpr int kCovFarMost = 1 << 16;
+constexpr int kCovFarLevel = 4;  // the last cube radius (cells) the selecting kernel tries before it hands a point over
+__global__ __launch_bounds__(1024) void gicp_cov_far_kernel(const float4* __restrict__ cloud, int n, double* __restrict__ cov6, float r_tried,
+                                                            const int* __restrict__ far_list, const int* __restrict__ far_n,
+                                                            int* __restrict__ list, int* __restrict__ list_n) {
+  __shared__ unsigned long long s_buf[CS_LIST];
+  __shared__ unsigned long long s_top[GK];
+  __shared__ int s_count;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int slot = blockIdx.x; slot < *far_n; slot += gridDim.x) {
+    const int packed = far_list[slot];  // point index | (keys the last cube found inside its radius) << 20
+    const int i = packed & 0xFFFFF, seen = packed >> 20;
+    const float4 s = cloud[i];
+    // the keys with d2 <= cap: their number, the first CS_LIST of them in s_buf (any order: they are ranked later)
+    auto pass = [&](float cap) -> int {
+      __syncthreads();
+      if (tid == 0) s_count = 0;
+      __syncthreads();
+      for (int j0 = 0; j0 < n; j0 += 8192) {  // block-uniform; eight loads in flight per thread
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * 1024 + tid;
+          q[u] = j < n ? cloud[j] : make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * 1024 + tid;
+          const float d = dist2(q[u].x, q[u].y, q[u].z, s.x, s.y, s.z);
+          const bool in = finite3g(q[u].x, q[u].y, q[u].z) && d <= cap;  // (the grid's sorted copy leaves non-finite points out: so do we)
+          const unsigned long long b = __ballot(in);
+          if (b) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_count, __popcll(b));
+            base = __shfl(base, 0, 64);
+            const int at = base + __popcll(b & lane_lt);
+            if (in && at < CS_LIST) s_buf[at] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)j;
+          }
+        }
+      }
+      __syncthreads();
+      return s_count;
+    };
+    float lo_c = r_tried * r_tried, hi_c = 0.0f;
+    int n_lo = seen, n_hi = 0, fill = 0;
+    float cap = lo_c * (60.0f / (float)max(seen, 2));  // (a point that saw nothing yet: 30 times the area)
+    bool settled = false, fail = false;
+    for (int pass_no = 0; pass_no < 40; ++pass_no) {
+      fill = pass(cap);
+      if (fill >= GK && fill <= CS_LIST) {
+        settled = true;
+        break;
+      }
+      if (fill < GK) {
+        lo_c = cap;
+        n_lo = fill;
+      } else {
+        hi_c = cap;
+        n_hi = fill;
+      }
+      float next;
+      if (n_hi == 0) {
+        next = cap * (fill < 5 ? 8.0f : 60.0f / (float)fill);  // nothing above yet: grow (by the same rule)
+        if (!(next < 3.0e38f)) { fail = true; break; }  // fewer than 20 finite points in the cloud
+      } else {
+        next = pass_no < 30 ? lo_c + (hi_c - lo_c) * ((60.0f - (float)n_lo) / (float)(n_hi - n_lo)) : 0.5f * (lo_c + hi_c);
+        if (!(next > lo_c && next < hi_c)) next = 0.5f * (lo_c + hi_c);
+        if (!(next > lo_c && next < hi_c)) { fail = true; break; }  // hundreds of keys at one distance
+      }
+      cap = next;
+    }
+    if (settled && tid < 64) {  // one wave finishes
+      int probes = 0, ranked = 0;
+      if (cov_pick20(s_buf, s_top, fill, cap, lane, lane_lt, probes, ranked)) cov_emit(s_top, reinterpret_cast<double*>(s_buf), cloud, i, cov6, lane);
+      else fail = true;
+    }
+    if (tid == 0 && (fail || !settled)) list[atomicAdd(list_n, 1)] = i;  // the streaming kernel's
+  }
+}
+
+// computeCovariances, the SELECTING form (round 6).  gicp_cov_kernel above streams candidates 64 at a time into a running top-20 and
+// pays ~100 + 6 x (improving candidates) instructions per chunk -- 460 for the first chunk of every level, when all 64 improve --
+// in ONE dependent chain per point; a dense corner of a scan (a thousand candidates in the first cube) kept a wave for 30 us.
+// Here a level's candidates (the cube of radius rho cells around the point) are only EVALUATED, and the keys (d2 bits << 32 |
+// index) that lie within a distance cap -- the level's certified radius to begin with -- are appended to a per-wave LDS list:
+//   * a level succeeds iff >= 20 keys lie within its certified radius (the 20th neighbour is then known to be the true one); a
+//     level that fails has cost nothing but the evaluations;
+//   * a list that overflows (> 256 keys inside the radius: a dense corner) is collected again under a smaller cap, aimed at ~128
+//     keys by interpolating on d2 (neighbours on a surface grow linearly with it);
+//   * from the list, held in registers, a threshold is lowered the same way until 20..64 keys pass; those are compacted into one
+//     lane each and ranked by counting (keys are distinct): ranks 0..19 are the neighbours, in key order.
+// The next chunk's load is in flight while a chunk is processed, and rows are found by counting over at most 25 lane reads instead
+// of a six-step search through the LDS crossbar: the kernel is a latency chain per point, not an issue problem (23k waves for 8k
+// slots).  Same neighbours, same order, same sums as gicp_cov_kernel (tests/test_gpu_gicp.py compares the covariances bit for bit
+// with it and with the oracle).  A point whose caps do not settle (dozens of equal distances) or whose search reaches the whole
+// grid goes on a list, and gicp_cov_kernel finishes the list.
+template <bool STATS>
+#if defined(ICPGPU_COV_WAVES8)  // A/B build: 64 registers (a few spilled) for 8 waves per SIMD instead of 72 for 7 (no difference measured)
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+__attribute__((amdgpu_waves_per_eu(7, 8)))  // (left alone the compiler spreads to 108 registers: 4 waves per SIMD for a latency-bound kernel)
+#endif
+__global__ __launch_bounds__(256) void gicp_cov_select_kernel(const float4* __restrict__ cloud, int n,
+                                                              const float4* __restrict__ sorted,
+                                                              const int* __restrict__ cell_start, GridDesc g,
+                                                              double* __restrict__ cov6, int* __restrict__ list,
+                                                              int* __restrict__ list_n, int far_ok, int* __restrict__ far_list,
+                                                              int* __restrict__ far_n, unsigned long long* __restrict__ stats) {
+#define CS_STAT(k, v) do { if (STATS && lane == 0) atomicAdd(stats + (k), (unsigned long long)(v)); } while (0)
+  __shared__ unsigned long long s_buf[4][CS_LIST];
+  __shared__ unsigned long long s_top[4][GK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wv;  // one wave per point
+  if (i >= n) return;
+  const float4 s = cloud[i];
+  if (!finite3g(s.x, s.y, s.z)) {  // (as gicp_cov_kernel: the marker of an identity covariance)
+    if (lane < 6) cov6[(size_t)i * 6 + lane] = lane == 0 ? __longlong_as_double(0x7FF8000000000000ll) : (lane == 3 || lane == 5 ? 1.0 : 0.0);
+    return;
+  }
+  int cx, cy, cz;
+  cell_of_g(g, s.x, s.y, s.z, cx, cy, cz);
+  const int span = max(g.nx, max(g.ny, g.nz));
+  const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  unsigned long long* buf = s_buf[wv];
+  bool done = false, give_up = false, go_far = false;
+  int last_seen = 0;  // keys inside the radius of the last level that failed
+  for (int rho = 1; !done && !give_up; rho *= 2) {
+    if (far_ok && rho > kCovFarLevel) {  // wave-uniform
+      go_far = true;
+      break;
+    }
+    const int side = 2 * rho + 1, nrows = side * side;
+    const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.nx - 1);
+    const float inv_side = 1.0f / (float)side;
+    const float safe = (float)rho * g.h * kGridSafety;
+    const float safe_sq = safe * safe;
+    // One pass over the level's candidates: the keys with d2 <= cap into buf (the first CS_LIST of them), their number returned.
+    // Under a cap below the level's radius only the cells the cap's ball reaches are read (box pruning on the SAME float cell
+    // coordinates that binned the points, which are monotone in x: a point within sqrt(cap) of s cannot lie in a skipped cell).
+    // A list that overflows ends the pass at once (levels of one row batch): `est` then extrapolates the count from the share of
+    // the candidates seen so far -- a guide for the next cap, not a result.
+    auto collect = [&](float cap, int& est) -> int {
+      int fill = 0;
+      const float r_cap = sqrtf(cap) * 1.0001f + g.h * 0.03125f;
+      const int xa = (int)fmaxf(floorf((s.x - r_cap - g.ox) * g.inv_h), -4.0f), xb = (int)fminf(floorf((s.x + r_cap - g.ox) * g.inv_h), 1048576.0f);
+      const int ya = (int)fmaxf(floorf((s.y - r_cap - g.oy) * g.inv_h), -4.0f), yb = (int)fminf(floorf((s.y + r_cap - g.oy) * g.inv_h), 1048576.0f);
+      const int za = (int)fmaxf(floorf((s.z - r_cap - g.oz) * g.inv_h), -4.0f), zb = (int)fminf(floorf((s.z + r_cap - g.oz) * g.inv_h), 1048576.0f);
+      const int xx0 = max(x0, xa), xx1 = min(x1, xb);
+      for (int rb = 0; rb < nrows; rb += 64) {
+        const int r = rb + lane;
+        const int zr = (int)(((float)r + 0.5f) * inv_side), yr = r - zr * side;
+        const int yy = cy + yr - rho, zz = cz + zr - rho;
+        int lo = 0, len = 0;
+        if (r < nrows && xx0 <= xx1 && yy >= max(0, ya) && yy <= min(g.ny - 1, yb) && zz >= max(0, za) && zz <= min(g.nz - 1, zb)) {
+          const int row = zz * g.sz + yy * g.sy;
+          lo = cell_start[row + xx0];
+          len = cell_start[row + xx1 + 1] - lo;
+        }
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d, 64);
+          if ((int)lane >= d) incl += t;
+        }
+        const int start = incl - len, total = __shfl(incl, 63, 64);
+        if (nrows <= 64 && total < GK) {  // fewer than 20 points in reach: nothing to evaluate
+          est = total;
+          return total;
+        }
+        const int rows_here = min(nrows - rb, 64);
+        // entry e of the batch's candidate list lives in the LAST row whose offset is <= e (empty rows share their successor's
+        // offset: the successor wins) -- (rows with offset <= e) - 1, counted over lane reads when the rows are few
+        auto locate = [&](int e) -> int {
+          int rr = 0;
+          if (rows_here <= 25) {
+            for (int j = 1; j < rows_here; ++j) rr += __builtin_amdgcn_readlane(start, j) <= e ? 1 : 0;
+          } else {
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+              const int probe = rr + step;
+              const int sp = __shfl(start, probe & 63, 64);
+              if (probe < 64 && sp <= e) rr = probe;
+            }
+          }
+          return __shfl(lo, rr, 64) + (e - __shfl(start, rr, 64));
+        };
+        // (locate() moves data between lanes: every lane of the wave takes part in it, only the load is conditional)
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        int at0 = locate(lane);
+        if (lane < total) q = sorted[at0];
+        for (int c0 = 0; c0 < total; c0 += 64) {  // wave-uniform
+          const float4 cur = q;
+          const bool live = c0 + lane < total;
+          if (c0 + 64 < total) {  // wave-uniform: the next chunk's load, in flight during this one
+            const int at1 = locate(c0 + 64 + lane);
+            if (c0 + 64 + lane < total) q = sorted[at1];
+          }
+          const float d = dist2(cur.x, cur.y, cur.z, s.x, s.y, s.z);
+          const bool pass = live && d <= cap;
+          const unsigned long long b = __ballot(pass);
+          const int at = fill + __popcll(b & lane_lt);
+          if (pass && at < CS_LIST) buf[at] = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cur.w);
+          fill += __popcll(b);
+          if (fill > CS_LIST && nrows <= 64) {  // wave-uniform: overflow
+            const int seen = min(c0 + 64, total);
+            est = (int)fminf((float)fill * ((float)total / (float)seen), 1.0e9f);
+            return fill;
+          }
+        }
+      }
+      est = fill;
+      return fill;
+    };
+    CS_STAT(2, 1);
+    // the level's radius first; a list that overflows (a dense corner) again under smaller caps, [lo_c: fewer than 20 keys, hi_c: more
+    // than the list holds], aimed at ~100 keys by interpolating on d2
+    float cap = safe_sq, lo_c = 0.0f, hi_c = safe_sq;
+    int fill = 0, est = 0, n_lo = 0, n_hi = 0;
+    bool level_fails = false;
+    for (int pass_no = 0;; ++pass_no) {
+      fill = collect(cap, est);
+      if (pass_no == 0 && fill < GK) {  // the level cannot certify 20 neighbours
+        level_fails = true;
+        break;
+      }
+      if (fill >= GK && fill <= CS_LIST) break;
+      if (pass_no == 0) CS_STAT(3, 1);
+      if (fill < GK) {
+        lo_c = cap;
+        n_lo = fill;
+      } else {
+        hi_c = cap;
+        n_hi = est;
+      }
+      float mid = pass_no < 4 ? lo_c + (hi_c - lo_c) * ((100.0f - (float)n_lo) / (float)(n_hi - n_lo)) : 0.5f * (lo_c + hi_c);
+      if (!(mid > lo_c && mid < hi_c)) mid = 0.5f * (lo_c + hi_c);
+      if (pass_no >= 12 || !(mid > lo_c && mid < hi_c)) {
+        give_up = true;
+        CS_STAT(4, 1);
+        break;
+      }
+      cap = mid;
+    }
+    if (level_fails) {
+      last_seen = fill;
+      if (rho >= span) { give_up = true; CS_STAT(5, 1); }  // (the whole grid has been looked at: gicp_cov_kernel's closing rule applies)
+      continue;
+    }
+    if (give_up) break;
+    CS_STAT(1, fill);
+    int probes = 0, ranked = 0;
+    if (!cov_pick20(buf, s_top[wv], fill, cap, lane, lane_lt, probes, ranked)) {
+      give_up = true;
+      CS_STAT(4, 1);
+      break;
+    }
+    done = true;
+    CS_STAT(6, probes);
+    CS_STAT(7, ranked);
+    CS_STAT(0, 1);
+    CS_STAT(8 + min(31 - __clz(rho), 7), 1);  // histogram of the level that succeeded: rho = 1, 2, 4, ... 128+
+  }
+#undef CS_STAT
+  if (!done) {
+    // far_ok: a point no cube of up to kCovFarLevel cells has certified goes to gicp_cov_far_kernel; everything else that is not
+    // done (caps that do not settle, any such point of a cloud too large for that kernel) to gicp_cov_kernel
+    if (lane == 0) {
+      if (go_far) far_list[atomicAdd(far_n, 1)] = i | (last_seen << 20);  // (i < kCovFarMost, last_seen < 20)
+      else list[atomicAdd(list_n, 1)] = i;
+    }
+    return;
+  }
+  cov_emit(s_top[wv], reinterpret_cast<double*>(buf), cloud, i, cov6, lane);
 }
 
 // The 3x3 decomposition, ONE LANE PER POINT: inside the search kernel every lane of the wave repeated it (several thousand
@@ -1290,10 +1694,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
+// list (optional): 2 n + 2 ints of scratch -- with it the selecting kernel runs first and gicp_cov_kernel only finishes what that one
+// left over (list[0] = how many, list[1 ..] = which; cleared here); without it gicp_cov_kernel does every point, as until round 5.
 hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
-                                   const GridDesc& g, double* cov6, hipStream_t stream) {
+                                   const GridDesc& g, double* cov6, hipStream_t stream, int* list) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6);
+  // development flavour, ICPGPU_COV_SELECT=0: the streaming kernel for every point
+  static const bool select = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_COV_SELECT"); return !e || atoi(e) != 0; }();
+  if (list && select) {
+    hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    // development flavour, ICPGPU_COV_STATS=1: what the selecting kernel did with the cloud (a synchronising print per cloud)
+    static const bool want_stats = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_COV_STATS"); return e && atoi(e) != 0; }();
+    unsigned long long* d_stats = nullptr;
+    if (want_stats && hipMalloc(reinterpret_cast<void**>(&d_stats), 16 * sizeof(unsigned long long)) == hipSuccess)
+      (void)hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), stream);
+    // list layout: [0] streaming count, [1] far count, [2 .. 2 + n) streaming list, [2 + n .. 2 + 2n) far list
+    const int far_ok = n <= kCovFarMost ? 1 : 0;
+    int* far_list = list + 2 + n;
+    if (d_stats)
+      hipLaunchKernelGGL(gicp_cov_select_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, list + 2, list, far_ok,
+                         far_list, list + 1, d_stats);
+    else
+      hipLaunchKernelGGL(gicp_cov_select_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, list + 2, list, far_ok,
+                         far_list, list + 1, d_stats);
+    if (far_ok)  // (the first cap: the radius the last cube tried has already failed)
+      hipLaunchKernelGGL(gicp_cov_far_kernel, dim3(std::min(n, 256)), dim3(1024), 0, stream, cloud, n, cov6, (float)kCovFarLevel * g.h * kGridSafety, far_list,
+                         list + 1, list + 2, list);
+    if (d_stats) {
+      unsigned long long h[16];
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost);
+      (void)hipFree(d_stats);
+      fprintf(stderr, "[icpgpu] covariances of %d points (cells of %.3f m): %llu selected (%.1f levels, %.0f keys inside the certified radius, %.2f threshold probes, %.1f keys ranked "
+                      "each), %llu dense corners collected again; left over: %llu caps not settled, %llu whole grid searched\n", n, (double)g.h, h[0],
+              (double)h[2] / (double)(h[0] ? h[0] : 1), (double)h[1] / (double)(h[0] ? h[0] : 1), (double)h[6] / (double)(h[0] ? h[0] : 1),
+              (double)h[7] / (double)(h[0] ? h[0] : 1), h[3], h[4], h[5]);
+      int h_lists[2] = {0, 0};
+      (void)hipMemcpy(h_lists, list, sizeof(h_lists), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[icpgpu]   handed over: %d to the far-field kernel, %d to the streaming kernel (before the far-field kernel ran)\n", h_lists[1], h_lists[0]);
+      fprintf(stderr, "[icpgpu]   points by the cube radius (in cells) that certified them: 1: %llu, 2: %llu, 4: %llu, 8: %llu, 16: %llu, 32: %llu, 64: %llu, more: %llu\n", h[8],
+              h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+    }
+    hipLaunchKernelGGL(gicp_cov_kernel, dim3(std::min((n + 3) / 4, 128)), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, list + 2, list);
+  } else {
+    hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, nullptr, nullptr);
+  }
   hipLaunchKernelGGL(gicp_cov_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, cov6);
   return hipGetLastError();
 }

@@ -131,6 +131,11 @@ ICPGPU_HD inline unsigned long long fp_finish(unsigned long long sum, unsigned l
 // *d_acc (zeroed by the launcher) receives the sum of fp_point over pts[0..n)
 hipError_t launch_fingerprint(const float4* pts, int n, unsigned long long* d_acc, hipStream_t stream);
 
+// pts[0 .. min(d_counts[0] + d_counts[1], cap)) into host-mapped memory with 16-byte stores, *d_acc (ZERO before: the voxel
+// filter's last kernel clears it) += the sum of fp_point over them (the voxel filter's result on its way to the caller: icpgpu_voxel_grid_view); n_most sizes the launch
+hipError_t launch_publish_cloud(const float4* pts, const int* d_counts, int n_most, int cap, float4* host_out, unsigned long long* d_acc,
+                                hipStream_t stream);
+
 // keys -> (idx, d2) arrays for the kernel-level C-ABI entry point.
 hipError_t launch_unpack_keys(const unsigned long long* keys, int n, int32_t* idx, float* d2, hipStream_t stream);
 
@@ -234,7 +239,8 @@ struct Rot3d {
 };
 // cov6[i] = upper triangle (xx, xy, xz, yy, yz, zz) of the regularised covariance of point i's 20 nearest neighbours
 hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
-                                   const GridDesc& g, double* cov6, hipStream_t stream);
+                                   const GridDesc& g, double* cov6, hipStream_t stream, int* list = nullptr);
+// (list: 2 n + 2 ints of scratch -- the points the selecting kernel hands to the far-field and the streaming kernel; icp_gicp.hip)
 // maha6[i] = upper triangle of (C_t[j] + R C_s[i] R^T)^-1 for every source point whose key passes d2 < thr
 hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, float thr, const Rot3d& R, const double* cov_s,
                                    const double* cov_t, double* maha6, hipStream_t stream);
@@ -388,6 +394,7 @@ size_t voxel_direct_scratch_ints(int n);
 int voxel_direct_groups(int n);
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
                                     unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
-                                    int* d_n_out, int* status, hipStream_t stream);
+                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word = nullptr);
+// (clear_word, optional: a 64-bit word of device memory the last kernel sets to zero -- launch_publish_cloud's accumulator)
 
 }  // namespace icpgpu

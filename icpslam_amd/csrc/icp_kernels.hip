@@ -532,7 +532,39 @@ __global__ __launch_bounds__(256) void fingerprint_kernel(const float4* __restri
   for (int off = 32; off > 0; off >>= 1) s += (unsigned long long)__shfl_down((long long)s, off, 64);
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(acc, s);  // integer addition: any order gives the same sum
 }
+// A result cloud straight into the context's pinned, mapped staging buffer (the caller's cloud is one host copy away), with its
+// content fingerprint taken on the way: 16-byte stores, a wave writes 1 KiB of consecutive host addresses.  The number of points
+// is on the device (the voxel filter's two counters) -- the host learns it from the same posted marker that tells it the points
+// have arrived; nothing beyond `cap` points is written (the host falls back to the copy engine then).
+__global__ __launch_bounds__(256) void publish_cloud_kernel(const float4* __restrict__ pts, const int* __restrict__ d_counts, int cap,
+                                                            float4* __restrict__ host_out, unsigned long long* __restrict__ acc) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  int n = d_counts[0] + d_counts[1];
+  n = n < 0 ? 0 : (n > cap ? cap : n);
+  unsigned long long s = 0ull;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 p = pts[i];
+    v4f o;
+    o.x = p.x; o.y = p.y; o.z = p.z; o.w = p.w;
+    __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(host_out + i));
+    const unsigned long long w0 = ((unsigned long long)__float_as_uint(p.y) << 32) | __float_as_uint(p.x);
+    const unsigned long long w1 = ((unsigned long long)__float_as_uint(p.w) << 32) | __float_as_uint(p.z);
+    s += fp_point(w0, w1, (unsigned long long)i);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += (unsigned long long)__shfl_down((long long)s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(acc, s);
+}
 }  // namespace
+
+hipError_t launch_publish_cloud(const float4* pts, const int* d_counts, int n_most, int cap, float4* host_out, unsigned long long* d_acc,
+                                hipStream_t stream) {
+  if (n_most <= 0) return hipSuccess;
+  int blocks = (n_most + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(publish_cloud_kernel, dim3(blocks), dim3(256), 0, stream, pts, d_counts, cap, host_out, d_acc);
+  return hipGetLastError();
+}
 
 hipError_t launch_fingerprint(const float4* pts, int n, unsigned long long* d_acc, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_acc, 0, sizeof(unsigned long long), stream);

@@ -433,7 +433,9 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
                                                                unsigned int epoch, float4* __restrict__ out,
                                                                int* __restrict__ d_n_out, int* __restrict__ hist, int nbins,
                                                                int* __restrict__ status, long long* __restrict__ dbg,
-                                                               int test_stall) {
+                                                               int test_stall, unsigned long long* __restrict__ clear_word) {
+  // (the accumulator of the kernel that may follow -- publish_cloud_kernel's fingerprint -- starts from zero)
+  if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0ull;
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #define VX_STAMP(k) do { if (dbg && threadIdx.x == 0) stamp[k] = (long long)wall_clock64(); } while (0)
   VX_STAMP(0);
@@ -640,7 +642,7 @@ size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 4 * (size
 // sort path.
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
                                     unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
-                                    int* d_n_out, int* status, hipStream_t stream) {
+                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word) {
   const long long ncells = (long long)divb[0] * divb[1] * divb[2];
   // buckets of cpb consecutive cells, as many of the 8192 as the index space fills (a power-of-two bucket would leave up to
   // half of them unused -- 4350 for a raw scan at 0.2 m -- and the near-field buckets twice as full)
@@ -671,7 +673,7 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
     return v;
   }();
   hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, published, epoch, out,
-                     d_n_out, hist, nbins, status, dbg, test_stall);
+                     d_n_out, hist, nbins, status, dbg, test_stall, clear_word);
   if (dbg) {
     std::vector<long long> h((size_t)groups * 8);
     (void)hipStreamSynchronize(stream);

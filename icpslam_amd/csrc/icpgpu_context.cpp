@@ -140,8 +140,80 @@ int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst) {
 // filtered cloud of every VoxelGrid::filter); a DMA into pinned memory, its end seen through a posted marker (fetch_ints: no stream
 // synchronisation), and a memcpy take ~60.  `extra_ints` (optional, n_extra <= 8 ints of device memory) ride on the same marker.
 // Copies above kStageMaxBytes go the direct way (the staging buffer is not meant to hold a raw 16 MB submap).
+int ensure_stage(icpgpu_ctx* c, size_t bytes, bool any_size) {
+  if (bytes <= c->h_stage_cap) return ICPGPU_OK;
+  if (bytes > kStageMaxBytes && !any_size) return fail(c, ICPGPU_ERR_UNSUPPORTED, "staging buffer: %zu bytes asked for", bytes);
+  if (c->h_stage) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // (nothing in flight may still write to the old one)
+    (void)hipHostFree(c->h_stage);
+  }
+  c->h_stage = c->h_stage_dev = nullptr;
+  c->h_stage_cap = 0;
+  const size_t want = any_size && bytes > kStageMaxBytes ? bytes : std::min(kStageMaxBytes, std::max<size_t>(bytes + bytes / 4, 1u << 20));
+  // mapped + coherent: kernels store into it (a kernel's end makes its stores visible to the host before the next kernel's marker)
+  HIP_TRY(c, hipHostMalloc(&c->h_stage, want, hipHostMallocMapped | hipHostMallocCoherent));
+  hipError_t e = hipHostGetDevicePointer(&c->h_stage_dev, c->h_stage, 0);
+  if (e != hipSuccess) {
+    (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    return fail(c, ICPGPU_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e));
+  }
+  c->h_stage_cap = want;
+  return ICPGPU_OK;
+}
+
+// the staged clouds' markers live behind fetch_ints' 32 pairs and the 8 of a grid's statistics
+static constexpr int kStagePostSlot = 40, kStagePostInts = 8;
+
+int stage_post(icpgpu_ctx* c, const int* d_ints, int n_ints, StageTicket& tk) {
+  if (n_ints > kStagePostInts) return fail(c, ICPGPU_ERR_INVALID_ARG, "stage_post: %d values", n_ints);
+  if (n_ints <= 0) {  // any device int will do for the marker
+    int rc = ensure(c, c->fp_acc, sizeof(unsigned long long));
+    if (rc) return rc;
+    d_ints = static_cast<const int*>(c->fp_acc.ptr);
+    n_ints = 1;
+  }
+  tk.number = ++c->post_seq;
+  tk.n_ints = n_ints;
+  HIP_TRY(c, launch_post_ints(d_ints, n_ints, c->h_post_dev + 2 * kStagePostSlot, wire_seq(c, tk.number), c->stream));
+  tk.issued = true;
+  return ICPGPU_OK;
+}
+
+int stage_wait(icpgpu_ctx* c, StageTicket& tk, int* ints_out) {
+  if (!tk.issued) return fail(c, ICPGPU_ERR_INVALID_ARG, "stage_wait: nothing posted");
+  tk.issued = false;
+  const volatile unsigned long long* box = c->h_post + 2 * kStagePostSlot;
+  const int n = tk.n_ints;
+  std::chrono::steady_clock::time_point t0;
+  for (unsigned spins = 1;; ++spins) {
+    bool all = true;
+    for (int k = 0; k < n && all; ++k) all = (box[2 * k + 1] >> 24) == tk.number;
+    if (all) {
+      unsigned long long bits;
+      for (int k = 0; k < n && all; ++k) {
+        all = mailbox_read(box + 2 * k, tk.number, &bits);
+        if (all && ints_out) ints_out[k] = (int)(unsigned int)bits;
+      }
+      if (all) break;
+    }
+    if ((spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a staged cloud: %s", hipGetErrorString(q));
+      const auto now = std::chrono::steady_clock::now();
+      if (spins == 0x400u) t0 = now;
+      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a staged cloud (hung kernel?)", wait_timeout_ms());
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return ICPGPU_OK;
+}
+
 int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, const int* d_extra, int n_extra, int* extra_out) {
-  constexpr size_t kStageMaxBytes = 8u << 20;
   int rc;
   if (bytes == 0 && n_extra == 0) return ICPGPU_OK;
   if (bytes > kStageMaxBytes) {
@@ -151,14 +223,7 @@ int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, cons
     if (n_extra) std::memcpy(extra_out, c->h_ints + 8, (size_t)n_extra * sizeof(int));
     return ICPGPU_OK;
   }
-  if (bytes > c->h_stage_cap) {
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
-    c->h_stage = nullptr;
-    c->h_stage_cap = 0;
-    const size_t want = std::min(kStageMaxBytes, std::max<size_t>(bytes + bytes / 4, 1u << 20));
-    HIP_TRY(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
-    c->h_stage_cap = want;
-  }
+  if ((rc = ensure_stage(c, bytes))) return rc;
   if (bytes) HIP_TRY(c, hipMemcpyAsync(c->h_stage, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   int dummy = 0;
   if (n_extra == 0) {  // any device int will do for the marker
@@ -168,7 +233,7 @@ int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, cons
     extra_out = &dummy;
   }
   if ((rc = fetch_ints(c, d_extra, n_extra, extra_out))) return rc;  // queued behind the copy: returns when both are there
-  if (bytes) std::memcpy(dst, c->h_stage, bytes);
+  if (bytes && dst != c->h_stage) std::memcpy(dst, c->h_stage, bytes);  // (a view's caller reads the staging buffer itself)
   return ICPGPU_OK;
 }
 
@@ -533,8 +598,9 @@ int create_context(icpgpu_ctx** out_ctx, int device_id, bool with_stream) {
   {
     void* hp = nullptr;
     // 32 result pairs for fetch_ints and the markers, 8 more for the statistics of a covariance grid built ahead of them (spec_grid)
-    if ((e = hipHostMalloc(&hp, 40 * 16, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
-    std::memset(hp, 0, 40 * 16);
+    // ... and 8 for the marker of a cloud staged for the host (stage_post)
+    if ((e = hipHostMalloc(&hp, 48 * 16, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+    std::memset(hp, 0, 48 * 16);
     c->h_post = static_cast<volatile unsigned long long*>(hp);
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_post_dev), hp, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
   }
@@ -598,6 +664,7 @@ int icpgpu_destroy(icpgpu_ctx* c) {
   release(c->cov_src);
   release(c->cov_tgt);
   release(c->maha);
+  release(c->cov_list);
   release(c->vox_in);
   release(c->vox_out);
   release(c->vox_keys);
@@ -916,6 +983,8 @@ int icpgpu_profile_reset(icpgpu_ctx* c) {
   (void)resolve_sweep_timings(c);
   (void)resolve_cov_timing(c);
   std::memset(&c->prof, 0, sizeof(c->prof));
+  for (double& v : c->gt_stage) v = 0.0;  // (ICPGPU_GICP_TIMING's host stage timers restart too: a harness resets after its warm-up)
+  c->gt_aligns = 0;
   return ICPGPU_OK;
 }
 

@@ -64,8 +64,10 @@ static int cov_launch(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridI
     if ((rc = resolve_cov_timing(c))) return rc;  // (the events are about to be reused: an alignment with two new clouds)
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   }
+  if ((rc = ensure(c, c->cov_list, (2 * cloud.n + 2) * sizeof(int)))) return rc;
   HIP_TRY(c, launch_gicp_covariances(cloud.data(), (int)cloud.n, static_cast<const float4*>(G.sorted.ptr),
-                                     static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream));
+                                     static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream,
+                                     static_cast<int*>(c->cov_list.ptr)));
   if (timed) {
     HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     // No synchronisation: what follows is queued behind the pass (it used to end with one only to time itself: the host sat out
@@ -833,16 +835,29 @@ int align_gicp(icpgpu_ctx* c, const float* guess_in, float* out_xyzw, int want_f
   res->n_correspondences = n_corr;
   res->mse_last = mse;
   const Xform Tf = xform_from_f16(fin);
+  // The aligned cloud and the fitness the reference asks for on every scan (icp_odometer.cpp:196-201), round 6: the transform kernel
+  // writes the cloud into the pinned staging buffer, a marker follows, the fitness sweep is queued behind both -- and the host copies
+  // the cloud out while the sweep runs (it used to wait for the sweep, then for a transform, a copy engine and a marker, then copy).
+  StageTicket out_ticket;
+  bool out_done = false;
   if (want_fitness) {
     if ((rc = resolve_sweep_timings(c))) return rc;
     c->dev_ms_accum = 0.0;
-    if ((rc = nn_and_reduce(c, Tf, FLT_MAX, true))) return rc;
+    if ((rc = output_cloud_issue(c, Tf, out_xyzw, out_ticket))) return rc;
+    SweepTicket tk;
+    if ((rc = sweep_issue(c, Tf, FLT_MAX, true, tk))) return rc;
+    if (out_ticket.issued) {
+      if ((rc = output_cloud_complete(c, out_ticket, out_xyzw))) return rc;
+      out_done = true;
+    }
+    if ((rc = wait_sums(c, tk.seq))) return rc;
+    if ((rc = sweep_complete(c, tk))) return rc;
     if ((rc = resolve_sweep_timings(c))) return rc;
     dev_ms += c->dev_ms_accum;  // 0 when this sweep was not a timed one
     res->fitness = c->h_sums[0] > 0.0 ? c->h_sums[16] / c->h_sums[0] : DBL_MAX;
   }
   mark(7);
-  if ((rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
+  if (!out_done && (rc = write_output_cloud(c, Tf, out_xyzw))) return rc;
   mark(8);
   if ((rc = resolve_cov_timing(c))) return rc;  // (long finished: the evaluations ran behind it)
   if (stage_timing) c->gt_aligns += 1;

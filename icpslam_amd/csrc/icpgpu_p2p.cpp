@@ -349,15 +349,63 @@ int nn_and_reduce(icpgpu_ctx* c, const Xform& T, float thr, bool open_range) {
 }
 
 
+// development flavour, ICPGPU_STAGE_DIRECT=0: result clouds go through device memory and the copy engine, as until round 5
+static bool stage_direct() {
+  static const bool v = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_STAGE_DIRECT"); return !e || std::atoi(e) != 0; }();
+  return v;
+}
+
+int output_cloud_issue(icpgpu_ctx* c, const Xform& T, float* out_xyzw, StageTicket& tk) {
+  tk.issued = false;
+  const int n_s = (int)c->src.n;
+  const size_t bytes = (size_t)n_s * sizeof(float4);
+  if ((!out_xyzw && !c->want_view) || n_s == 0 || !stage_direct()) return ICPGPU_OK;
+  if (bytes > kStageMaxBytes && !c->want_view) return ICPGPU_OK;
+  int rc = ensure_stage(c, bytes, c->want_view);
+  if (rc) return rc;
+  HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, launch_transform(c->src.data(), n_s, T, static_cast<float4*>(c->h_stage_dev), c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+  return stage_post(c, nullptr, 0, tk);
+}
+
+int output_cloud_complete(icpgpu_ctx* c, StageTicket& tk, float* out_xyzw) {
+  if (!tk.issued) return ICPGPU_OK;
+  int rc = stage_wait(c, tk, nullptr);
+  if (rc) return rc;
+  const size_t n_s = c->src.n;
+  if (out_xyzw && !c->want_view) std::memcpy(out_xyzw, c->h_stage, n_s * sizeof(float4));
+  float ms = 0.f;
+  hipError_t te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+  if (te == hipErrorNotReady) {  // (the events lie in front of the marker's kernel: complete; the runtime may not have noticed yet)
+    (void)hipGetLastError();
+    HIP_TRY(c, hipEventSynchronize(c->ev[1]));
+    te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+  }
+  HIP_TRY(c, te);
+  c->prof.transform_launches += 1;
+  c->prof.transform_ms += ms;
+  c->prof.transform_bytes += 32ull * (uint64_t)n_s;
+  return ICPGPU_OK;
+}
+
 int write_output_cloud(icpgpu_ctx* c, const Xform& T, float* out_xyzw) {
   const int n_s = (int)c->src.n;
-  if (!out_xyzw || n_s == 0) return ICPGPU_OK;
-  int rc = ensure(c, c->out, (size_t)n_s * sizeof(float4));
+  if ((!out_xyzw && !c->want_view) || n_s == 0) return ICPGPU_OK;
+  StageTicket tk;
+  int rc = output_cloud_issue(c, T, out_xyzw, tk);
   if (rc) return rc;
+  if (tk.issued) return output_cloud_complete(c, tk, out_xyzw);
+  // too large for the staging buffer (or the development switch): device memory, then the copy engine
+  if ((rc = ensure(c, c->out, (size_t)n_s * sizeof(float4)))) return rc;
   HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
   HIP_TRY(c, launch_transform(c->src.data(), n_s, T, static_cast<float4*>(c->out.ptr), c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-  if ((rc = copy_to_host(c, out_xyzw, c->out.ptr, (size_t)n_s * sizeof(float4)))) return rc;
+  if (c->want_view) {
+    if ((rc = ensure_stage(c, (size_t)n_s * sizeof(float4), true))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage, c->out.ptr, (size_t)n_s * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else if ((rc = copy_to_host(c, out_xyzw, c->out.ptr, (size_t)n_s * sizeof(float4)))) return rc;
   float ms = 0.f;
   HIP_TRY(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
   c->prof.transform_launches += 1;
@@ -376,7 +424,9 @@ void init_result(icpgpu_result* r) {
 
 int p2p_finish(icpgpu_ctx* c, P2PRun& r) {
   const Xform Tf = to_xform(r.final_T);
-  int rc = write_output_cloud(c, Tf, r.out_xyzw);
+  // (the aligned cloud was queued in front of the fitness sweep when there was one: p2p_advance)
+  int rc = r.out_done ? ICPGPU_OK
+                      : (r.out_ticket.issued ? output_cloud_complete(c, r.out_ticket, r.out_xyzw) : write_output_cloud(c, Tf, r.out_xyzw));
   if (rc) return rc;
   if ((rc = resolve_sweep_timings(c, /*block=*/false))) return rc;
   r.res->t_device_ms = c->call_timed ? c->dev_ms_accum * (double)c->call_sweeps / (double)c->call_timed : 0.0;
@@ -483,6 +533,9 @@ int p2p_advance(icpgpu_ctx* c, P2PRun& r, int* deferred) {
       *deferred = 2;
       return ICPGPU_OK;
     }
+    // the aligned cloud first (into the pinned staging buffer, a marker behind it), then the fitness sweep: p2p_finish copies the
+    // cloud out while nothing else waits for it (round 6; icp_odometer.cpp:196-201 asks for both on every scan)
+    if ((rc = output_cloud_issue(c, to_xform(r.final_T), r.out_xyzw, r.out_ticket))) return rc;
     return sweep_issue(c, to_xform(r.final_T), FLT_MAX, true, r.ticket);
   }
   return p2p_finish(c, r);
@@ -494,6 +547,10 @@ int align_p2p(icpgpu_ctx* c, const float* guess, float* out_xyzw, int want_fitne
   static const bool timing = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_P2P_TIMING"); return e && std::atoi(e) != 0; }();
   while (!rc && r.phase != P2PRun::Done) {
     const auto t0 = std::chrono::steady_clock::now();
+    if (r.phase == P2PRun::Fitness && r.out_ticket.issued) {  // the aligned cloud leaves the staging buffer while the fitness sweep runs
+      if ((rc = output_cloud_complete(c, r.out_ticket, r.out_xyzw))) break;
+      r.out_done = true;
+    }
     if ((rc = wait_sums(c, r.ticket.seq))) break;
     if (timing) {
       c->pt_ready = std::chrono::steady_clock::now();
@@ -625,6 +682,31 @@ int icpgpu_solve(const double sums[17], double Tk[16]) {
   const bool ok = solve_umeyama(sums, M);
   for (int i = 0; i < 16; ++i) Tk[i] = M[i];
   return ok ? ICPGPU_OK : ICPGPU_ERR_INVALID_ARG;
+}
+
+int icpgpu_align_view(icpgpu_ctx* c, const float* guess, int want_fitness, icpgpu_result* user_res, const float** view_xyzw, size_t* n_out) {
+  ENTER(c);
+  if (!user_res || !view_xyzw || !n_out) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  *view_xyzw = nullptr;
+  *n_out = 0;
+  if (!c->src.set || !c->tgt.set) return fail(c, ICPGPU_ERR_NO_INPUT, "align: source and target must be set first");
+  icpgpu_result own;
+  icpgpu_result* res = c->abi_result == sizeof(icpgpu_result) ? user_res : &own;
+  struct ViewGuard {
+    icpgpu_ctx* c;
+    ~ViewGuard() { c->want_view = false; }
+  } guard{c};
+  c->want_view = true;
+  const int rc = c->params.method == ICPGPU_GICP ? align_gicp(c, guess, nullptr, want_fitness, res) : align_p2p(c, guess, nullptr, want_fitness, res);
+  if (res != user_res) {
+    std::memset(user_res, 0, c->abi_result);
+    std::memcpy(user_res, res, std::min(c->abi_result, sizeof(own)));
+  }
+  if (rc == ICPGPU_OK && c->src.n) {
+    *view_xyzw = static_cast<const float*>(c->h_stage);
+    *n_out = c->src.n;
+  }
+  return rc;
 }
 
 int icpgpu_transform(icpgpu_ctx* c, const float* T, float* out_xyzw) {

@@ -6,8 +6,12 @@ namespace icpgpu_impl {
 
 // pcl::VoxelGrid<PointXYZ>::filter on a device-resident cloud (icp_odometer.cpp:96-101). out receives *n_out points
 // (ascending cell index). *passthrough = PCL's "leaf size too small for the input dataset" case: input returned as is.
+// publish (icpgpu_voxel_grid_view): the result also goes into the pinned staging buffer, written by a kernel queued right behind the
+// filter's last one, and its content fingerprint rides on the read-back of the cell count -- *published says whether that happened
+// (the direct path ran and the result fits the staging buffer); *fp_sum is the fingerprint's sum then.
 int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, DeviceBuf& out, int* n_out, bool* passthrough,
-                        int* bbox_enc_out) {
+                        int* bbox_enc_out, bool publish, bool* published, unsigned long long* fp_sum) {
+  if (published) *published = false;
   *n_out = 0;
   *passthrough = false;
   if (bbox_enc_out)
@@ -63,20 +67,31 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
       c->vox_pub_zeroed = c->vox_pub.ptr;
       c->vox_pub_zeroed_cap = c->vox_pub.cap;
     }
+    // (the staging buffer is sized for the input: a filter's result is never longer)
+    int stage_points = 0;
+    if (publish && (size_t)n * sizeof(float4) <= kStageMaxBytes && !ensure_stage(c, (size_t)n * sizeof(float4))) stage_points = n;
+    auto* d_fp = reinterpret_cast<unsigned long long*>(d_ints + 10);  // (8-byte aligned: the buffer is)
     HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
     hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
                                              static_cast<unsigned long long*>(c->vox_pub.ptr),
                                              static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
                                              static_cast<unsigned long long*>(c->vox_vals.ptr), static_cast<float4*>(out.ptr),
-                                             d_ints + 6, d_ints + 8, c->stream);
+                                             d_ints + 6, d_ints + 8, c->stream, stage_points ? d_fp : nullptr);
     if (le != hipSuccess) {
       c->vox_bins_zeroed = nullptr;
       return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
     }
     HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    if ((rc = fetch_ints(c, d_ints + 6, 3, c->h_ints + 6))) {
+    if (stage_points)
+      HIP_TRY(c, launch_publish_cloud(static_cast<const float4*>(out.ptr), d_ints + 6, n, stage_points, static_cast<float4*>(c->h_stage_dev), d_fp,
+                                      c->stream));
+    if ((rc = fetch_ints(c, d_ints + 6, stage_points ? 6 : 3, c->h_ints + 6))) {
       c->vox_bins_zeroed = nullptr;
       return rc;
+    }
+    if (stage_points && c->h_ints[8] == 0 && published) {
+      *published = true;
+      std::memcpy(fp_sum, c->h_ints + 10, sizeof *fp_sum);
     }
     {  // (the events lie in front of the posted kernel: complete by now; should the runtime not have noticed yet, wait for the second)
       hipError_t te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
@@ -160,6 +175,43 @@ int icpgpu_voxel_grid(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, fl
     c->vox_box_valid = true;
   }
   if (m && out_xyzw && (rc = fetch_filtered(c, out_xyzw, (size_t)m))) return rc;
+  *n_out = (size_t)m;
+  return ICPGPU_OK;
+}
+
+int icpgpu_voxel_grid_view(icpgpu_ctx* c, const float* xyzw, size_t n, float leaf, const float** view_xyzw, size_t* n_out) {
+  ENTER(c);
+  if (!n_out || !view_xyzw || (n && !xyzw)) return fail(c, ICPGPU_ERR_INVALID_ARG, "null argument");
+  if (n > (size_t)INT32_MAX - 4096) return fail(c, ICPGPU_ERR_INVALID_ARG, "cloud too large: %zu points", n);
+  *n_out = 0;
+  *view_xyzw = nullptr;
+  c->vox_last_n = 0;
+  c->vox_fp_valid = c->vox_box_valid = false;
+  int rc = ensure(c, c->vox_in, n * sizeof(float4));
+  if (rc) return rc;
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->vox_in.ptr, xyzw, n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  int m = 0;
+  bool pass = false, published = false;
+  unsigned long long fp_sum = 0;
+  int box[6];
+  if ((rc = voxel_filter_device(c, static_cast<const float4*>(c->vox_in.ptr), (int)n, leaf, c->vox_out, &m, &pass, box, /*publish=*/true, &published,
+                                &fp_sum)))
+    return rc;
+  c->vox_last_n = (size_t)m;
+  if (m > 0) {
+    std::memcpy(c->vox_box, box, sizeof(box));
+    c->vox_box_valid = true;
+    if (published) {  // the points are in the staging buffer already: they arrived in front of the cell count
+      c->vox_fp = fp_finish(fp_sum, (unsigned long long)m);
+      c->vox_sample_fp = sample_fingerprint(static_cast<const float*>(c->h_stage), (size_t)m);
+      c->vox_fp_valid = true;
+      c->prof.voxel_views_direct += 1;
+    } else {  // the sort path, a pass-through or a cloud beyond the staging buffer: the copy engine brings them
+      if ((rc = ensure_stage(c, (size_t)m * sizeof(float4), /*any_size=*/true))) return rc;
+      if ((rc = fetch_filtered(c, static_cast<float*>(c->h_stage), (size_t)m))) return rc;
+    }
+    *view_xyzw = static_cast<const float*>(c->h_stage);
+  }
   *n_out = (size_t)m;
   return ICPGPU_OK;
 }

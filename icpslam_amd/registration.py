@@ -173,6 +173,20 @@ class Context:
                                          C.byref(res)))
         return result_dict(res, out)
 
+    def align_view(self, guess=None, want_fitness: bool = False):
+        """icpgpu_align_view: align with the aligned cloud taken from the context's staging buffer (copied here: the view lives until
+        the context's next call)."""
+        res = Result()
+        g = None
+        if guess is not None:
+            gbuf = _colmajor16(guess)
+            g = _fp(gbuf)
+        view = C.POINTER(C.c_float)()
+        n_out = C.c_size_t()
+        self._check(self._L.icpgpu_align_view(self._h, g, int(want_fitness), C.byref(res), C.byref(view), C.byref(n_out)))
+        out = np.ctypeslib.as_array(view, shape=(n_out.value, 4)).copy() if n_out.value else np.empty((0, 4), np.float32)
+        return result_dict(res, out)
+
     def fitness(self, max_range: float = float(np.finfo(np.float64).max)) -> float:
         v = C.c_double()
         self._check(self._L.icpgpu_fitness(self._h, float(max_range), C.byref(v)))
@@ -246,6 +260,17 @@ class Context:
         n_out = C.c_size_t()
         self._check(self._L.icpgpu_voxel_grid(self._h, _fp(cloud), cloud.shape[0], float(leaf), _fp(out), C.byref(n_out)))
         return out[: n_out.value].copy()
+
+    def voxel_grid_view(self, cloud, leaf: float) -> np.ndarray:
+        """icpgpu_voxel_grid_view: the filtered cloud copied out of the context's staging buffer (one host copy; the view itself is
+        only valid until the context's next call)."""
+        cloud = _as_cloud(cloud)
+        view = C.POINTER(C.c_float)()
+        n_out = C.c_size_t()
+        self._check(self._L.icpgpu_voxel_grid_view(self._h, _fp(cloud), cloud.shape[0], float(leaf), C.byref(view), C.byref(n_out)))
+        if n_out.value == 0:
+            return np.empty((0, 4), np.float32)
+        return np.ctypeslib.as_array(view, shape=(n_out.value, 4)).copy()
 
     def set_source_voxel_filtered(self, cloud, leaf: float) -> int:
         cloud = _as_cloud(cloud)

@@ -37,7 +37,7 @@ extern "C" {
 #endif
 
 #define ICPGPU_VERSION_MAJOR 1
-#define ICPGPU_VERSION_MINOR 0
+#define ICPGPU_VERSION_MINOR 1
 #define ICPGPU_HEADER_VERSION (ICPGPU_VERSION_MAJOR * 1000 + ICPGPU_VERSION_MINOR)
 /* ABI rule (1.0).  icpgpu_params, icpgpu_result and icpgpu_profile only ever GROW AT THE END, and the library never assumes the
  * caller's structs are as long as its own: the caller's sizeof of the three travels with icpgpu_create (the macro below hands them
@@ -210,6 +210,8 @@ typedef struct {
                                     * the voxel filter + the last cloud's cell size; the statistics are checked at the alignment's first
                                     * wait) -- 1.0 */
   uint64_t cov_grids_rebuilt;      /* ... of which the check failed: rebuilt the waiting way, the alignment started over -- 1.0 */
+  uint64_t voxel_views_direct;     /* icpgpu_voxel_grid_view calls whose points reached the host in front of the cell count (the others
+                                    * went through the copy engine: sort path, pass-through, a result beyond the staging buffer) -- 1.1 */
 } icpgpu_profile;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -271,6 +273,12 @@ int icpgpu_promote_source_to_target(icpgpu_ctx* ctx);
  *               D2H copy (the reference only publishes it for debugging, icp_odometer.cpp:216-218)
  *   want_fitness : != 0 also evaluates getFitnessScore() (one more NN sweep)                     */
 int icpgpu_align(icpgpu_ctx* ctx, const float* guess, float* out_xyzw, int want_fitness, icpgpu_result* result);
+/* the same, the aligned cloud handed out as a VIEW: *view_xyzw points at *n_out points in the context's pinned staging buffer
+ * (written there by the transform kernel itself, in front of the fitness sweep), valid until the context's next call.  For a
+ * caller that owns a container to fill -- align(output) resizes `output` (icp_odometer.cpp:196-198): `output.points.assign(view,
+ * view + n)` is one pass where resize + copy are two.  1.1 */
+int icpgpu_align_view(icpgpu_ctx* ctx, const float* guess, int want_fitness, icpgpu_result* result, const float** view_xyzw,
+                      size_t* n_out);
 
 /* replaces getFitnessScore(max_range) (icp_odometer.cpp:201) using the last align's transform. */
 int icpgpu_fitness(icpgpu_ctx* ctx, double max_range, double* out_fitness);
@@ -342,6 +350,12 @@ int icpgpu_voxel_grid(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, 
  * out_xyzw = NULL above -- *n_out is the number of voxels, the filtered cloud stays in HBM -- then fetch it into a
  * buffer of `capacity` >= *n_out points.  Valid until the context's next voxel-filter call. */
 int icpgpu_voxel_grid_fetch(icpgpu_ctx* ctx, float* out_xyzw, size_t capacity, size_t* n_out);
+/* one-step form of the same (1.1): filter, and hand the result out as a VIEW -- *view_xyzw points at *n_out points in the context's
+ * pinned staging buffer, valid until the context's next call.  The points are written there by a kernel queued behind the filter's
+ * last one and arrive in front of the cell count the host waits for anyway: no second round trip, no copy engine
+ * (pcl::VoxelGrid::filter(output): `output.points.assign(view, view + n)`).  The cloud also stays in HBM, and icpgpu_set_source
+ * recognises the host copy, exactly as after icpgpu_voxel_grid. */
+int icpgpu_voxel_grid_view(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, const float** view_xyzw, size_t* n_out);
 /* the odometer's pre-step fused with setInputSource: upload, filter on the device, and make the
  * filtered cloud the source without a round trip to the host (icp_odometer.cpp:177 then :193). */
 int icpgpu_set_source_voxel_filtered(icpgpu_ctx* ctx, const float* xyzw, size_t n, float leaf, size_t* n_out);

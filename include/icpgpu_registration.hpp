@@ -34,6 +34,24 @@
 
 #include "icpgpu.h"
 
+// -DICPGPU_SHIM_TIMING (development): wall time of the phases of align() -- 1 the uploads / recognitions, 2 icpgpu_align_view,
+// 3 filling `output` -- summed in icpgpu::detail::shim_us[] (not thread-safe: for harnesses that run one callback at a time)
+#if defined(ICPGPU_SHIM_TIMING)
+#include <chrono>
+namespace icpgpu { namespace detail {
+inline double* shim_us_array() { static double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return v; }
+inline void shim_mark(int k) {
+  static std::chrono::steady_clock::time_point t;
+  const auto now = std::chrono::steady_clock::now();
+  if (k > 0) shim_us_array()[k] += std::chrono::duration<double, std::micro>(now - t).count();
+  t = now;
+}
+} }
+#define ICPGPU_SHIM_MARK(k) ::icpgpu::detail::shim_mark(k)
+#else
+#define ICPGPU_SHIM_MARK(k) ((void)0)
+#endif
+
 #if defined(__has_include)
 #if __has_include(<Eigen/Core>)
 #include <Eigen/Core>
@@ -288,19 +306,29 @@ class IterativeClosestPoint {
     aligned_ = false;
     result_.converged = 0;
     if (!source_ || (!target_ && !target_from_map_)) return;  // PCL: initCompute() fails, align returns, converged_ stays false
+    ICPGPU_SHIM_MARK(-1);
     if (!upload()) return;
     const std::size_t ns = source_->points.size();
-    output.points.resize(ns);
-    detail::set_cloud_shape(output, ns, 0);
-    float* out = ns ? reinterpret_cast<float*>(&output.points[0]) : nullptr;
     generation_ = ++ctx_holder_->generation;
     // getFitnessScore() nearly always follows (icp_odometer.cpp:201): evaluated inside align it is one more sweep queued behind
-    // the last iteration instead of a call of its own (setFitnessWithAlign(false) for callers that never ask: octree_mapper.cpp:117)
-    if (icpgpu_align(ctx_, guess, out, fitness_with_align_ ? 1 : 0, &result_) != ICPGPU_OK) {
+    // the last iteration instead of a call of its own (setFitnessWithAlign(false) for callers that never ask: octree_mapper.cpp:117).
+    // The aligned cloud comes as a view of the context's pinned staging buffer (the transform kernel writes it there while the
+    // fitness sweep is still to run): `assign` fills `output` in one pass -- resize() + a copy would touch it twice.
+    const float* view = nullptr;
+    std::size_t nv = 0;
+    ICPGPU_SHIM_MARK(1);
+    if (icpgpu_align_view(ctx_, guess, fitness_with_align_ ? 1 : 0, &result_, &view, &nv) != ICPGPU_OK || nv != ns) {
       result_.converged = 0;
+      output.points.resize(ns);  // (PCL sizes the output before it computes anything)
+      detail::set_cloud_shape(output, ns, 0);
       return;
     }
+    ICPGPU_SHIM_MARK(2);
+    const PointT* first = reinterpret_cast<const PointT*>(view);
+    output.points.assign(first, first + nv);
+    detail::set_cloud_shape(output, ns, 0);
     aligned_ = true;
+    ICPGPU_SHIM_MARK(3);
   }
 
   detail::ContextPtr ctx_holder_;
@@ -352,12 +380,19 @@ class VoxelGrid {
     if (!input_) return;
     const std::size_t n = input_->points.size();
     std::size_t m = 0;
-    // two steps: filter (the result stays in HBM), size `output` by the voxel count, fetch -- sizing it for the worst case
-    // first would value-initialise n points (3.2 MB for a raw 200k-point scan) to receive a tenth of them
-    int rc = icpgpu_voxel_grid(ctx_, n ? reinterpret_cast<const float*>(&input_->points[0]) : nullptr, n, leaf_, nullptr, &m);
-    output.points.resize(rc == ICPGPU_OK ? m : 0);
-    if (rc == ICPGPU_OK && m) rc = icpgpu_voxel_grid_fetch(ctx_, reinterpret_cast<float*>(&output.points[0]), m, &m);
-    if (rc != ICPGPU_OK) output.points.resize(0);
+    // the result as a view of the context's pinned staging buffer (the points arrive there in front of the voxel count the call
+    // waits for): `assign` sizes and fills `output` in one pass -- sizing it for the worst case first would value-initialise n points
+    // (3.2 MB for a raw 200k-point scan) to receive a tenth of them, and a fetch of its own is a second round trip to the device
+    typedef typename std::remove_reference<decltype(output.points[0])>::type PointT;
+    static_assert(sizeof(PointT) == 16, "icpgpu: 16-byte points (pcl::PointXYZ)");
+    const float* view = nullptr;
+    const int rc = icpgpu_voxel_grid_view(ctx_, n ? reinterpret_cast<const float*>(&input_->points[0]) : nullptr, n, leaf_, &view, &m);
+    if (rc == ICPGPU_OK && m) {
+      const PointT* first = reinterpret_cast<const PointT*>(view);
+      output.points.assign(first, first + m);
+    } else {
+      output.points.resize(0);
+    }
     detail::set_cloud_shape(output, output.points.size(), 0);
   }
 

@@ -163,5 +163,12 @@ int main(int argc, char** argv) {
                 "align %.1f | getFinalTransformation + hasConverged + getFitnessScore %.1f | result line + *prev = *curr %.1f\n",
                 odo.stage_n, odo.stage_us[0] / odo.stage_n, odo.stage_us[1] / odo.stage_n, odo.stage_us[2] / odo.stage_n, odo.stage_us[3] / odo.stage_n,
                 odo.stage_us[4] / odo.stage_n, odo.stage_us[5] / odo.stage_n);
+#if defined(ICPGPU_SHIM_TIMING)
+  {  // (all callbacks, the warm-up ones included)
+    const double* u = icpgpu::detail::shim_us_array();
+    std::printf("SHIM us per align (%d aligns): uploads / recognitions %.1f | icpgpu_align_view %.1f | output.points.assign %.1f\n", n_scans - 1,
+                u[1] / (n_scans - 1), u[2] / (n_scans - 1), u[3] / (n_scans - 1));
+  }
+#endif
   return 0;
 }

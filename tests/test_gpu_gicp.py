@@ -519,3 +519,57 @@ def test_covariance_grid_built_ahead_of_its_statistics(built, tmp_path):
             assert unchecked == 0 and rebuilt == 0
         else:
             assert unchecked >= 2 and rebuilt == unchecked      # every build that went ahead was caught and repeated
+
+
+def test_selecting_covariance_kernel_equals_the_streaming_one_and_the_oracle(tmp_path):
+    """Round 6: gicp_cov_select_kernel (a level's candidates evaluated into registers, the 20 nearest selected by a distance threshold
+    and ranked by counting) against gicp_cov_kernel (the streaming top-20, ICPGPU_COV_SELECT=0 in the development flavour) and the
+    oracle: the same covariances BIT FOR BIT on a voxel-filtered scan (the reference's case, icp_odometer.cpp:177,198), a raw scan
+    (dense near field: levels beyond the 512 candidates the registers hold go to the streaming kernel), a lattice (dozens of
+    neighbours at one distance: the threshold cannot separate them), a cloud of 25 points (the search reaches the whole grid),
+    duplicates and non-finite points."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(61)
+    scene = synth.make_scene(5, extent=120.0)
+    raw = synth.scan(scene, np.eye(4), 120000, seed=7300)
+    g = np.arange(14, dtype=np.float32) * np.float32(0.25)
+    lattice = np.ones((14 ** 3, 4), np.float32)
+    lattice[:, :3] = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    tiny = np.ones((25, 4), np.float32)
+    tiny[:, :3] = rng.uniform(-2, 2, (25, 3)).astype(np.float32)
+    dup = np.ones((4000, 4), np.float32)
+    dup[:, :3] = rng.uniform(-5, 5, (4000, 3)).astype(np.float32)
+    dup[1000:1600, :3] = dup[0, :3]          # 600 copies of one point: every one of them sees 600 neighbours at distance 0
+    bad = synth.scan(scene, np.eye(4), 30000, seed=7301)
+    bad[17, 0] = np.nan
+    bad[4000, 2] = np.inf
+    clump = np.ones((6000, 4), np.float32)
+    clump[:, :3] = rng.normal(0, 0.05, (6000, 3)).astype(np.float32)   # thousands of candidates in the first cube
+    clouds = dict(filtered=oracle.voxel_grid(raw, 0.2), raw=raw[:60000], lattice=lattice, tiny=tiny, dup=dup, bad=bad, clump=clump)
+    np.savez(tmp_path / "clouds.npz", **clouds)
+    code = (
+        "import sys, numpy as np\n"
+        "from icpslam_amd import Context, GICP\n"
+        "z = np.load(sys.argv[1]); out = {}\n"
+        "with Context(0) as c:\n"
+        "    c.set_params(c.default_params(), method=GICP)\n"
+        "    for k in z.files:\n"
+        "        c.set_source(z[k]); out[k] = c.gicp_covariances()\n"
+        "np.savez(sys.argv[2], **out)\n")
+    res = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, ICPGPU_FLAVOUR="dev", ICPGPU_COV_SELECT=flag, PYTHONPATH=root)
+        path = str(tmp_path / f"cov{flag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "clouds.npz"), path], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = dict(np.load(path))
+    for k, cloud in clouds.items():
+        a, b = res["1"][k], res["0"][k]
+        assert a.shape == (len(cloud), 3, 3)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), k   # (NaNs never leave the finish kernel: identity instead)
+        fin = np.isfinite(cloud[:, :3]).all(axis=1)
+        ref = oracle.gicp_covariances(cloud[fin])
+        diff = np.abs(a[fin] - ref).reshape(int(fin.sum()), -1).max(axis=1)
+        assert (diff > 0).mean() <= 0.001 and diff.max() <= 1e-6, (k, (diff > 0).mean(), diff.max())

@@ -183,3 +183,41 @@ def test_voxel_published_count_timeout_hands_over_to_the_sort_path(tmp_path):
     env = dict(os.environ, ICPGPU_VOXEL_TEST_STALL="1", ICPGPU_FLAVOUR="dev", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_voxel_grid_view_equals_the_oracle_and_is_recognised_as_the_source(ctx):
+    """Round 6 (icpgpu.h 1.1): icpgpu_voxel_grid_view hands the filtered cloud out of the pinned staging buffer -- written there by
+    a kernel behind the filter's last one, its fingerprint riding on the cell count's read-back.  Same bits as the oracle (and as
+    icpgpu_voxel_grid); icpgpu_set_source recognises the host copy (no upload: sources_adopted); clouds the direct path hands to the
+    sort path, PCL's pass-through case, an empty cloud and a cloud beyond the staging buffer come through the copy engine with
+    the same bits."""
+    scene = synth.make_scene(7)
+    rng = np.random.default_rng(77)
+    ctx.profile_reset()
+    for rep, n in enumerate((200000, 50000, 777, 120000)):
+        cloud = synth.scan(scene, np.eye(4), n, seed=60 + rep)
+        got, ref = ctx.voxel_grid_view(cloud, 0.2), oracle.voxel_grid(cloud, 0.2)
+        assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref)), n
+        assert np.array_equal(_bits(got), _bits(ctx.voxel_grid(cloud, 0.2)))
+        got = ctx.voxel_grid_view(cloud, 0.2)
+        before = ctx.profile().sources_adopted
+        ctx.set_source(got)
+        assert ctx.profile().sources_adopted == before + 1, n
+    p = ctx.profile()
+    assert p.voxel_views_direct == 8, p.voxel_views_direct
+    # thousands of points in one voxel: the direct path reports the cloud, the sort path runs, the copy engine brings the result
+    dup = np.ones((30000, 4), np.float32)
+    dup[:, :3] = np.float32(0.123)
+    dup[15000:, :3] = rng.uniform(-3, 3, (15000, 3)).astype(np.float32)
+    got, ref = ctx.voxel_grid_view(dup, 0.2), oracle.voxel_grid(dup, 0.2)
+    assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
+    # PCL's "leaf size is too small": the input comes back unchanged
+    wide = synth.make_pair(3000, 10, seed=7)[0]
+    got, ref = ctx.voxel_grid_view(wide, 1e-4), oracle.voxel_grid(wide, 1e-4)
+    assert got.shape == ref.shape == wide.shape and np.array_equal(_bits(got), _bits(wide)) and np.array_equal(_bits(ref), _bits(wide))
+    assert ctx.voxel_grid_view(np.empty((0, 4), np.float32), 0.2).shape == (0, 4)
+    # 700k points = 11 MB: beyond the staging buffer's 8 MB, the view still holds the whole result
+    big = synth.scan(scene, np.eye(4), 700000, seed=99)
+    got, ref = ctx.voxel_grid_view(big, 0.05), oracle.voxel_grid(big, 0.05)
+    assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
+    assert ctx.profile().voxel_views_direct == 8
