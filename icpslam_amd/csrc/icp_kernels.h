@@ -394,7 +394,10 @@ size_t voxel_direct_scratch_ints(int n);
 int voxel_direct_groups(int n);
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
                                     unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
-                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word = nullptr);
+                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word = nullptr,
+                                    const int* d_bbox6 = nullptr, int* d_plan = nullptr);
+// (d_plan, 8 ints, with d_bbox6 = launch_bbox's result queued in front: the device derives minb / divb / the buckets itself and the
+// host need not have seen the box; plan[7] = 0 the filter ran, 1 no finite point, 2 PCL's pass-through, 3 the sort path's cloud)
 // (clear_word, optional: a 64-bit word of device memory the last kernel sets to zero -- launch_publish_cloud's accumulator)
 
 }  // namespace icpgpu

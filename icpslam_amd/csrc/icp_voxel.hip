@@ -140,10 +140,72 @@ constexpr int VX_SORT = 4096;
 constexpr int VX_CHUNK = 256;  // elements one wave sorts without workgroup barriers (4 per lane)
 constexpr int VX_PER = VX_BINS / VX_BLOCK;  // histogram bins per thread in the scans
 
+// The filter's parameters as the DEVICE derives them from the bounding box (voxel_plan_kernel): with a plan the kernels below read
+// them from memory instead of taking them as arguments, and the host does not wait for the box before it queues them (round 6).
+struct VoxelPlan {
+  int minb[3], mul_y, mul_z;
+  unsigned int cpb;
+  int nbins;
+  int pre;  // 0: the direct path runs; 1: no finite point; 2: PCL's "leaf size too small" (input returned); 3: the index may wrap (sort path)
+};
+
+// (inv_leaf = 1 / leaf in float, as PCL's inverse_leaf_size_; the arithmetic is voxel_filter_device's, operation for operation)
+__global__ void voxel_plan_kernel(const int* __restrict__ bbox6, float inv_leaf, VoxelPlan* __restrict__ plan, int* __restrict__ d_n_out,
+                                  int* __restrict__ status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) {
+    const int el = bbox6[a], eh = bbox6[3 + a];
+    lo[a] = __int_as_float(el >= 0 ? el : el ^ 0x7FFFFFFF);
+    hi[a] = __int_as_float(eh >= 0 ? eh : eh ^ 0x7FFFFFFF);
+  }
+  VoxelPlan p;
+  p.pre = 0;
+  p.cpb = 1u;
+  p.nbins = 1;
+  p.mul_y = p.mul_z = 0;
+  p.minb[0] = p.minb[1] = p.minb[2] = 0;
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) {
+    p.pre = 1;
+  } else {
+    long long d[3];
+    int divb[3];
+    for (int a = 0; a < 3; ++a) {
+      d[a] = (long long)((hi[a] - lo[a]) * inv_leaf) + 1;
+      p.minb[a] = (int)floorf(lo[a] * inv_leaf);
+      divb[a] = (int)floorf(hi[a] * inv_leaf) - p.minb[a] + 1;
+    }
+    const long long ncells = (long long)divb[0] * divb[1] * divb[2];
+    if (d[0] * d[1] * d[2] > (long long)INT32_MAX) p.pre = 2;
+    else if (ncells > (long long)INT32_MAX) p.pre = 3;
+    else {
+      p.mul_y = divb[0];
+      p.mul_z = divb[0] * divb[1];
+      p.cpb = (unsigned int)((ncells + VX_BINS - 1) / VX_BINS);
+      p.nbins = (int)((ncells - 1) / p.cpb) + 1;
+    }
+  }
+  *plan = p;
+  if (p.pre != 0) {  // nothing below runs: an empty result, the host reads `pre`
+    d_n_out[0] = d_n_out[1] = 0;
+    *status = 0;
+  }
+}
+
 __global__ __launch_bounds__(VX_BLOCK) void voxel_hist_kernel(const float4* __restrict__ pts, int n, float inv_leaf, int minb_x,
                                                               int minb_y, int minb_z, int mul_y, int mul_z, unsigned int cpb, int nbins,
                                                               int* __restrict__ keys, int* __restrict__ relpos,
-                                                              int* __restrict__ hist) {
+                                                              int* __restrict__ hist, const VoxelPlan* __restrict__ plan) {
+  if (plan) {  // (uniform: scalar loads)
+    if (plan->pre != 0) return;
+    minb_x = plan->minb[0];
+    minb_y = plan->minb[1];
+    minb_z = plan->minb[2];
+    mul_y = plan->mul_y;
+    mul_z = plan->mul_z;
+    cpb = plan->cpb;
+    nbins = plan->nbins;
+  }
   __shared__ int lh[VX_BINS];
   for (int b = threadIdx.x; b < nbins; b += VX_BLOCK) lh[b] = 0;
   __syncthreads();
@@ -206,7 +268,11 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_scatter_kernel(const int* __re
                                                                  int n, unsigned int cpb, int nbins, const int* __restrict__ hist,
                                                                  int n_groups, int4* __restrict__ group_range,
                                                                  int* __restrict__ status,
-                                                                 unsigned long long* __restrict__ comp) {
+                                                                 unsigned long long* __restrict__ comp, const VoxelPlan* __restrict__ plan) {
+  if (plan) {
+    if (plan->pre != 0) return;
+    cpb = plan->cpb;
+  }
   __shared__ int st[VX_BINS + 1];  // first item of every bucket
   __shared__ int wsum[VX_BLOCK / 64];
   // this thread's eight buckets of the histogram (two 16-byte loads) and its points, all in flight together
@@ -433,9 +499,14 @@ __global__ __launch_bounds__(VX_BLOCK) void voxel_group_kernel(const float4* __r
                                                                unsigned int epoch, float4* __restrict__ out,
                                                                int* __restrict__ d_n_out, int* __restrict__ hist, int nbins,
                                                                int* __restrict__ status, long long* __restrict__ dbg,
-                                                               int test_stall, unsigned long long* __restrict__ clear_word) {
+                                                               int test_stall, unsigned long long* __restrict__ clear_word,
+                                                               const VoxelPlan* __restrict__ plan) {
   // (the accumulator of the kernel that may follow -- publish_cloud_kernel's fingerprint -- starts from zero)
   if (clear_word && blockIdx.x == 0 && threadIdx.x == 0) *clear_word = 0ull;
+  if (plan) {
+    if (plan->pre != 0) return;
+    nbins = plan->nbins;
+  }
   long long stamp[6] = {0, 0, 0, 0, 0, 0};
 #define VX_STAMP(k) do { if (dbg && threadIdx.x == 0) stamp[k] = (long long)wall_clock64(); } while (0)
   VX_STAMP(0);
@@ -640,14 +711,25 @@ size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 4 * (size
 // call's when its upper half is this call's number: memory that once held anything else could pass for one); keys: n ints;
 // relpos: n ints; comp: n 64-bit words; d_n_out: 2 ints (sum = cells written); status: 1 int, non-zero = not done, use the
 // sort path.
+// d_plan (with d_bbox6): the parameters are derived on the device from the encoded bounding box in d_bbox6 (launch_bbox's result,
+// queued in front) -- minb / divb are not looked at, the host has not seen the box yet; 8 ints of device memory.
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
                                     unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
-                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word) {
+                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word, const int* d_bbox6,
+                                    int* d_plan) {
+  static_assert(sizeof(VoxelPlan) == 8 * sizeof(int), "the plan is read back as 8 ints");
+  const VoxelPlan* plan = reinterpret_cast<const VoxelPlan*>(d_plan);
+  static const int no3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
+  if (plan) {
+    hipLaunchKernelGGL(voxel_plan_kernel, dim3(1), dim3(64), 0, stream, d_bbox6, inv_leaf, reinterpret_cast<VoxelPlan*>(d_plan), d_n_out, status);
+    minb = no3;
+    divb = one3;
+  }
   const long long ncells = (long long)divb[0] * divb[1] * divb[2];
   // buckets of cpb consecutive cells, as many of the 8192 as the index space fills (a power-of-two bucket would leave up to
   // half of them unused -- 4350 for a raw scan at 0.2 m -- and the near-field buckets twice as full)
   const unsigned int cpb = (unsigned int)((ncells + VX_BINS - 1) / VX_BINS);
-  const int nbins = (int)((ncells - 1) / cpb) + 1;
+  const int nbins = plan ? VX_BINS : (int)((ncells - 1) / cpb) + 1;  // (with a plan: the kernels read theirs)
   const int groups = voxel_direct_groups(n);
   int* hist = bins;
   int4* group_range = reinterpret_cast<int4*>(bins + VX_BINS + 8);
@@ -656,9 +738,9 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
   if (epoch == 0u) epoch = ++call_counter;  // (zero is what a fresh buffer holds)
   const int blocks = (n + VX_BLOCK * VX_PPT - 1) / (VX_BLOCK * VX_PPT);
   hipLaunchKernelGGL(voxel_hist_kernel, dim3(blocks), dim3(VX_BLOCK), 0, stream, pts, n, inv_leaf, minb[0], minb[1], minb[2],
-                     divb[0], divb[0] * divb[1], cpb, nbins, keys, relpos, hist);
+                     divb[0], divb[0] * divb[1], cpb, nbins, keys, relpos, hist, plan);
   hipLaunchKernelGGL(voxel_scatter_kernel, dim3(blocks), dim3(VX_BLOCK), 0, stream, keys, relpos, n, cpb, nbins, hist, groups,
-                     group_range, status, comp);
+                     group_range, status, comp, plan);
   // ICPGPU_VOXEL_DEBUG=1 (development): phase time stamps of every group, the slowest ones printed
   static const bool debug = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_DEBUG"); return e && std::atoi(e) != 0; }();
   long long* dbg = nullptr;
@@ -673,7 +755,7 @@ hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, co
     return v;
   }();
   hipLaunchKernelGGL(voxel_group_kernel, dim3(groups), dim3(VX_BLOCK), 0, stream, pts, n, comp, group_range, published, epoch, out,
-                     d_n_out, hist, nbins, status, dbg, test_stall, clear_word);
+                     d_n_out, hist, nbins, status, dbg, test_stall, clear_word, plan);
   if (dbg) {
     std::vector<long long> h((size_t)groups * 8);
     (void)hipStreamSynchronize(stream);

@@ -18,16 +18,95 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
     for (int a = 0; a < 3; ++a) bbox_enc_out[a] = 1, bbox_enc_out[3 + a] = 0;  // (an empty box until the input's has been read back)
   if (!(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel filter: leaf size must be positive");
   if (n <= 0) return ICPGPU_OK;
-  int rc = ensure(c, c->vox_ints, 16 * sizeof(int));
+  // device ints: [0..5] the encoded bounding box, [6, 7] the cell counts, [8] the direct path's status, [10, 11] the published
+  // cloud's fingerprint, [16..23] the plan the device derives from the box (launch_voxel_grid_direct)
+  int rc = ensure(c, c->vox_ints, 32 * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(c->vox_ints.ptr);
   HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream));
-  if ((rc = fetch_ints(c, d_ints, 6, c->h_ints))) return rc;
-  float lo[3], hi[3];
-  decode_bbox(c->h_ints, lo, hi);
-  if (bbox_enc_out) std::memcpy(bbox_enc_out, c->h_ints, 6 * sizeof(int));  // the input's box: it contains every centroid
-  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
   const float inv = 1.0f / leaf;  // PCL: inverse_leaf_size_ = 1 / leaf_size_ in float
+  float ms = 0.f;
+  // the direct path (one distribution pass + a sort in LDS): every cloud up to 2M points; it reports the rare cloud it cannot
+  // take (thousands of points in one voxel) through `status`, and the library-sort path runs instead
+  static const bool force_sort = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
+  // Round 6: the direct path is queued BEHIND the bounding-box pass without the host having seen the box -- the device derives the
+  // filter's parameters itself (voxel_plan_kernel) -- so a scan's filter is ONE wait for the device (box, plan, counts, status and
+  // the published cloud's fingerprint arrive together) where it was two.  The rare clouds that are not the direct path's (PCL's
+  // pass-through, an index that may wrap, no finite point) show in the plan; the host then goes the old way with the box it has by
+  // then.  (development flavour, ICPGPU_VOXEL_PLANNED=0: the box first, as until round 5)
+  static const bool planned_enabled = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_PLANNED"); return !e || std::atoi(e) != 0; }();
+  const bool direct_size = !force_sort && n <= (1 << 21);
+  auto direct_scratch = [&]() -> int {
+    int r;
+    if ((r = ensure(c, out, (size_t)n * sizeof(float4)))) return r;
+    if ((r = ensure(c, c->vox_keys, (size_t)2 * n * sizeof(int)))) return r;
+    if ((r = ensure(c, c->vox_vals, (size_t)2 * n * sizeof(int)))) return r;
+    if ((r = ensure(c, c->vox_bins, voxel_direct_scratch_ints(n) * sizeof(int)))) return r;
+    if (c->vox_bins_zeroed != c->vox_bins.ptr || c->vox_bins_zeroed_cap != c->vox_bins.cap) {
+      HIP_TRY(c, hipMemsetAsync(c->vox_bins.ptr, 0, c->vox_bins.cap, c->stream));
+      c->vox_bins_zeroed = c->vox_bins.ptr;
+      c->vox_bins_zeroed_cap = c->vox_bins.cap;
+    }
+    if ((r = ensure(c, c->vox_pub, (size_t)voxel_direct_groups(n) * sizeof(unsigned long long)))) return r;
+    if (c->vox_pub_zeroed != c->vox_pub.ptr || c->vox_pub_zeroed_cap != c->vox_pub.cap) {
+      HIP_TRY(c, hipMemsetAsync(c->vox_pub.ptr, 0, c->vox_pub.cap, c->stream));
+      c->vox_pub_zeroed = c->vox_pub.ptr;
+      c->vox_pub_zeroed_cap = c->vox_pub.cap;
+    }
+    return ICPGPU_OK;
+  };
+  int stage_points = 0;
+  auto* d_fp = reinterpret_cast<unsigned long long*>(d_ints + 10);  // (8-byte aligned: the buffer is)
+  // queue the direct path's kernels (minb / divb: the host's values, or null = the device's plan)
+  auto direct_launch = [&](const int* minb, const int* divb) -> int {
+    // (the staging buffer is sized for the input: a filter's result is never longer)
+    stage_points = 0;
+    if (publish && (size_t)n * sizeof(float4) <= kStageMaxBytes && !ensure_stage(c, (size_t)n * sizeof(float4))) stage_points = n;
+    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
+                                             static_cast<unsigned long long*>(c->vox_pub.ptr),
+                                             static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
+                                             static_cast<unsigned long long*>(c->vox_vals.ptr), static_cast<float4*>(out.ptr),
+                                             d_ints + 6, d_ints + 8, c->stream, stage_points ? d_fp : nullptr, minb ? nullptr : d_ints,
+                                             minb ? nullptr : d_ints + 16);
+    if (le != hipSuccess) {
+      c->vox_bins_zeroed = nullptr;
+      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (stage_points)
+      HIP_TRY(c, launch_publish_cloud(static_cast<const float4*>(out.ptr), d_ints + 6, n, stage_points, static_cast<float4*>(c->h_stage_dev), d_fp,
+                                      c->stream));
+    return ICPGPU_OK;
+  };
+  auto direct_time = [&]() -> int {  // (the events lie in front of the posted kernel: complete by now; should the runtime not have noticed yet, wait for the second)
+    hipError_t te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    if (te == hipErrorNotReady) {
+      (void)hipGetLastError();
+      HIP_TRY(c, hipEventSynchronize(c->ev[1]));
+      te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    }
+    HIP_TRY(c, te);
+    return ICPGPU_OK;
+  };
+  int hv[24];
+  for (int& v : hv) v = 0;
+  const bool planned = planned_enabled && direct_size;
+  if (planned) {
+    if ((rc = direct_scratch())) return rc;
+    if ((rc = direct_launch(nullptr, nullptr))) return rc;
+    if ((rc = fetch_ints(c, d_ints, 24, hv))) {
+      c->vox_bins_zeroed = nullptr;
+      return rc;
+    }
+  } else if ((rc = fetch_ints(c, d_ints, 6, hv))) {
+    return rc;
+  }
+  std::memcpy(c->h_ints, hv, 12 * sizeof(int));
+  float lo[3], hi[3];
+  decode_bbox(hv, lo, hi);
+  if (bbox_enc_out) std::memcpy(bbox_enc_out, hv, 6 * sizeof(int));  // the input's box: it contains every centroid
+  if (!(lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2])) return ICPGPU_OK;  // no finite point
   int minb[3], divb[3];
   long long d[3];
   for (int a = 0; a < 3; ++a) {
@@ -45,64 +124,33 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   }
   if ((rc = ensure(c, c->vox_keys, (size_t)2 * n * sizeof(int)))) return rc;
   if ((rc = ensure(c, c->vox_vals, (size_t)2 * n * sizeof(int)))) return rc;
-  float ms = 0.f;
-  // the direct path (one distribution pass + a sort in LDS): every cloud up to 2M points; it reports the rare cloud it cannot
-  // take (thousands of points in one voxel) through `status`, and the library-sort path runs instead
-  static const bool force_sort = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_VOXEL_SORT"); return e && std::atoi(e) != 0; }();
   bool done = false;
   // (PCL's overflow test uses the float extents, its cell index the integer ones: when these are one cell wider the index of
   // the topmost cells can wrap in int32 and PCL -- and the sort path, on signed keys -- puts them first.  The direct path's
   // buckets assume keys in [0, number of cells): leave that corner to the sort path.)
   const bool keys_may_wrap = (long long)divb[0] * divb[1] * divb[2] > (long long)INT32_MAX;
-  if (!force_sort && !keys_may_wrap && n <= (1 << 21)) {
-    if ((rc = ensure(c, c->vox_bins, voxel_direct_scratch_ints(n) * sizeof(int)))) return rc;
-    if (c->vox_bins_zeroed != c->vox_bins.ptr || c->vox_bins_zeroed_cap != c->vox_bins.cap) {
-      HIP_TRY(c, hipMemsetAsync(c->vox_bins.ptr, 0, c->vox_bins.cap, c->stream));
-      c->vox_bins_zeroed = c->vox_bins.ptr;
-      c->vox_bins_zeroed_cap = c->vox_bins.cap;
+  if (planned) {
+    // the device decided by the same arithmetic: its verdict and the host's must agree
+    const int pre = hv[23];
+    if ((pre == 0) != !keys_may_wrap) return fail(c, ICPGPU_ERR_HIP, "voxel filter: the device's plan (%d) and the host's disagree (internal error)", pre);
+    if (pre == 0) {
+      if ((rc = direct_time())) return rc;
+      done = hv[8] == 0;
     }
-    if ((rc = ensure(c, c->vox_pub, (size_t)voxel_direct_groups(n) * sizeof(unsigned long long)))) return rc;
-    if (c->vox_pub_zeroed != c->vox_pub.ptr || c->vox_pub_zeroed_cap != c->vox_pub.cap) {
-      HIP_TRY(c, hipMemsetAsync(c->vox_pub.ptr, 0, c->vox_pub.cap, c->stream));
-      c->vox_pub_zeroed = c->vox_pub.ptr;
-      c->vox_pub_zeroed_cap = c->vox_pub.cap;
-    }
-    // (the staging buffer is sized for the input: a filter's result is never longer)
-    int stage_points = 0;
-    if (publish && (size_t)n * sizeof(float4) <= kStageMaxBytes && !ensure_stage(c, (size_t)n * sizeof(float4))) stage_points = n;
-    auto* d_fp = reinterpret_cast<unsigned long long*>(d_ints + 10);  // (8-byte aligned: the buffer is)
-    HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
-    hipError_t le = launch_voxel_grid_direct(d_in, n, inv, minb, divb, static_cast<int*>(c->vox_bins.ptr),
-                                             static_cast<unsigned long long*>(c->vox_pub.ptr),
-                                             static_cast<int*>(c->vox_keys.ptr), static_cast<int*>(c->vox_keys.ptr) + n,
-                                             static_cast<unsigned long long*>(c->vox_vals.ptr), static_cast<float4*>(out.ptr),
-                                             d_ints + 6, d_ints + 8, c->stream, stage_points ? d_fp : nullptr);
-    if (le != hipSuccess) {
-      c->vox_bins_zeroed = nullptr;
-      return fail(c, ICPGPU_ERR_HIP, "voxel filter: %s", hipGetErrorString(le));
-    }
-    HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
-    if (stage_points)
-      HIP_TRY(c, launch_publish_cloud(static_cast<const float4*>(out.ptr), d_ints + 6, n, stage_points, static_cast<float4*>(c->h_stage_dev), d_fp,
-                                      c->stream));
-    if ((rc = fetch_ints(c, d_ints + 6, stage_points ? 6 : 3, c->h_ints + 6))) {
+  } else if (direct_size && !keys_may_wrap) {
+    if ((rc = direct_scratch())) return rc;
+    if ((rc = direct_launch(minb, divb))) return rc;
+    if ((rc = fetch_ints(c, d_ints + 6, stage_points ? 6 : 3, hv + 6))) {
       c->vox_bins_zeroed = nullptr;
       return rc;
     }
-    if (stage_points && c->h_ints[8] == 0 && published) {
-      *published = true;
-      std::memcpy(fp_sum, c->h_ints + 10, sizeof *fp_sum);
-    }
-    {  // (the events lie in front of the posted kernel: complete by now; should the runtime not have noticed yet, wait for the second)
-      hipError_t te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
-      if (te == hipErrorNotReady) {
-        (void)hipGetLastError();
-        HIP_TRY(c, hipEventSynchronize(c->ev[1]));
-        te = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
-      }
-      HIP_TRY(c, te);
-    }
-    done = c->h_ints[8] == 0;
+    std::memcpy(c->h_ints + 6, hv + 6, 6 * sizeof(int));
+    if ((rc = direct_time())) return rc;
+    done = hv[8] == 0;
+  }
+  if (done && stage_points && published) {
+    *published = true;
+    std::memcpy(fp_sum, hv + 10, sizeof *fp_sum);
   }
   if (!done) {
     const size_t tb = voxel_temp_bytes(n);

@@ -221,3 +221,49 @@ def test_voxel_grid_view_equals_the_oracle_and_is_recognised_as_the_source(ctx):
     got, ref = ctx.voxel_grid_view(big, 0.05), oracle.voxel_grid(big, 0.05)
     assert got.shape == ref.shape and np.array_equal(_bits(got), _bits(ref))
     assert ctx.profile().voxel_views_direct == 8
+
+
+def test_filter_queued_behind_the_box_equals_the_filter_that_waits_for_it(tmp_path):
+    """Round 6: the direct path's kernels are queued behind the bounding-box pass and take their parameters from a plan the DEVICE
+    derives from the box (one wait per filter instead of two).  Against the oracle on the clouds that decide the plan -- a scan, no
+    finite point at all, PCL's pass-through, an index that wraps (the sort path's), a single point -- and, in the development flavour
+    with ICPGPU_VOXEL_PLANNED=0 (the box first, as until round 5), the same bytes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(9000 + 2864)
+    n = int(rng.integers(1, 120000))
+    leaf_w = float(rng.choice([0.03, 0.1, 0.2, 0.35, 0.77, 2.0, 5.0]))
+    wrap = np.ones((n, 4), np.float32)
+    wrap[:, :3] = rng.normal(0, float(rng.choice([2.0, 30.0, 300.0])), (n, 3)).astype(np.float32)
+    scan = synth.scan(synth.make_scene(3), np.eye(4), 150000, seed=4)
+    nothing = np.full((500, 4), np.nan, np.float32)
+    one = np.array([[1.5, -2.5, 0.25, 1.0]], np.float32)
+    cases = dict(scan=(scan, 0.2), nothing=(nothing, 0.2), tiny_leaf=(scan[:3000], 1e-4), wrap=(wrap, leaf_w), one=(one, 0.2))
+    np.savez(tmp_path / "c.npz", **{k: v[0] for k, v in cases.items()})
+    code = (
+        "import sys, hashlib, numpy as np\n"
+        "from icpslam_amd import Context\n"
+        "z = np.load(sys.argv[1]); leaves = dict(" + ", ".join(f"{k}={v[1]!r}" for k, v in cases.items()) + ")\n"
+        "with Context(0) as c:\n"
+        "    for k in sorted(z.files):\n"
+        "        for fn in (c.voxel_grid, c.voxel_grid_view):\n"
+        "            out = fn(z[k], leaves[k])\n"
+        "            print(k, out.shape[0], hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest())\n")
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, ICPGPU_FLAVOUR="dev", ICPGPU_VOXEL_PLANNED=flag, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "c.npz")], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines())
+    assert outs[0] == outs[1] and len(outs[0]) == 2 * len(cases)
+    import hashlib
+    want = {}
+    for k, (cloud, leaf) in cases.items():
+        fin = cloud[np.isfinite(cloud[:, :3]).all(axis=1)]
+        ref = oracle.voxel_grid(fin, leaf) if len(fin) else np.empty((0, 4), np.float32)
+        want[k] = (ref.shape[0], hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest())
+    for line in outs[0]:
+        k, m, h = line.split()
+        assert (int(m), h) == want[k], k
