@@ -552,8 +552,9 @@ def main():
                     "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": cov_bytes / (cov_ms * 1e-3) / 1e9 if cov_ms else None,
                     "frac": cov_bytes / (cov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if cov_ms else None, "avg_cloud_ms": cov_ms,
                     "clouds": int(pg.gicp_cov_launches), "algorithmic_bytes_per_cloud": cov_bytes,
-                    "note": "gicp_cov_kernel + gicp_cov_finish_kernel per cloud (HIP events): 16 B read + 48 B written per point; the "
-                            "time is the 20-NN selection over the cloud's own grid and the per-point 3x3 Jacobi SVD, not the bytes"}}
+                    "note": "gicp_cov_select_kernel + gicp_cov_far_kernel + gicp_cov_kernel (what is left) + gicp_cov_finish_kernel per cloud "
+                            "(HIP events): 16 B read + 48 B written per point; the time is the 20-NN selection over the cloud's own grid (a latency "
+                            "chain per point: ~23k waves for 7k slots) and the per-point 3x3 Jacobi SVD, not the bytes"}}
         # (4) the same solver through icpgpu_align_batch: 32 voxel-filtered pairs as resumable runs (GicpRun: one or two host
         #     threads keep eight registrations in flight, every outer iteration's BFGS inside the device solver)
         gicp_batch = None
