@@ -47,7 +47,8 @@ extern "C" {
  * icpgpu_create_abi refuses a header of another MAJOR version (ICPGPU_ERR_UNSUPPORTED).  Until 0.4 the structs grew in place with
  * nothing but a comment to protect an older caller; the unsized symbols of those versions (icpgpu_create, icpgpu_default_params,
  * icpgpu_align_batch_multi) are NOT exported any more, so a binary built against a 0.x header fails at load time instead of
- * overrunning its structs.  History: 1.0 icpgpu_result.gicp_solver, icpgpu_calibrate, sized entry points; 0.4 icpgpu_params.gicp_inner,
+ * overrunning its structs.  History: 1.1 icpgpu_align_view, icpgpu_voxel_grid_view (result clouds as views of the pinned staging
+ * buffer), icpgpu_profile.voxel_views_direct; 1.0 icpgpu_result.gicp_solver, icpgpu_calibrate, sized entry points; 0.4 icpgpu_params.gicp_inner,
  * icpgpu_profile.gicp_quadratic_solves; 0.3 icpgpu_profile (sources_adopted, gicp_host_solves, gicp_solver_choice). */
 
 /* ---- environment ---------------------------------------------------------------------------------

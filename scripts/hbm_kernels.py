@@ -17,7 +17,10 @@ with Context(0) as ctx:
         ctx.transform(T); ctx.profile_reset()
         for _ in range(5): ctx.transform(T)
         p = ctx.profile(); ms = p.transform_ms / p.transform_launches
-        print(f"transform_kernel  n={n:8d}: {ms*1e3:8.1f} us, {32.0*n/ms/1e6:7.0f} GB/s = {32.0*n/ms/1e6/PEAK*100:5.1f} % of HBM peak (32 B/point)")
+        if 16 * n <= (8 << 20):  # round 6: clouds up to 8 MB are written by the kernel straight into pinned HOST memory (icpgpu_transform's output)
+            print(f"transform_kernel  n={n:8d}: {ms*1e3:8.1f} us, {16.0*n/ms/1e6:7.1f} GB/s of 16-byte stores into pinned host memory over PCIe (not an HBM figure: the aligned cloud's way to the caller)")
+        else:
+            print(f"transform_kernel  n={n:8d}: {ms*1e3:8.1f} us, {32.0*n/ms/1e6:7.0f} GB/s = {32.0*n/ms/1e6/PEAK*100:5.1f} % of HBM peak (32 B/point)")
         ctx.nn(T)                                        # keys for the reduce (brute force against a tiny target: cheap)
         ctx.reduce(T, 1e9); ctx.profile_reset()
         t0 = time.perf_counter()
