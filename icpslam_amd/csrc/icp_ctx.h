@@ -320,9 +320,12 @@ struct icpgpu_ctx {
   Mat4d final_T = mat4_identity();
   icpgpu_profile prof{};
   int nn_variant = -1;  // ICPGPU_NN_VARIANT: a variant of the plain-VALU brute-force kernel (-1: none forced)
-  DeviceBuf cov_list;  // GICP covariances: the points the selecting kernel leaves to the streaming one (count + indices)
+  DeviceBuf cov_list;  // GICP covariances: the points the selecting kernel leaves to the far-field and the streaming kernel (counts + indices)
+  void* cov_list_zeroed = nullptr;  // the allocation (address, size) whose two counters are known to be zero (the finish kernel leaves them so)
+  size_t cov_list_zeroed_cap = 0;
   DeviceBuf vox_in, vox_out, vox_keys, vox_vals, vox_flags, vox_slots, vox_temp, vox_ints;  // voxel filter scratch
   DeviceBuf vox_bins, vox_pub;   // ... of the direct (no library sort) path: self-cleaning histogram + group ranges; published counts
+  int* vox_bbox_ready = nullptr; // vox_ints' address when its bounding-box slots are known to hold the initial values (icpgpu_voxel.cpp)
   size_t vox_last_n = 0;         // points of the last icpgpu_voxel_grid result (still in vox_out)
   // ... what icpgpu_set_source needs to recognise that result when the caller hands it back as a host buffer (the reference's
   // voxelFilterCloud -> setInputSource sequence, icp_odometer.cpp:177,193): its content fingerprint (taken on the device while

@@ -323,9 +323,11 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
 constexpr int CS = 4;            // 256 keys per level in registers (a scan filtered at 0.2 m has ~60 inside a level's radius)
 constexpr int CS_LIST = 64 * CS;
 
-// buf[0 .. fill): distinct keys (d2 bits << 32 | index), all with d2 <= cap, 20 <= fill <= CS_LIST; one wave.  On return lanes 0..19
-// of `top` (LDS, 20 words) hold the 20 smallest in ascending order.  false: the threshold did not settle (dozens of equal distances).
-__device__ __forceinline__ bool cov_pick20(unsigned long long* buf, unsigned long long* top, int fill, float cap, int lane,
+// buf[0 .. fill): distinct keys (d2 bits << 32 | index), all <= cap_key, 20 <= fill <= CS_LIST; one wave.  On return lanes 0..19
+// of `top` (LDS, 20 words) hold the 20 smallest in ascending order.  The threshold is lowered on the float distance while that
+// separates, then by bisection on the 64-bit keys themselves (dozens of equal distances: the index part decides) -- keys are
+// distinct, so a threshold with 20..64 keys below it always exists.
+__device__ __forceinline__ void cov_pick20(unsigned long long* buf, unsigned long long* top, int fill, unsigned long long cap_key, int lane,
                                            unsigned long long lane_lt, int& probes, int& ranked) {
   unsigned long long K[CS];
   const int nreg = (fill + 63) >> 6;  // wave-uniform: registers in use
@@ -338,25 +340,29 @@ __device__ __forceinline__ bool cov_pick20(unsigned long long* buf, unsigned lon
       if (m < nreg) c += __popcll(__ballot(K[m] <= T));
     return c;
   };
-  // lower the threshold until 20 .. 64 keys pass: [lo_f: fewer than 20, hi_f: at least 20]
-  float lo_f = 0.0f, hi_f = cap;
-  unsigned long long T = ((unsigned long long)__float_as_uint(hi_f) << 32) | 0xFFFFFFFFull;
+  // lower the threshold until 20 .. 64 keys pass: [T_lo: fewer than 20 (at most the key 0 itself), T: at least 20]
+  unsigned long long T_lo = 0ull, T = cap_key;
   int c_lo = 0, c_hi = fill;
+  bool by_key = false;
   for (int probe = 0; c_hi > 64; ++probe) {
-    // interpolate for ~40 on d2 (the first probes), bisect afterwards
-    float mid = probe < 6 ? lo_f + (hi_f - lo_f) * ((40.0f - (float)c_lo) / (float)(c_hi - c_lo)) : 0.5f * (lo_f + hi_f);
-    if (!(mid > lo_f && mid < hi_f)) mid = 0.5f * (lo_f + hi_f);
-    if (probe >= 24 || !(mid > lo_f && mid < hi_f)) return false;  // (adjacent floats: more than 44 keys at one distance)
+    unsigned long long Tm = 0ull;
+    if (!by_key) {
+      // interpolate for ~40 on d2 (the first probes), bisect afterwards
+      const float lo_f = __uint_as_float((unsigned int)(T_lo >> 32)), hi_f = __uint_as_float((unsigned int)(T >> 32));
+      float mid = probe < 6 ? lo_f + (hi_f - lo_f) * ((40.0f - (float)c_lo) / (float)(c_hi - c_lo)) : 0.5f * (lo_f + hi_f);
+      if (!(mid > lo_f && mid < hi_f)) mid = 0.5f * (lo_f + hi_f);
+      if (probe >= 12 || !(mid > lo_f && mid < hi_f)) by_key = true;  // (adjacent floats: more than 44 keys at one distance)
+      else Tm = ((unsigned long long)__float_as_uint(mid) << 32) | 0xFFFFFFFFull;
+    }
+    if (by_key) Tm = T_lo + ((T - T_lo) >> 1);  // strictly inside: T - T_lo >= 2 while more than one key lies between them
     probes += 1;
-    const unsigned long long Tm = ((unsigned long long)__float_as_uint(mid) << 32) | 0xFFFFFFFFull;
     const int cm = count_le(Tm);
     if (cm < GK) {
-      lo_f = mid;
+      T_lo = Tm;
       c_lo = cm;
     } else {
-      hi_f = mid;
-      c_hi = cm;
       T = Tm;
+      c_hi = cm;
     }
   }
   // compact the passing keys, one per lane (the list is in registers: its first 64 entries are free again; one wave reads what
@@ -385,7 +391,6 @@ __device__ __forceinline__ bool cov_pick20(unsigned long long* buf, unsigned lon
   for (int j = c8; j < c_hi; ++j) rank += buf[j] < k ? 1 : 0;
   if (lane < c_hi && rank < GK) top[rank] = k;
   ranked = c_hi;
-  return true;
 }
 
 // Lanes 0..19 of `top` hold the neighbours in key order: mean and second moments exactly as gicp_cov_kernel forms them -- there nine
@@ -431,27 +436,32 @@ __device__ __forceinline__ void cov_emit(const unsigned long long* top, double* 
 
 // The points the selecting kernel's cubes do not reach cheaply -- isolated far-field points whose 20th neighbour is metres away: cube
 // radii 8, 16, ... cells are hundreds to thousands of rows walked in one dependent chain (27 row batches, ~65 us, for a point
-// certified at radius 16; a handful of them per scan set the kernel's duration).  Here a WORKGROUP takes such a point and looks at
-// the whole cloud (a filtered scan: ~23k points, 23 per thread): a pass collects the keys under a cap into the list; the first cap
-// extrapolates the count the last cube found inside its radius (neighbours on a surface grow with d2) to ~60, later ones
-// interpolate between the caps tried -- usually one pass, then the same selection and sums as above.  Exact whatever the caps were:
-// every point of the cloud is looked at.  Clouds above kCovFarMost points keep the streaming kernel for these points.
-constexpr int kCovFarMost = 1 << 16;
+// certified at radius 16; a handful of them per scan set the kernel's duration) -- and the rare ones its caps cannot settle
+// (hundreds of points at one distance).  Here a WORKGROUP takes such a point and looks at the whole cloud (a filtered scan: ~23k
+// points, 23 per thread): a pass collects the keys under a cap into the list; the first cap extrapolates the count the last cube
+// found inside its radius (neighbours on a surface grow with d2) to ~60, later ones interpolate between the caps tried -- usually
+// one pass -- and when float distances no longer separate, the caps become 64-bit keys and are bisected as such (keys are distinct:
+// that always ends).  Then the same selection and sums as above.  Exact whatever the caps were: every point of the cloud is looked
+// at; a cloud with fewer than 20 finite points gets the identity marker, as in gicp_cov_kernel.  It is also the whole covariance
+// pass of a cloud the k-NN grid refuses (thousands of points in one cell of the largest table: gicp_cov_all_far_kernel queues every
+// point).  Clouds above kGicpCovFarMost points keep the streaming kernel for these points.
+// far_list entries: point index | code << 20; code 0..19 = the keys the last cube found inside r_tried, 31 = no such knowledge.
 constexpr int kCovFarLevel = 4;  // the last cube radius (cells) the selecting kernel tries before it hands a point over
+constexpr int kCovFarNoHint = 31;
 __global__ __launch_bounds__(1024) void gicp_cov_far_kernel(const float4* __restrict__ cloud, int n, double* __restrict__ cov6, float r_tried,
-                                                            const int* __restrict__ far_list, const int* __restrict__ far_n,
-                                                            int* __restrict__ list, int* __restrict__ list_n) {
+                                                            const int* __restrict__ far_list, const int* __restrict__ far_n) {
   __shared__ unsigned long long s_buf[CS_LIST];
   __shared__ unsigned long long s_top[GK];
   __shared__ int s_count;
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lane_lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  auto key_of = [](float d2, unsigned int idx) -> unsigned long long { return ((unsigned long long)__float_as_uint(d2) << 32) | idx; };
   for (int slot = blockIdx.x; slot < *far_n; slot += gridDim.x) {
-    const int packed = far_list[slot];  // point index | (keys the last cube found inside its radius) << 20
-    const int i = packed & 0xFFFFF, seen = packed >> 20;
+    const int packed = far_list[slot];
+    const int i = packed & 0xFFFFF, code = (packed >> 20) & 31;
     const float4 s = cloud[i];
-    // the keys with d2 <= cap: their number, the first CS_LIST of them in s_buf (any order: they are ranked later)
-    auto pass = [&](float cap) -> int {
+    // the keys <= cap: their number, the first CS_LIST of them in s_buf (any order: they are ranked later)
+    auto pass = [&](unsigned long long cap) -> int {
       __syncthreads();
       if (tid == 0) s_count = 0;
       __syncthreads();
@@ -465,55 +475,83 @@ __global__ __launch_bounds__(1024) void gicp_cov_far_kernel(const float4* __rest
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int j = j0 + u * 1024 + tid;
-          const float d = dist2(q[u].x, q[u].y, q[u].z, s.x, s.y, s.z);
-          const bool in = finite3g(q[u].x, q[u].y, q[u].z) && d <= cap;  // (the grid's sorted copy leaves non-finite points out: so do we)
+          const unsigned long long key = key_of(dist2(q[u].x, q[u].y, q[u].z, s.x, s.y, s.z), (unsigned int)j);
+          const bool in = finite3g(q[u].x, q[u].y, q[u].z) && key <= cap;  // (the grid's sorted copy leaves non-finite points out: so do we)
           const unsigned long long b = __ballot(in);
           if (b) {  // wave-uniform
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_count, __popcll(b));
             base = __shfl(base, 0, 64);
             const int at = base + __popcll(b & lane_lt);
-            if (in && at < CS_LIST) s_buf[at] = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)j;
+            if (in && at < CS_LIST) s_buf[at] = key;
           }
         }
       }
       __syncthreads();
       return s_count;
     };
-    float lo_c = r_tried * r_tried, hi_c = 0.0f;
-    int n_lo = seen, n_hi = 0, fill = 0;
-    float cap = lo_c * (60.0f / (float)max(seen, 2));  // (a point that saw nothing yet: 30 times the area)
-    bool settled = false, fail = false;
-    for (int pass_no = 0; pass_no < 40; ++pass_no) {
+    // [lo: fewer than 20 keys (the key 0 alone at most), hi: more than the list holds]
+    const bool hint = code != kCovFarNoHint;
+    unsigned long long lo = hint ? key_of(r_tried * r_tried, 0xFFFFFFFFu) : 0ull, hi = 0ull;
+    int n_lo = hint ? code : 0, n_hi = 0, fill = 0;
+    unsigned long long cap = key_of(r_tried * r_tried * (hint ? 60.0f / (float)max(code, 2) : 1.0f), 0xFFFFFFFFu);
+    bool settled = false, by_key = false;
+    for (int pass_no = 0; pass_no < 200; ++pass_no) {
       fill = pass(cap);
       if (fill >= GK && fill <= CS_LIST) {
         settled = true;
         break;
       }
       if (fill < GK) {
-        lo_c = cap;
+        lo = cap;
         n_lo = fill;
       } else {
-        hi_c = cap;
+        hi = cap;
         n_hi = fill;
       }
-      float next;
-      if (n_hi == 0) {
-        next = cap * (fill < 5 ? 8.0f : 60.0f / (float)fill);  // nothing above yet: grow (by the same rule)
-        if (!(next < 3.0e38f)) { fail = true; break; }  // fewer than 20 finite points in the cloud
-      } else {
-        next = pass_no < 30 ? lo_c + (hi_c - lo_c) * ((60.0f - (float)n_lo) / (float)(n_hi - n_lo)) : 0.5f * (lo_c + hi_c);
-        if (!(next > lo_c && next < hi_c)) next = 0.5f * (lo_c + hi_c);
-        if (!(next > lo_c && next < hi_c)) { fail = true; break; }  // hundreds of keys at one distance
+      if (n_hi == 0) {  // nothing above yet: grow (by the same rule)
+        const float c = __uint_as_float((unsigned int)(cap >> 32));
+        float next = c * (fill < 5 ? 8.0f : 60.0f / (float)fill);
+        if (!(next > c)) next = c > 0.0f ? c * 2.0f : 1.0e-12f;
+        if (!(next < 3.0e38f)) break;  // fewer than 20 finite points in the cloud
+        cap = key_of(next, 0xFFFFFFFFu);
+        continue;
       }
-      cap = next;
+      if (!by_key) {
+        const float lo_f = __uint_as_float((unsigned int)(lo >> 32)), hi_f = __uint_as_float((unsigned int)(hi >> 32));
+        float mid = pass_no < 8 ? lo_f + (hi_f - lo_f) * ((60.0f - (float)n_lo) / (float)(n_hi - n_lo)) : 0.5f * (lo_f + hi_f);
+        if (!(mid > lo_f && mid < hi_f)) mid = 0.5f * (lo_f + hi_f);
+        if (pass_no >= 40 || !(mid > lo_f && mid < hi_f)) by_key = true;  // hundreds of keys at one distance: the index part decides
+        else cap = key_of(mid, 0xFFFFFFFFu);
+      }
+      if (by_key) cap = lo + ((hi - lo) >> 1);
     }
-    if (settled && tid < 64) {  // one wave finishes
-      int probes = 0, ranked = 0;
-      if (cov_pick20(s_buf, s_top, fill, cap, lane, lane_lt, probes, ranked)) cov_emit(s_top, reinterpret_cast<double*>(s_buf), cloud, i, cov6, lane);
-      else fail = true;
+    if (tid < 64) {  // one wave finishes
+      if (settled) {
+        int probes = 0, ranked = 0;
+        cov_pick20(s_buf, s_top, fill, cap, lane, lane_lt, probes, ranked);
+        cov_emit(s_top, reinterpret_cast<double*>(s_buf), cloud, i, cov6, lane);
+      } else if (lane < 6) {  // (the marker of an identity covariance, as gicp_cov_kernel writes it for a cloud of fewer than 20 points)
+        cov6[(size_t)i * 6 + lane] = lane == 0 ? __longlong_as_double(0x7FF8000000000000ll) : (lane == 3 || lane == 5 ? 1.0 : 0.0);
+      }
     }
-    if (tid == 0 && (fail || !settled)) list[atomicAdd(list_n, 1)] = i;  // the streaming kernel's
+  }
+}
+
+// every finite point of the cloud onto the far-field kernel's list (no hint), the marker for the others: the covariance pass of a
+// cloud that has no grid
+__global__ __launch_bounds__(256) void gicp_cov_all_far_kernel(const float4* __restrict__ cloud, int n, double* __restrict__ cov6,
+                                                               int* __restrict__ far_list, int* __restrict__ far_n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 s = cloud[i];
+  if (finite3g(s.x, s.y, s.z)) {
+    far_list[atomicAdd(far_n, 1)] = i | (kCovFarNoHint << 20);
+  } else {
+    double* c = cov6 + (size_t)i * 6;
+    c[0] = __longlong_as_double(0x7FF8000000000000ll);
+    c[1] = c[2] = c[4] = 0.0;
+    c[3] = c[5] = 1.0;
   }
 }
 
@@ -688,11 +726,7 @@ __global__ __launch_bounds__(256) void gicp_cov_select_kernel(const float4* __re
     if (give_up) break;
     CS_STAT(1, fill);
     int probes = 0, ranked = 0;
-    if (!cov_pick20(buf, s_top[wv], fill, cap, lane, lane_lt, probes, ranked)) {
-      give_up = true;
-      CS_STAT(4, 1);
-      break;
-    }
+    cov_pick20(buf, s_top[wv], fill, ((unsigned long long)__float_as_uint(cap) << 32) | 0xFFFFFFFFull, lane, lane_lt, probes, ranked);
     done = true;
     CS_STAT(6, probes);
     CS_STAT(7, ranked);
@@ -701,10 +735,11 @@ __global__ __launch_bounds__(256) void gicp_cov_select_kernel(const float4* __re
   }
 #undef CS_STAT
   if (!done) {
-    // far_ok: a point no cube of up to kCovFarLevel cells has certified goes to gicp_cov_far_kernel; everything else that is not
-    // done (caps that do not settle, any such point of a cloud too large for that kernel) to gicp_cov_kernel
+    // far_ok (clouds up to kGicpCovFarMost points): whatever is not done -- no cube of up to kCovFarLevel cells certified the point,
+    // the caps did not settle -- goes to gicp_cov_far_kernel; in larger clouds to gicp_cov_kernel
     if (lane == 0) {
-      if (go_far) far_list[atomicAdd(far_n, 1)] = i | (last_seen << 20);  // (i < kCovFarMost, last_seen < 20)
+      if (go_far) far_list[atomicAdd(far_n, 1)] = i | (last_seen << 20);  // (i < kGicpCovFarMost, last_seen < 20)
+      else if (far_ok) far_list[atomicAdd(far_n, 1)] = i | (kCovFarNoHint << 20);  // caps that did not settle, the whole grid searched
       else list[atomicAdd(list_n, 1)] = i;
     }
     return;
@@ -714,8 +749,10 @@ __global__ __launch_bounds__(256) void gicp_cov_select_kernel(const float4* __re
 
 // The 3x3 decomposition, ONE LANE PER POINT: inside the search kernel every lane of the wave repeated it (several thousand
 // double-precision instructions per point, the largest part of that kernel's time); here 64 points share a wave.
-__global__ __launch_bounds__(256) void gicp_cov_finish_kernel(int n, double* __restrict__ cov6) {
+// (zero2, optional: the two list counters of launch_gicp_covariances, left zero for the next cloud -- every kernel that reads them has run)
+__global__ __launch_bounds__(256) void gicp_cov_finish_kernel(int n, double* __restrict__ cov6, int* __restrict__ zero2) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (zero2 && i == 0) zero2[0] = zero2[1] = 0;
   if (i >= n) return;
   double* c = cov6 + (size_t)i * 6;
   const double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3], a4 = c[4], a5 = c[5];
@@ -1694,23 +1731,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-// list (optional): 2 n + 2 ints of scratch -- with it the selecting kernel runs first and gicp_cov_kernel only finishes what that one
-// left over (list[0] = how many, list[1 ..] = which; cleared here); without it gicp_cov_kernel does every point, as until round 5.
+// list (optional): 2 n + 2 ints of scratch -- with it the selecting kernel runs first, the far-field kernel takes what that one hands
+// over (clouds up to kGicpCovFarMost points; in larger ones gicp_cov_kernel finishes the list); without it gicp_cov_kernel does
+// every point, as until round 5.
 hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
-                                   const GridDesc& g, double* cov6, hipStream_t stream, int* list) {
+                                   const GridDesc& g, double* cov6, hipStream_t stream, int* list, bool list_counters_zero) {
   if (n <= 0) return hipSuccess;
   // development flavour, ICPGPU_COV_SELECT=0: the streaming kernel for every point
   static const bool select = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_COV_SELECT"); return !e || atoi(e) != 0; }();
   if (list && select) {
-    hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(int), stream);
-    if (e != hipSuccess) return e;
+    if (!list_counters_zero) {  // (a fresh buffer; afterwards the finish kernel leaves them zero: one launch less per cloud)
+      hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(int), stream);
+      if (e != hipSuccess) return e;
+    }
     // development flavour, ICPGPU_COV_STATS=1: what the selecting kernel did with the cloud (a synchronising print per cloud)
     static const bool want_stats = [] { const char* e = ICPGPU_DEV_ENV("ICPGPU_COV_STATS"); return e && atoi(e) != 0; }();
     unsigned long long* d_stats = nullptr;
     if (want_stats && hipMalloc(reinterpret_cast<void**>(&d_stats), 16 * sizeof(unsigned long long)) == hipSuccess)
       (void)hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), stream);
     // list layout: [0] streaming count, [1] far count, [2 .. 2 + n) streaming list, [2 + n .. 2 + 2n) far list
-    const int far_ok = n <= kCovFarMost ? 1 : 0;
+    const int far_ok = n <= kGicpCovFarMost ? 1 : 0;
     int* far_list = list + 2 + n;
     if (d_stats)
       hipLaunchKernelGGL(gicp_cov_select_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, list + 2, list, far_ok,
@@ -1720,14 +1760,14 @@ hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sor
                          far_list, list + 1, d_stats);
     if (far_ok)  // (the first cap: the radius the last cube tried has already failed)
       hipLaunchKernelGGL(gicp_cov_far_kernel, dim3(std::min(n, 256)), dim3(1024), 0, stream, cloud, n, cov6, (float)kCovFarLevel * g.h * kGridSafety, far_list,
-                         list + 1, list + 2, list);
+                         list + 1);
     if (d_stats) {
       unsigned long long h[16];
       (void)hipStreamSynchronize(stream);
       (void)hipMemcpy(h, d_stats, sizeof(h), hipMemcpyDeviceToHost);
       (void)hipFree(d_stats);
       fprintf(stderr, "[icpgpu] covariances of %d points (cells of %.3f m): %llu selected (%.1f levels, %.0f keys inside the certified radius, %.2f threshold probes, %.1f keys ranked "
-                      "each), %llu dense corners collected again; left over: %llu caps not settled, %llu whole grid searched\n", n, (double)g.h, h[0],
+                      "each), %llu dense corners collected again; handed on: %llu caps not settled, %llu whole grid searched\n", n, (double)g.h, h[0],
               (double)h[2] / (double)(h[0] ? h[0] : 1), (double)h[1] / (double)(h[0] ? h[0] : 1), (double)h[6] / (double)(h[0] ? h[0] : 1),
               (double)h[7] / (double)(h[0] ? h[0] : 1), h[3], h[4], h[5]);
       int h_lists[2] = {0, 0};
@@ -1736,11 +1776,28 @@ hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sor
       fprintf(stderr, "[icpgpu]   points by the cube radius (in cells) that certified them: 1: %llu, 2: %llu, 4: %llu, 8: %llu, 16: %llu, 32: %llu, 64: %llu, more: %llu\n", h[8],
               h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
     }
-    hipLaunchKernelGGL(gicp_cov_kernel, dim3(std::min((n + 3) / 4, 128)), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, list + 2, list);
+    // (with the far-field kernel nothing is left over: it settles every point it is handed)
+    if (!far_ok) hipLaunchKernelGGL(gicp_cov_kernel, dim3(std::min((n + 3) / 4, 128)), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, list + 2, list);
   } else {
     hipLaunchKernelGGL(gicp_cov_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, cloud, n, sorted, cell_start, g, cov6, nullptr, nullptr);
   }
-  hipLaunchKernelGGL(gicp_cov_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, cov6);
+  hipLaunchKernelGGL(gicp_cov_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, cov6, (list && select) ? list : nullptr);
+  return hipGetLastError();
+}
+
+// The covariances of a cloud WITHOUT a grid (the k-NN grid refuses a cloud whose densest cell of the largest table holds thousands of
+// points): every finite point through the far-field kernel's whole-cloud passes.  n <= kGicpCovFarMost; list as above.
+hipError_t launch_gicp_covariances_brute(const float4* cloud, int n, double* cov6, hipStream_t stream, int* list, bool list_counters_zero) {
+  if (n <= 0) return hipSuccess;
+  if (n > kGicpCovFarMost || !list) return hipErrorInvalidValue;
+  if (!list_counters_zero) {
+    hipError_t e = hipMemsetAsync(list, 0, 2 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+  }
+  int* far_list = list + 2 + n;
+  hipLaunchKernelGGL(gicp_cov_all_far_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cloud, n, cov6, far_list, list + 1);
+  hipLaunchKernelGGL(gicp_cov_far_kernel, dim3(std::min(n, 1024)), dim3(1024), 0, stream, cloud, n, cov6, 0.05f, far_list, list + 1);
+  hipLaunchKernelGGL(gicp_cov_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, cov6, list);
   return hipGetLastError();
 }
 

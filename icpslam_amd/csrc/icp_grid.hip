@@ -614,8 +614,8 @@ __global__ __launch_bounds__(WQ_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))
 
 }  // namespace
 
-hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t stream) {
-  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, stream, d_minmax6);
+hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t stream, bool init) {
+  if (init) hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, stream, d_minmax6);
   if (n > 0) {
     int blocks = (n + 255) / 256;
     if (blocks > 256) blocks = 256;

@@ -155,7 +155,7 @@ static constexpr float kGridSafety = 0.984375f;  // 63/64: covers the rounding o
 static constexpr int kScanItems = 4096;           // elements per block of the cell-count scan
 
 // encoded min/max (6 ints, see decode_bbox) of the finite points of a cloud
-hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t stream);
+hipError_t launch_bbox(const float4* pts, int n, int* d_minmax6, hipStream_t stream, bool init = true);  // init = false: d_minmax6 holds the initial values already
 void decode_bbox(const int enc[6], float lo[3], float hi[3]);  // host
 
 // Produces cell_start (exclusive scan of the per-cell counts, ncells+1 entries, in place in counts_then_start),
@@ -237,10 +237,14 @@ static constexpr double kGicpEpsilon = 1e-3;   // PCL gicp_epsilon_
 struct Rot3d {
   double m[9];  // row-major
 };
+static constexpr int kGicpCovFarMost = 1 << 16;  // clouds up to this size: the far-field kernel (a workgroup over the whole cloud per point)
+// the covariances of a cloud that has no grid (n <= kGicpCovFarMost): every point through the far-field kernel; list as below
+hipError_t launch_gicp_covariances_brute(const float4* cloud, int n, double* cov6, hipStream_t stream, int* list, bool list_counters_zero);
 // cov6[i] = upper triangle (xx, xy, xz, yy, yz, zz) of the regularised covariance of point i's 20 nearest neighbours
 hipError_t launch_gicp_covariances(const float4* cloud, int n, const float4* sorted, const int* cell_start,
-                                   const GridDesc& g, double* cov6, hipStream_t stream, int* list = nullptr);
-// (list: 2 n + 2 ints of scratch -- the points the selecting kernel hands to the far-field and the streaming kernel; icp_gicp.hip)
+                                   const GridDesc& g, double* cov6, hipStream_t stream, int* list = nullptr, bool list_counters_zero = false);
+// (list: 2 n + 2 ints of scratch -- the points the selecting kernel hands to the far-field and the streaming kernel; icp_gicp.hip.
+//  list_counters_zero: list[0] and list[1] are zero -- true from the second cloud on the same buffer: the last kernel leaves them so)
 // maha6[i] = upper triangle of (C_t[j] + R C_s[i] R^T)^-1 for every source point whose key passes d2 < thr
 hipError_t launch_gicp_mahalanobis(int n_s, const unsigned long long* keys, float thr, const Rot3d& R, const double* cov_s,
                                    const double* cov_t, double* maha6, hipStream_t stream);
@@ -395,9 +399,10 @@ int voxel_direct_groups(int n);
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
                                     unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
                                     int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word = nullptr,
-                                    const int* d_bbox6 = nullptr, int* d_plan = nullptr);
-// (d_plan, 8 ints, with d_bbox6 = launch_bbox's result queued in front: the device derives minb / divb / the buckets itself and the
-// host need not have seen the box; plan[7] = 0 the filter ran, 1 no finite point, 2 PCL's pass-through, 3 the sort path's cloud)
+                                    int* d_bbox6 = nullptr, int* d_plan = nullptr);
+// (d_plan, 14 ints, with d_bbox6 = launch_bbox's result queued in front: the device derives minb / divb / the buckets itself and the
+// host need not have seen the box; plan[7] = 0 the filter ran, 1 no finite point, 2 PCL's pass-through, 3 the sort path's cloud;
+// plan[8..13] = the box, d_bbox6 itself is left as bbox_init_kernel leaves it: the next launch_bbox on it may skip its init)
 // (clear_word, optional: a 64-bit word of device memory the last kernel sets to zero -- launch_publish_cloud's accumulator)
 
 }  // namespace icpgpu

@@ -150,12 +150,18 @@ struct VoxelPlan {
 };
 
 // (inv_leaf = 1 / leaf in float, as PCL's inverse_leaf_size_; the arithmetic is voxel_filter_device's, operation for operation)
-__global__ void voxel_plan_kernel(const int* __restrict__ bbox6, float inv_leaf, VoxelPlan* __restrict__ plan, int* __restrict__ d_n_out,
-                                  int* __restrict__ status) {
+// bbox6 is handed on to bbox_keep[0..5] (what the host reads) and left INITIALISED for the next bounding-box pass (its own init
+// launch is then not needed: voxel_filter_device).
+__global__ void voxel_plan_kernel(int* __restrict__ bbox6, float inv_leaf, VoxelPlan* __restrict__ plan, int* __restrict__ d_n_out,
+                                  int* __restrict__ status, int* __restrict__ bbox_keep) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float lo[3], hi[3];
   for (int a = 0; a < 3; ++a) {
     const int el = bbox6[a], eh = bbox6[3 + a];
+    bbox_keep[a] = el;
+    bbox_keep[3 + a] = eh;
+    bbox6[a] = 0x7FFFFFFF;          // (bbox_init_kernel's values)
+    bbox6[3 + a] = (int)0x80000000;
     lo[a] = __int_as_float(el >= 0 ? el : el ^ 0x7FFFFFFF);
     hi[a] = __int_as_float(eh >= 0 ? eh : eh ^ 0x7FFFFFFF);
   }
@@ -712,16 +718,18 @@ size_t voxel_direct_scratch_ints(int n) { return (size_t)VX_BINS + 8 + 4 * (size
 // relpos: n ints; comp: n 64-bit words; d_n_out: 2 ints (sum = cells written); status: 1 int, non-zero = not done, use the
 // sort path.
 // d_plan (with d_bbox6): the parameters are derived on the device from the encoded bounding box in d_bbox6 (launch_bbox's result,
-// queued in front) -- minb / divb are not looked at, the host has not seen the box yet; 8 ints of device memory.
+// queued in front) -- minb / divb are not looked at, the host has not seen the box yet; 14 ints of device memory: the plan and,
+// behind it, the box (d_bbox6 itself is left initialised for the next pass).
 hipError_t launch_voxel_grid_direct(const float4* pts, int n, float inv_leaf, const int minb[3], const int divb[3], int* bins,
                                     unsigned long long* published, int* keys, int* relpos, unsigned long long* comp, float4* out,
-                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word, const int* d_bbox6,
+                                    int* d_n_out, int* status, hipStream_t stream, unsigned long long* clear_word, int* d_bbox6,
                                     int* d_plan) {
   static_assert(sizeof(VoxelPlan) == 8 * sizeof(int), "the plan is read back as 8 ints");
   const VoxelPlan* plan = reinterpret_cast<const VoxelPlan*>(d_plan);
   static const int no3[3] = {0, 0, 0}, one3[3] = {1, 1, 1};
   if (plan) {
-    hipLaunchKernelGGL(voxel_plan_kernel, dim3(1), dim3(64), 0, stream, d_bbox6, inv_leaf, reinterpret_cast<VoxelPlan*>(d_plan), d_n_out, status);
+    hipLaunchKernelGGL(voxel_plan_kernel, dim3(1), dim3(64), 0, stream, d_bbox6, inv_leaf, reinterpret_cast<VoxelPlan*>(d_plan), d_n_out, status,
+                       d_plan + 8);
     minb = no3;
     divb = one3;
   }

@@ -57,7 +57,10 @@ static int cov_launch(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridI
     c->cov_h_hint = (double)G.g.h;
     c->cov_h_hint_cut = std::isfinite(cut) ? std::min(cut, 1e6) : 1.0;
   }
-  if (!G.usable) return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud (degenerate or non-finite input)");
+  // a cloud the k-NN grid refuses (thousands of points in one cell of the largest table: tight clusters in a wide volume) has its
+  // covariances computed without one, every point by the far-field kernel's passes over the whole cloud -- up to kGicpCovFarMost points
+  if (!G.usable && cloud.n > (size_t)kGicpCovFarMost)
+    return fail(c, ICPGPU_ERR_UNSUPPORTED, "GICP: cannot index this cloud of %zu points (degenerate or non-finite input)", cloud.n);
   int rc;
   if ((rc = ensure(c, cov, cloud.n * 6 * sizeof(double)))) return rc;
   if (timed) {
@@ -65,9 +68,17 @@ static int cov_launch(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, GridI
     HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
   }
   if ((rc = ensure(c, c->cov_list, (2 * cloud.n + 2) * sizeof(int)))) return rc;
-  HIP_TRY(c, launch_gicp_covariances(cloud.data(), (int)cloud.n, static_cast<const float4*>(G.sorted.ptr),
-                                     static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream,
-                                     static_cast<int*>(c->cov_list.ptr)));
+  const bool counters_zero = c->cov_list_zeroed == c->cov_list.ptr && c->cov_list_zeroed_cap == c->cov_list.cap;
+  c->cov_list_zeroed = nullptr;  // (until the launches below are known to be queued)
+  if (G.usable)
+    HIP_TRY(c, launch_gicp_covariances(cloud.data(), (int)cloud.n, static_cast<const float4*>(G.sorted.ptr),
+                                       static_cast<const int*>(G.cell_start.ptr), G.g, static_cast<double*>(cov.ptr), c->stream,
+                                       static_cast<int*>(c->cov_list.ptr), counters_zero));
+  else
+    HIP_TRY(c, launch_gicp_covariances_brute(cloud.data(), (int)cloud.n, static_cast<double*>(cov.ptr), c->stream,
+                                             static_cast<int*>(c->cov_list.ptr), counters_zero));
+  c->cov_list_zeroed = c->cov_list.ptr;
+  c->cov_list_zeroed_cap = c->cov_list.cap;
   if (timed) {
     HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
     // No synchronisation: what follows is queued behind the pass (it used to end with one only to time itself: the host sat out

@@ -19,11 +19,15 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
   if (!(leaf > 0.f) || !std::isfinite(leaf)) return fail(c, ICPGPU_ERR_INVALID_ARG, "voxel filter: leaf size must be positive");
   if (n <= 0) return ICPGPU_OK;
   // device ints: [0..5] the encoded bounding box, [6, 7] the cell counts, [8] the direct path's status, [10, 11] the published
-  // cloud's fingerprint, [16..23] the plan the device derives from the box (launch_voxel_grid_direct)
+  // cloud's fingerprint, [16..23] the plan the device derives from the box (launch_voxel_grid_direct), [24..29] the box as the plan
+  // kernel hands it on -- it leaves [0..5] initialised, so the NEXT call's bounding-box pass goes without its init launch
+  // (vox_bbox_ready: only after a call that got as far as the plan kernel; anything else starts with the init launch again)
   int rc = ensure(c, c->vox_ints, 32 * sizeof(int));
   if (rc) return rc;
   int* d_ints = static_cast<int*>(c->vox_ints.ptr);
-  HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream));
+  const bool box_ready = c->vox_bbox_ready == d_ints;
+  c->vox_bbox_ready = nullptr;
+  HIP_TRY(c, launch_bbox(d_in, n, d_ints, c->stream, !box_ready));
   const float inv = 1.0f / leaf;  // PCL: inverse_leaf_size_ = 1 / leaf_size_ in float
   float ms = 0.f;
   // the direct path (one distribution pass + a sort in LDS): every cloud up to 2M points; it reports the rare cloud it cannot
@@ -89,16 +93,18 @@ int voxel_filter_device(icpgpu_ctx* c, const float4* d_in, int n, float leaf, De
     HIP_TRY(c, te);
     return ICPGPU_OK;
   };
-  int hv[24];
-  for (int& v : hv) v = 0;
   const bool planned = planned_enabled && direct_size;
+  int hv[32];
+  for (int& v : hv) v = 0;
   if (planned) {
     if ((rc = direct_scratch())) return rc;
     if ((rc = direct_launch(nullptr, nullptr))) return rc;
-    if ((rc = fetch_ints(c, d_ints, 24, hv))) {
+    if ((rc = fetch_ints(c, d_ints, 30, hv))) {
       c->vox_bins_zeroed = nullptr;
       return rc;
     }
+    std::memcpy(hv, hv + 24, 6 * sizeof(int));  // the box, from where the plan kernel put it
+    c->vox_bbox_ready = d_ints;                 // ... having left [0..5] initialised
   } else if ((rc = fetch_ints(c, d_ints, 6, hv))) {
     return rc;
   }

@@ -573,3 +573,41 @@ def test_selecting_covariance_kernel_equals_the_streaming_one_and_the_oracle(tmp
         ref = oracle.gicp_covariances(cloud[fin])
         diff = np.abs(a[fin] - ref).reshape(int(fin.sum()), -1).max(axis=1)
         assert (diff > 0).mean() <= 0.001 and diff.max() <= 1e-6, (k, (diff > 0).mean(), diff.max())
+
+
+def test_gicp_on_a_cloud_the_knn_grid_refuses(ctx):
+    """Tight clusters in a wide sparse volume: the densest cell of the largest cell table holds thousands of points and the k-NN grid
+    refuses the cloud -- until round 6 icpgpu_gicp_covariances / a GICP alignment then failed with "cannot index this cloud".  Now
+    the covariances of such a cloud (up to 64k points) come from the far-field kernel alone (a workgroup per point over the whole
+    cloud): the oracle's, and a whole GICP registration of two such clouds is the oracle's bit for bit."""
+    rng = np.random.default_rng(70_040)
+
+    def clustered(n, seed):
+        r = np.random.default_rng(seed)
+        centres = r.uniform(-50, 50, (4, 3))
+        c = np.ones((n, 4), np.float32)
+        c[:, :3] = (centres[r.integers(0, 4, n)] + r.normal(0, 0.3, (n, 3))).astype(np.float32)
+        c[::11, :3] = r.uniform(-200, 200, (len(c[::11]), 3)).astype(np.float32)
+        return c
+
+    cloud = clustered(30000, 1)
+    cloud[7, 1] = np.nan
+    ctx.set_params(ctx.default_params(), method=GICP)
+    ctx.set_source(cloud)
+    fin = np.isfinite(cloud[:, :3]).all(axis=1)
+    got, ref = ctx.gicp_covariances()[fin], oracle.gicp_covariances(cloud[fin])
+    diff = np.abs(got - ref).reshape(len(ref), -1).max(axis=1)
+    assert (diff > 0).mean() <= 0.001 and diff.max() <= 1e-6, ((diff > 0).mean(), diff.max())
+    assert np.array_equal(ctx.gicp_covariances()[~fin], np.tile(np.eye(3), (int((~fin).sum()), 1, 1)))   # non-finite points: identity
+    tgt = clustered(12000, 2)
+    R = synth.pose_matrix(0.05, -0.03, 0.02, 0.0, 0.0, np.deg2rad(0.4))
+    src = tgt.copy()
+    src[:, :3] = (tgt[:, :3] @ R[:3, :3].T + R[:3, 3]).astype(np.float32)
+    src = src[rng.permutation(len(src))[:11000]]
+    ctx.set_params(ctx.default_params(), method=GICP, max_iterations=10)
+    ctx.set_source(src)
+    ctx.set_target(tgt)
+    g = ctx.align(want_fitness=True)
+    o = oracle.icp_align(src, tgt, oracle.default_params(method=oracle.GICP, max_iterations=10), want_fitness=True)
+    assert (g["iterations"], g["n_corr"], g["converged"]) == (o["iterations"], o["n_corr"], o["converged"])
+    assert np.array_equal(g["T"].view(np.uint32), np.asarray(o["T"], np.float32).view(np.uint32))
