@@ -407,17 +407,19 @@ def main():
     if not batch:
         gather({"T": np.eye(4, dtype=np.float32), "iterations": 0, "converged": False, "state": 0, "n_corr": 0, "mse": 0.0,
                 "fitness": 0.0})
+    # the harness's own interpreter must not stop the clock's world: a generation-2 garbage collection of CPython takes ~40 ms
+    # here (the synthetic clouds and records are large containers) and used to land in the SIXTH batch of every batch50k run --
+    # one 52 ms step among 15 ms ones (scripts/batch_jitter.py with and without gc.disable(): profiles/r02_batch_scheduler.txt).
+    # Collected BEFORE the warm-up since round 6: between the warm-up and the clock it left the GPU idle for those 40 ms, and the
+    # K timed steps that followed ran 3-8 % below the steady-state loop's rate (a warm-up followed by a pause is not a warm-up).
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(setup_steps):
         step()
     for _ in range(a.warmup):
         last = step()
     ctx.profile_reset()
-    # the harness's own interpreter must not stop the clock's world: a generation-2 garbage collection of CPython takes ~40 ms
-    # here (the synthetic clouds and records are large containers) and used to land in the SIXTH batch of every batch50k run --
-    # one 52 ms step among 15 ms ones (scripts/batch_jitter.py with and without gc.disable(): profiles/r02_batch_scheduler.txt)
-    import gc
-    gc.collect()
-    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
