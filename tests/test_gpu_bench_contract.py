@@ -33,6 +33,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and rf["peak"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    # round 6: the figures come from the dense pass (every launch timed), the timed region's own sample and a steady-state loop
+    # stand beside them, and the roofline that binds the kernel (vector issue) is at the top level
+    assert rf["dense_pass"]["timed_launches"] == 200 and rf["avg_launch_ms"] == rf["dense_pass"]["avg_launch_ms"]
+    assert rf["sampled_in_timed_region"]["avg_launch_ms"] > 0 and rf["steady_state"]["iterations_per_sec"] > 0
+    assert rf["steady_state"]["seconds"] >= 1.0 and 0 < rf["steady_state"]["kernel_busy_frac"] <= 1.0
+    assert rf["binding"]["bound"] == "valu_issue" and 0 < rf["binding"]["frac"] < 1
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
