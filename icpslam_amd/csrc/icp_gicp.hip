@@ -323,6 +323,16 @@ __global__ __launch_bounds__(256) void gicp_cov_kernel(const float4* __restrict_
 constexpr int CS = 4;            // 256 keys per level in registers (a scan filtered at 0.2 m has ~60 inside a level's radius)
 constexpr int CS_LIST = 64 * CS;
 
+// Lanes of ONE wave hand data to each other through LDS below (a list appended to by some lanes and read by others).  The LDS
+// operations of a wave complete in order, so no instruction is needed -- but the memory model orders one lane's stores before
+// another lane's loads only across a synchronisation: a wavefront-scope release / acquire fence pair around a wave barrier says so
+// (no instruction beyond, at most, a wait for the LDS counter).
+__device__ __forceinline__ void wave_lds_handover() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // buf[0 .. fill): distinct keys (d2 bits << 32 | index), all <= cap_key, 20 <= fill <= CS_LIST; one wave.  On return lanes 0..19
 // of `top` (LDS, 20 words) hold the 20 smallest in ascending order.  The threshold is lowered on the float distance while that
 // separates, then by bisection on the 64-bit keys themselves (dozens of equal distances: the index part decides) -- keys are
@@ -331,6 +341,7 @@ __device__ __forceinline__ void cov_pick20(unsigned long long* buf, unsigned lon
                                            unsigned long long lane_lt, int& probes, int& ranked) {
   unsigned long long K[CS];
   const int nreg = (fill + 63) >> 6;  // wave-uniform: registers in use
+  wave_lds_handover();  // (the list was appended to by whichever lanes found the keys)
 #pragma unroll
   for (int m = 0; m < CS; ++m) K[m] = (m < nreg && m * 64 + lane < fill) ? buf[m * 64 + lane] : kEmptyKey;
   auto count_le = [&](unsigned long long T) {
@@ -365,10 +376,10 @@ __device__ __forceinline__ void cov_pick20(unsigned long long* buf, unsigned lon
       c_hi = cm;
     }
   }
-  // compact the passing keys, one per lane (the list is in registers: its first 64 entries are free again; one wave reads what
-  // it wrote itself -- no barrier, the LDS operations of a wave complete in order)
+  // compact the passing keys, one per lane (the list is in registers: its first 64 entries are free again)
   unsigned long long k = K[0];  // (a list of one register's length that passes whole is in place already)
   if (!(nreg == 1 && c_hi == fill)) {
+    wave_lds_handover();  // (every lane has its part of the list in registers before the buffer is written again)
     int base = 0;
 #pragma unroll
     for (int m = 0; m < CS; ++m)
@@ -377,6 +388,7 @@ __device__ __forceinline__ void cov_pick20(unsigned long long* buf, unsigned lon
         if (K[m] <= T) buf[base + __popcll(b & lane_lt)] = K[m];
         base += __popcll(b);
       }
+    wave_lds_handover();
     k = lane < c_hi ? buf[lane] : kEmptyKey;
   }
   int rank = 0;
@@ -390,6 +402,7 @@ __device__ __forceinline__ void cov_pick20(unsigned long long* buf, unsigned lon
   }
   for (int j = c8; j < c_hi; ++j) rank += buf[j] < k ? 1 : 0;
   if (lane < c_hi && rank < GK) top[rank] = k;
+  wave_lds_handover();  // (top[] is read by lanes 0..19 next: cov_emit)
   ranked = c_hi;
 }
 
@@ -415,6 +428,7 @@ __device__ __forceinline__ void cov_emit(const unsigned long long* top, double* 
     term[8 * GK + lane] = (double)(q.z * q.z);
   }
   double* sums = term + 9 * GK;  // [9]
+  wave_lds_handover();
   if (lane < 9) {
     const volatile double* v = term + lane * GK;  // (volatile: read in the order of use -- all twenty at once cost 40 registers)
     // a(l) = lane l's value after the xor-32 and xor-16 steps; then c(l) = a(l) + a(l + 8), d(l) = c(l) + c(l + 4),
@@ -425,6 +439,7 @@ __device__ __forceinline__ void cov_emit(const unsigned long long* top, double* 
     const double e1 = d(1) + d(3);
     sums[lane] = e0 + e1;
   }
+  wave_lds_handover();
   if (lane < 6) {
     // entry e = (row r, column c) of the upper triangle: (0,0) (1,0) (2,0) (1,1) (2,1) (2,2), second moments at sums[3 + e]
     const int r = lane == 0 ? 0 : (lane == 1 || lane == 3 ? 1 : 2), cidx = lane < 3 ? 0 : (lane < 5 ? 1 : 2);
