@@ -470,6 +470,7 @@ float threshold_from(double r2);
 // n <= 32 ints from device memory, queued behind everything the stream holds, into host_dst -- returns when they are there
 // (a posted kernel + a polled mailbox instead of hipMemcpyAsync + hipStreamSynchronize: icp_kernels.hip post_ints_kernel)
 int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst);
+int wait_posted(icpgpu_ctx* c, const volatile unsigned long long* box, int n, unsigned long long number, int* out, const char* what);
 unsigned long long sample_fingerprint(const float* xyzw, size_t n);
 int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, const int* d_extra = nullptr, int n_extra = 0, int* extra_out = nullptr);
 // The staging buffer as a target of kernels: at least `bytes` of pinned, mapped, coherent host memory (c->h_stage / h_stage_dev);

@@ -102,30 +102,29 @@ unsigned long long sample_fingerprint(const float* xyzw, size_t n) {
   return fp_finish(s, (unsigned long long)n);
 }
 
-int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst) {
-  if (n <= 0) return ICPGPU_OK;
-  if (n > 32) return fail(c, ICPGPU_ERR_INVALID_ARG, "fetch_ints: %d values", n);
-  const unsigned long long number = ++c->post_seq;
-  HIP_TRY(c, launch_post_ints(d_src, n, c->h_post_dev, wire_seq(c, number), c->stream));
+// Spin until the n result pairs at `box` (mapped host memory: post_ints_kernel's target) carry `number`, then hand their values out
+// (out may be null).  The stream is queried now and then so that a faulted kernel turns into an error instead of an endless wait,
+// and the clock so that a hung one does.  `what` names the thing waited for in those messages.
+int wait_posted(icpgpu_ctx* c, const volatile unsigned long long* box, int n, unsigned long long number, int* out, const char* what) {
   std::chrono::steady_clock::time_point t0;
   for (unsigned spins = 1;; ++spins) {
     bool all = true;
-    for (int k = 0; k < n && all; ++k) all = (c->h_post[2 * k + 1] >> 24) == number;
+    for (int k = 0; k < n && all; ++k) all = (box[2 * k + 1] >> 24) == number;
     if (all) {
       unsigned long long bits;
       for (int k = 0; k < n && all; ++k) {
-        all = mailbox_read(c->h_post + 2 * k, number, &bits);  // (a torn pair: looked at again)
-        if (all) host_dst[k] = (int)(unsigned int)bits;
+        all = mailbox_read(box + 2 * k, number, &bits);  // (a torn pair: looked at again)
+        if (all && out) out[k] = (int)(unsigned int)bits;
       }
       if (all) break;
     }
     if ((spins & 0x3FFu) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a device read-back: %s", hipGetErrorString(q));
+      if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for %s: %s", what, hipGetErrorString(q));
       const auto now = std::chrono::steady_clock::now();
       if (spins == 0x400u) t0 = now;
       else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
-        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a device read-back (hung kernel?)", wait_timeout_ms());
+        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for %s (hung kernel?)", wait_timeout_ms(), what);
     }
 #if defined(__x86_64__)
     __builtin_ia32_pause();
@@ -133,6 +132,14 @@ int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst) {
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return ICPGPU_OK;
+}
+
+int fetch_ints(icpgpu_ctx* c, const int* d_src, int n, int* host_dst) {
+  if (n <= 0) return ICPGPU_OK;
+  if (n > 32) return fail(c, ICPGPU_ERR_INVALID_ARG, "fetch_ints: %d values", n);
+  const unsigned long long number = ++c->post_seq;
+  HIP_TRY(c, launch_post_ints(d_src, n, c->h_post_dev, wire_seq(c, number), c->stream));
+  return wait_posted(c, c->h_post, n, number, host_dst, "a device read-back");
 }
 
 // Device -> caller's (pageable) host buffer through the context's PINNED staging buffer: the runtime's own pageable copy takes
@@ -183,34 +190,7 @@ int stage_post(icpgpu_ctx* c, const int* d_ints, int n_ints, StageTicket& tk) {
 int stage_wait(icpgpu_ctx* c, StageTicket& tk, int* ints_out) {
   if (!tk.issued) return fail(c, ICPGPU_ERR_INVALID_ARG, "stage_wait: nothing posted");
   tk.issued = false;
-  const volatile unsigned long long* box = c->h_post + 2 * kStagePostSlot;
-  const int n = tk.n_ints;
-  std::chrono::steady_clock::time_point t0;
-  for (unsigned spins = 1;; ++spins) {
-    bool all = true;
-    for (int k = 0; k < n && all; ++k) all = (box[2 * k + 1] >> 24) == tk.number;
-    if (all) {
-      unsigned long long bits;
-      for (int k = 0; k < n && all; ++k) {
-        all = mailbox_read(box + 2 * k, tk.number, &bits);
-        if (all && ints_out) ints_out[k] = (int)(unsigned int)bits;
-      }
-      if (all) break;
-    }
-    if ((spins & 0x3FFu) == 0) {
-      const hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a staged cloud: %s", hipGetErrorString(q));
-      const auto now = std::chrono::steady_clock::now();
-      if (spins == 0x400u) t0 = now;
-      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
-        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a staged cloud (hung kernel?)", wait_timeout_ms());
-    }
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  return ICPGPU_OK;
+  return wait_posted(c, c->h_post + 2 * kStagePostSlot, tk.n_ints, tk.number, ints_out, "a staged cloud");
 }
 
 int copy_to_host(icpgpu_ctx* c, void* dst, const void* d_src, size_t bytes, const int* d_extra, int n_extra, int* extra_out) {

@@ -140,34 +140,11 @@ int ensure_covariances(icpgpu_ctx* c, const Cloud& cloud, uint64_t version, Grid
 int covariance_grid_check(icpgpu_ctx* c) {
   if (!c->spec_grid.pending) return 0;
   c->spec_grid.pending = false;
-  const unsigned long long number = c->spec_grid.number;
-  const volatile unsigned long long* box = c->h_post + 2 * 32;
   int v[kGridStatInts];
-  std::chrono::steady_clock::time_point t0;
-  for (unsigned spins = 1;; ++spins) {
-    bool all = true;
-    for (int k = 0; k < kGridStatInts && all; ++k) all = (box[2 * k + 1] >> 24) == number;
-    if (all) {
-      unsigned long long bits;
-      for (int k = 0; k < kGridStatInts && all; ++k) {
-        all = mailbox_read(box + 2 * k, number, &bits);
-        if (all) v[k] = (int)(unsigned int)bits;
-      }
-      if (all) break;
-    }
-    if ((spins & 0x3FFu) == 0) {
-      const hipError_t q = hipStreamQuery(c->stream);
-      if (q != hipSuccess && q != hipErrorNotReady) return fail(c, ICPGPU_ERR_HIP, "HIP error while waiting for a grid's statistics: %s", hipGetErrorString(q));
-      const auto now = std::chrono::steady_clock::now();
-      if (spins == 0x400u) t0 = now;
-      else if (std::chrono::duration<double, std::milli>(now - t0).count() > wait_timeout_ms())
-        return fail(c, ICPGPU_ERR_HIP, "timed out after %.0f ms waiting for a grid's statistics (hung kernel?)", wait_timeout_ms());
-    }
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
+  {
+    const int wrc = wait_posted(c, c->h_post + 2 * 32, kGridStatInts, c->spec_grid.number, v, "a grid's statistics");
+    if (wrc) return wrc;
   }
-  std::atomic_thread_fence(std::memory_order_acquire);
   unsigned long long sumsq = 0;
   std::memcpy(&sumsq, v + 2, sizeof sumsq);
   const int max_pop = v[1], binned = v[4];
