@@ -56,8 +56,8 @@ BATCH_PAIRS_PER_RANK = BATCH_TOTAL_PAIRS_AT_8 // 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 50 (pair workloads) / 5 (batch50k)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 10 (pair workloads) / 2 (batch50k)")
+    ap.add_argument("--steps", type=int, default=None, help="default 50 (pair workloads) / 10 (batch50k)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 10 (pair workloads) / 4 (batch50k)")
     ap.add_argument("--workload", default="200kx200k", choices=sorted(WORKLOADS))
     ap.add_argument("--iters", type=int, default=10, help="ICP iterations per scan pair (forced for the pair workloads)")
     ap.add_argument("--nn", default="auto", choices=["auto", "brute", "grid"],
@@ -75,10 +75,13 @@ def parse():
     ap.add_argument("--secondary-scans", type=int, default=50, help="scans in each secondary (e2e / GICP / pipeline) loop")
     a = ap.parse_args()
     batch = WORKLOADS[a.workload][2] == "batch"
+    # (batch50k: the workers' buffers settle over the first few calls -- a call with reallocations takes 18-32 ms instead of 12.5 --
+    #  and five timed steps behind two warm-up calls caught one or two of those on some boxes: 3.9-4.2k pairs/s where twenty steps
+    #  behind three say 5.1k, round 6)
     if a.steps is None:
-        a.steps = 5 if batch else 50
+        a.steps = 10 if batch else 50
     if a.warmup is None:
-        a.warmup = 2 if batch else 10
+        a.warmup = 4 if batch else 10
     return a
 
 
