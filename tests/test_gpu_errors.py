@@ -200,3 +200,38 @@ def test_callers_with_shorter_and_longer_structs(built):
                 assert np.array_equal(np.array(r.T, np.float32).reshape(4, 4).T, ref["T"]) and r.fitness == ref["fitness"]
         finally:
             assert L.icpgpu_destroy(h) == 0
+
+
+def test_view_entry_points_keep_the_error_convention():
+    """icpgpu.h 1.1's icpgpu_align_view / icpgpu_voxel_grid_view: the same status codes as the calls they shadow, null outputs refused, the
+    view pointer null and the count zero after a failure and for an empty result -- and the context works afterwards."""
+    from icpslam_amd import Context
+    L = _lib.load()
+    FP = C.POINTER(C.c_float)
+    with Context(0) as ctx:
+        view, n = FP(), C.c_size_t(7)
+        res = _lib.Result()
+        assert L.icpgpu_align_view(ctx._h, None, 1, C.byref(res), C.byref(view), C.byref(n)) == ERR_NO_INPUT   # nothing set yet
+        assert not view and n.value == 0
+        src, tgt, _ = synth.make_pair(3000, 3000, seed=1)
+        ctx.set_source(src)
+        ctx.set_target(tgt)
+        assert L.icpgpu_align_view(ctx._h, None, 1, None, C.byref(view), C.byref(n)) == ERR_INVALID_ARG
+        assert L.icpgpu_align_view(ctx._h, None, 1, C.byref(res), None, C.byref(n)) == ERR_INVALID_ARG
+        assert L.icpgpu_align_view(ctx._h, None, 1, C.byref(res), C.byref(view), None) == ERR_INVALID_ARG
+        cloud = np.ascontiguousarray(src)
+        p = cloud.ctypes.data_as(FP)
+        assert L.icpgpu_voxel_grid_view(ctx._h, p, 3000, C.c_float(0.0), C.byref(view), C.byref(n)) == ERR_INVALID_ARG   # leaf
+        assert not view and n.value == 0
+        assert L.icpgpu_voxel_grid_view(ctx._h, None, 3000, C.c_float(0.2), C.byref(view), C.byref(n)) == ERR_INVALID_ARG
+        assert L.icpgpu_voxel_grid_view(ctx._h, p, 3000, C.c_float(0.2), None, C.byref(n)) == ERR_INVALID_ARG
+        assert L.icpgpu_voxel_grid_view(ctx._h, p, 0, C.c_float(0.2), C.byref(view), C.byref(n)) == 0 and not view and n.value == 0
+        # an empty source: aligned "cloud" of zero points, no view
+        ctx.set_source(np.empty((0, 4), np.float32))
+        assert L.icpgpu_align_view(ctx._h, None, 0, C.byref(res), C.byref(view), C.byref(n)) == 0 and not view and n.value == 0
+        # ... and the context still works: filtered view, then an alignment whose cloud comes back as a view
+        got = ctx.voxel_grid_view(src, 0.5)
+        assert 0 < len(got) < len(src)
+        ctx.set_source(src)
+        r = ctx.align_view(want_fitness=True)
+        assert r["converged"] and r["cloud"].shape == src.shape and np.isfinite(r["fitness"])
