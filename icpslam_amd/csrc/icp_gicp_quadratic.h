@@ -39,6 +39,10 @@ struct QuadForm {
   double cq_hi, cq_lo;
   double m, d2;
   double B[3][4];  // base, row-major 3x4, the float entries as doubles
+  // the same A, laid out for quad_form_sums: [k = e' * 3 + d][j = e * 3 + c] -- step k of the twelve accumulators G[e][c] reads
+  // twelve consecutive numbers (round 6: the accumulators advance together as vectors)
+  alignas(32) double Vh[12][12], Vl[12][12], Vlo[12][12];
+  alignas(32) double nBq_hi[12], nBq_lo[12];  // -Bq[e][c] at j = e * 3 + c
 };
 
 namespace quad_detail {
@@ -94,6 +98,17 @@ inline void quad_form_load(QuadForm& Q, const double* sums, const float base16[1
       Q.Bq_hi[e][c] = sums[2 * (60 + e * 3 + c)];
       Q.Bq_lo[e][c] = sums[2 * (60 + e * 3 + c) + 1];
     }
+  for (int e = 0; e < 4; ++e)
+    for (int c = 0; c < 3; ++c) {
+      for (int f = 0; f < 4; ++f)
+        for (int d = 0; d < 3; ++d) {
+          Q.Vh[f * 3 + d][e * 3 + c] = Q.Ah[e][f][c][d];
+          Q.Vl[f * 3 + d][e * 3 + c] = Q.Al[e][f][c][d];
+          Q.Vlo[f * 3 + d][e * 3 + c] = Q.Alo[e][f][c][d];
+        }
+      Q.nBq_hi[e * 3 + c] = -Q.Bq_hi[e][c];
+      Q.nBq_lo[e * 3 + c] = -Q.Bq_lo[e][c];
+    }
   Q.cq_hi = sums[2 * 72];
   Q.cq_lo = sums[2 * 72 + 1];
   Q.m = sums[2 * 73] + sums[2 * 73 + 1];
@@ -104,21 +119,53 @@ inline void quad_form_load(QuadForm& Q, const double* sums, const float base16[1
 
 // The 15 numbers eval_from_sums consumes (icp_gicp_solver_impl.h), at the float matrix T16 (column-major, after apply_state):
 // s[0] = m, s[1] = sum r^T M r, s[2..4] = sum M r, s[5..13] = sum (base p)(M r)^T (row-major), s[14] = sum d2
-inline void quad_form_sums(const QuadForm& Q, const float T16[16], double* s) {
+__attribute__((always_inline)) inline void quad_form_sums(const QuadForm& Q, const float T16[16], double* s) {
   using namespace quad_detail;
   double T[3][4];
   for (int d = 0; d < 3; ++d)
     for (int e = 0; e < 4; ++e) T[d][e] = (double)T16[e * 4 + d];
   DD G[4][3];  // G[e][c] - Bq[e][c] folded in at the end
-  for (int e = 0; e < 4; ++e)
-    for (int c = 0; c < 3; ++c) {
-      DD acc{0.0, 0.0};
-      for (int f = 0; f < 4; ++f)
-        for (int d = 0; d < 3; ++d) dd_fma_split(acc, Q.Ah[e][f][c][d], Q.Al[e][f][c][d], Q.Alo[e][f][c][d], T[d][f]);
-      dd_add(acc, -Q.Bq_hi[e][c], -Q.Bq_lo[e][c]);
-      dd_renorm(acc);
-      G[e][c] = acc;
+  {
+    // The twelve accumulators take the SAME twelve steps (k = e' * 3 + d, in that order) on different numbers: they advance
+    // together as three 4-wide vectors -- element-wise IEEE operations, no contraction: the bits of the scalar loop
+    // (dd_fma_split, dd_add, dd_renorm above, operation for operation), a third of its instructions and its dependent chains.
+    typedef double v4 __attribute__((vector_size(32)));
+    v4 hi[3], lo[3];
+    for (int v = 0; v < 3; ++v) hi[v] = lo[v] = v4{0.0, 0.0, 0.0, 0.0};
+    for (int f = 0; f < 4; ++f)
+      for (int d = 0; d < 3; ++d) {
+        const int k = f * 3 + d;
+        const double ts = T[d][f];
+        const v4 t = {ts, ts, ts, ts};
+        for (int v = 0; v < 3; ++v) {
+          const v4 h = *reinterpret_cast<const v4*>(&Q.Vh[k][4 * v]), l = *reinterpret_cast<const v4*>(&Q.Vl[k][4 * v]),
+                   ll = *reinterpret_cast<const v4*>(&Q.Vlo[k][4 * v]);
+          const v4 b = h * t;                    // dd_fma_split: two_sum(acc.hi, h * t)
+          const v4 s2 = hi[v] + b;
+          const v4 bb = s2 - hi[v];
+          const v4 e = (hi[v] - (s2 - bb)) + (b - bb);
+          hi[v] = s2;
+          lo[v] += e + (l * t + ll * t);
+        }
+      }
+    for (int v = 0; v < 3; ++v) {
+      const v4 bh = *reinterpret_cast<const v4*>(&Q.nBq_hi[4 * v]), bl = *reinterpret_cast<const v4*>(&Q.nBq_lo[4 * v]);
+      v4 s2 = hi[v] + bh;                        // dd_add(acc, -Bq_hi, -Bq_lo)
+      v4 bb = s2 - hi[v];
+      v4 e = (hi[v] - (s2 - bb)) + (bh - bb);
+      hi[v] = s2;
+      lo[v] += e + bl;
+      s2 = hi[v] + lo[v];                        // dd_renorm
+      bb = s2 - hi[v];
+      e = (hi[v] - (s2 - bb)) + (lo[v] - bb);
+      hi[v] = s2;
+      lo[v] = e;
+      for (int u = 0; u < 4; ++u) {
+        const int j = 4 * v + u;
+        G[j / 3][j % 3] = DD{hi[v][u], lo[v][u]};
+      }
     }
+  }
   s[0] = Q.m;
   s[14] = Q.d2;
   for (int c = 0; c < 3; ++c) s[2 + c] = G[3][c].hi + G[3][c].lo;

@@ -31,6 +31,15 @@ GicpSolve gicp_minimize(const GicpEvalFn& eval, Vec6& x, int max_inner, double g
 
 
 namespace {
+// quad_form_sums for the CPU this process runs on: the twelve accumulators of its main loop are vectors of four doubles
+// (icp_gicp_quadratic.h) -- two SSE2 halves on the baseline target, one AVX2 register where the CPU has them; element-wise IEEE
+// operations without contraction either way, so both clones return the same bits (the host's share of a scan in the quadratic mode
+// is ~40 such evaluations per outer iteration).
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+void quad_sums_for_this_cpu(const gicp::QuadForm& Q, const float* T, double* s) { gicp::quad_form_sums(Q, T, s); }
+
 struct QuadEval {
   const gicp::QuadForm& Q;
   const float* base16;
@@ -41,7 +50,7 @@ struct QuadEval {
     const gicp::Trig6 tr = gicp::trig6(x);
     gicp::apply_state(T, x, tr);
     double s[15];
-    gicp::quad_form_sums(Q, T, s);
+    quad_sums_for_this_cpu(Q, T, s);
     gicp::eval_from_sums(tr, s, out);
     ++evaluations;
     return true;
