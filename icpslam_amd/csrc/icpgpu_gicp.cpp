@@ -287,26 +287,42 @@ static void gicp_server_stop(icpgpu_ctx* c) {
 
 // 0: the flags arrived; 1: the stream went idle without them (the server gave up waiting); < 0: error
 // What a block publishes (icp_kernels.h: four answer lines of seven values + a tag): m, the 13 sums' high parts, sum d2, their low parts.
-static bool gicp_tags_ready(const volatile double* mailbox, int n_blocks, unsigned long long seq) {
-  const volatile unsigned long long* w0 = reinterpret_cast<const volatile unsigned long long*>(mailbox);
+// (round 6: a line's seven folds are taken four words at a time -- vectors of four 64-bit words, an AVX2 clone where the CPU has it --
+//  and every line is looked at before the verdict: 0.37 -> 0.23 us for an evaluation's 92 lines on the development box, the same
+//  decisions on 20 000 random mailboxes, torn and stale lines among them; this runs once per dependent evaluation, right after its
+//  last answer has arrived)
+typedef unsigned long long gicp_u4 __attribute__((vector_size(32)));
+__attribute__((always_inline)) static inline bool gicp_tags_ready_body(const double* mailbox, int n_blocks, unsigned long long seq) {
+  asm volatile("" ::: "memory");  // the device writes these lines: every call reads them anew
+  const unsigned long long* w0 = reinterpret_cast<const unsigned long long*>(mailbox);
   // the numbers first (one compare per line, four lines per workgroup: this loop runs thousands of times per scan), the checksums
   // only once every line carries the number.  The pass over the numbers has NO early exit: the device's writes invalidate the
   // host's cached copies of these lines, and a loop that leaves at the first stale line fetches them one miss after the other
   // -- without the branch the loads are independent and the misses overlap.
   unsigned long long stale = 0;
-  const volatile unsigned long long* w = w0;
+  const unsigned long long* w = w0;
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
     for (int L = 0; L < kGicpLines; ++L) stale |= (w[8 * L + 7] >> 24) ^ seq;
   if (stale) return false;
   w = w0;
+  unsigned long long bad = 0;  // (a torn line: looked at again on the next poll)
+  const gicp_u4 mask = {0xFFFFFFull, 0xFFFFFFull, 0xFFFFFFull, 0xFFFFFFull}, values3 = {~0ull, ~0ull, ~0ull, 0ull};
   for (int b = 0; b < n_blocks; ++b, w += kGicpPartialStride)
     for (int L = 0; L < kGicpLines; ++L) {
-      unsigned long long x = 0;
-      for (int k = 0; k < 7; ++k) x ^= gicp_line_fold(w[8 * L + k]);
-      if (w[8 * L + 7] != ((seq << 24) | x)) return false;  // a torn line: looked at again on the next poll
+      gicp_u4 lo4, hi4;
+      __builtin_memcpy(&lo4, w + 8 * L, 32);
+      __builtin_memcpy(&hi4, w + 8 * L + 4, 32);
+      const unsigned long long tag = hi4[3];
+      hi4 &= values3;  // (the fold of zero is zero)
+      const gicp_u4 f = ((lo4 ^ (lo4 >> 24) ^ (lo4 >> 48)) ^ (hi4 ^ (hi4 >> 24) ^ (hi4 >> 48))) & mask;  // gicp_line_fold, word by word
+      bad |= tag ^ ((seq << 24) | (f[0] ^ f[1] ^ f[2] ^ f[3]));
     }
-  return true;
+  return bad == 0;
 }
+#if defined(__x86_64__) && defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("avx2", "default")))
+#endif
+static bool gicp_tags_ready(const double* mailbox, int n_blocks, unsigned long long seq) { return gicp_tags_ready_body(mailbox, n_blocks, seq); }
 // 0 = all entries of evaluation `seq` are there, 1 = the stream went idle without them (the server gave up), < 0 = error
 static int wait_gicp_tags(icpgpu_ctx* c, int n_blocks, unsigned long long seq, bool server) {
   std::chrono::steady_clock::time_point t0;
