@@ -1849,7 +1849,11 @@ int gicp_direct_blocks(int n_s, int most) {
   }();
   static const int per_block = [] {  // ICPGPU_GICP_PER_BLOCK (tuning): correspondences per workgroup of 256 lanes
     const char* e = ICPGPU_DEV_ENV("ICPGPU_GICP_PER_BLOCK");
-    const int v = e ? std::atoi(e) : 1024;
+    // 512 since round 6 (1024 before): two correspondences per lane halve a workgroup's accumulation (1.3 us of an evaluation's ~6),
+    // and twice the answer lines cost the host little now that it validates and merges them as vectors -- the alignment stage of a
+    // pipeline scan 1.24 -> 1.15 ms (256: 1.25, 384: 1.17, 640: 1.19, 768: 1.25; scripts/r6/perblock.sh).  The sums do not depend on
+    // the split: they are exact sums rounded once.
+    const int v = e ? std::atoi(e) : 512;
     return v < 256 ? 256 : (v > 4096 ? 4096 : v);
   }();
   int blocks = (n_s + per_block - 1) / per_block;
